@@ -1,0 +1,189 @@
+"""ctypes binding of oracle/liboracle.so -- the CPU checker (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+The shipped package (osmo_trx_amd/) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
+
+# CorrType (sigProcLib.h:30-38)
+OFF, TSC, EXT_RACH, RACH, SCH, EDGE, IDLE = range(7)
+SIGERR_NONE, SIGERR_BOUNDS, SIGERR_CLIP, SIGERR_UNSUPPORTED, SIGERR_INTERNAL = range(5)
+
+
+class CorrSeq(C.Structure):
+    _fields_ = [("n", C.c_int), ("seq", C.c_float * 128), ("gain", C.c_float * 2), ("toa", C.c_float)]
+
+
+class Tables(C.Structure):
+    _fields_ = [
+        ("sinc_table", C.c_float * 1025),
+        ("rot1", C.c_float * 314), ("rrot1", C.c_float * 314),
+        ("rot4", C.c_float * 1250), ("rrot4", C.c_float * 1250),
+        ("pulse1_c0", C.c_float * 4), ("pulse4_c0", C.c_float * 16), ("pulse4_c1", C.c_float * 8),
+        ("c0_inv", C.c_float * 5),
+        ("midamble", CorrSeq * 8), ("edge_midamble", CorrSeq * 8), ("rach", CorrSeq * 3),
+        ("sch", CorrSeq), ("dummy", CorrSeq),
+        ("delay_filt", (C.c_float * 20) * 64),
+        ("dec_taps", C.c_float * 16),
+    ]
+
+
+class Ebp(C.Structure):
+    _fields_ = [("amp", C.c_float * 2), ("toa", C.c_float), ("tsc", C.c_uint8), ("ci", C.c_float)]
+
+
+PARAMS_DTYPE = np.dtype([("type", "u1"), ("tsc", "u1"), ("max_toa", "<u2"), ("reserved", "<u4")])
+RESULT_DTYPE = np.dtype([
+    ("rc", "<i4"), ("toa", "<f4"), ("amp_re", "<f4"), ("amp_im", "<f4"), ("ci", "<f4"),
+    ("energy", "<f4"), ("rssi", "<f4"), ("tsc", "u1"), ("clip", "u1"), ("idle", "u1"), ("nbits_div4", "u1"),
+])
+assert PARAMS_DTYPE.itemsize == 8 and RESULT_DTYPE.itemsize == 32
+
+
+def build(force=False):
+    """Compile oracle/liboracle.so (and oracle/_ref when /root/reference is present)."""
+    src = os.path.join(ORACLE_DIR, "trx_oracle.c")
+    stale = (not os.path.exists(LIB_PATH)) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src)
+    if force or stale:
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    if os.path.isdir("/root/reference/Transceiver52M") and not os.path.exists(
+            os.path.join(ORACLE_DIR, "_ref", "libref_generic.so")):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "ref"], stdout=subprocess.DEVNULL)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(LIB_PATH)
+    fp = C.POINTER(C.c_float)
+    L.orc_setup.restype = C.c_int
+    L.orc_get_tables.restype = C.POINTER(Tables)
+    for f in (L.orc_convolve_real, L.orc_convolve_complex):
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.orc_convert_short_float.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.orc_convert_float_short.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int]
+    L.orc_energy_detect.restype = C.c_float
+    L.orc_energy_detect.argtypes = [C.c_void_p, C.c_int, C.c_uint]
+    L.orc_vector_slicer.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.orc_delay_vector.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p]
+    L.orc_detect_any_burst.restype = C.c_int
+    L.orc_detect_any_burst.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_float, C.c_int, C.c_int, C.c_uint,
+                                       C.POINTER(Ebp)]
+    L.orc_demod_any_burst.restype = C.c_int
+    L.orc_demod_any_burst.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(Ebp), C.c_void_p]
+    L.orc_modulate_burst.restype = C.c_int
+    L.orc_modulate_burst.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.orc_modulate_edge_burst.restype = C.c_int
+    L.orc_modulate_edge_burst.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.orc_pull_batch.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_double,
+                                 C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.orc_trxd_toa256.restype = C.c_int
+    L.orc_trxd_toa256.argtypes = [C.c_double]
+    L.orc_trxd_ci_cb.restype = C.c_int16
+    L.orc_trxd_ci_cb.argtypes = [C.c_float]
+    L.orc_trxd_soft_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
+    L.orc_resampler_new.restype = C.c_void_p
+    L.orc_resampler_new.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float]
+    L.orc_resampler_free.argtypes = [C.c_void_p]
+    L.orc_resampler_partition.restype = fp
+    L.orc_resampler_partition.argtypes = [C.c_void_p, C.c_int]
+    L.orc_resampler_rotate.restype = C.c_int
+    L.orc_resampler_rotate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    L.orc_channelizer_new.restype = C.c_void_p
+    L.orc_channelizer_new.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.orc_channelizer_free.argtypes = [C.c_void_p]
+    L.orc_channelizer_subfilter.restype = fp
+    L.orc_channelizer_subfilter.argtypes = [C.c_void_p, C.c_int]
+    L.orc_channelizer_rotate.restype = C.c_int
+    L.orc_channelizer_rotate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.orc_setup()
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def tables():
+    """Oracle tables as a dict of numpy arrays (complex tables as complex64)."""
+    t = lib().orc_get_tables().contents
+
+    def cx(a):
+        return np.frombuffer(bytes(a), dtype=np.complex64).copy()
+
+    def seq(s):
+        return {"n": s.n, "seq": cx(s.seq)[: s.n], "gain": complex(s.gain[0], s.gain[1]), "toa": float(s.toa)}
+
+    return {
+        "sinc_table": np.array(t.sinc_table, dtype=np.float32),
+        "rot1": cx(t.rot1), "rrot1": cx(t.rrot1), "rot4": cx(t.rot4), "rrot4": cx(t.rrot4),
+        "pulse1_c0": np.array(t.pulse1_c0, dtype=np.float32),
+        "pulse4_c0": np.array(t.pulse4_c0, dtype=np.float32),
+        "pulse4_c1": np.array(t.pulse4_c1, dtype=np.float32),
+        "c0_inv": np.array(t.c0_inv, dtype=np.float32),
+        "midamble": [seq(s) for s in t.midamble],
+        "edge_midamble": [seq(s) for s in t.edge_midamble],
+        "rach": [seq(s) for s in t.rach],
+        "sch": seq(t.sch), "dummy": seq(t.dummy),
+        "delay_filt": np.array([list(r) for r in t.delay_filt], dtype=np.float32),
+        "dec_taps": np.array(t.dec_taps, dtype=np.float32),
+    }
+
+
+def detect_any_burst(burst, tsc, threshold, sps, ctype, max_toa):
+    """burst: complex64[n].  Returns (rc, dict(amp, toa, tsc, ci))."""
+    b = np.ascontiguousarray(burst, dtype=np.complex64)
+    e = Ebp()
+    rc = lib().orc_detect_any_burst(_ptr(b), len(b), tsc, threshold, sps, ctype, max_toa, C.byref(e))
+    return rc, e
+
+
+def demod_any_burst(burst, ctype, sps, ebp):
+    b = np.ascontiguousarray(burst, dtype=np.complex64)
+    soft = np.zeros(448, dtype=np.float32)
+    n = lib().orc_demod_any_burst(_ptr(b), len(b), ctype, sps, C.byref(ebp), _ptr(soft))
+    return soft[:max(n, 0)].copy()
+
+
+def pull_batch(iq, sps, params, threshold=4.0, full_scale=32767.0, soft_stride=148, slice_bits=True):
+    """iq: int16[n, burst_len, 2]; params: PARAMS_DTYPE[n]. Returns (RESULT_DTYPE[n], float32[n, soft_stride])."""
+    iq = np.ascontiguousarray(iq, dtype=np.int16)
+    n, burst_len = iq.shape[0], iq.shape[1]
+    params = np.ascontiguousarray(params, dtype=PARAMS_DTYPE)
+    res = np.zeros(n, dtype=RESULT_DTYPE)
+    soft = np.zeros((n, soft_stride), dtype=np.float32)
+    lib().orc_pull_batch(_ptr(iq), n, burst_len, sps, _ptr(params), threshold, full_scale,
+                         _ptr(res), _ptr(soft), soft_stride, 1 if slice_bits else 0)
+    return res, soft
+
+
+def modulate_burst(bits, guard, sps, empty=False):
+    bits = np.ascontiguousarray(bits, dtype=np.uint8)
+    out = np.zeros(700, dtype=np.complex64)
+    n = lib().orc_modulate_burst(_ptr(bits), len(bits), guard, sps, int(empty), _ptr(out))
+    return out[:n].copy()
+
+
+def convolve(x, h, start, length, complex_taps):
+    """x: complex64 (may need history before `start`), h: complex64 taps."""
+    x = np.ascontiguousarray(x, dtype=np.complex64)
+    h = np.ascontiguousarray(h, dtype=np.complex64)
+    y = np.zeros(length, dtype=np.complex64)
+    f = lib().orc_convolve_complex if complex_taps else lib().orc_convolve_real
+    f(_ptr(x), len(x), _ptr(h), len(h), _ptr(y), len(y), start, length)
+    return y

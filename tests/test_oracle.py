@@ -1,0 +1,186 @@
+"""CPU tests: pin the oracle (oracle/trx_oracle.c) against everything the reference holds for the path.
+
+  * the reference's own known-answer vectors (tests/Transceiver52M/convolve_test_golden.h -> convolve_golden.npz)
+    with the test's LCG inputs restated (convolve_test.c:15-45) and its tolerance (1e-5 abs OR rel, :76-96)
+  * outputs of the reference's arch kernels + Resampler compiled unmodified (oracle/_ref -> ref_arch_vectors.npz):
+    bit-exact vs the generic-C build, <=1e-5 vs the SSE build
+  * the reference's captured burst + known-good bits (utils/va-test)
+  * the anchor values the survey dumped from the compiled reference
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+
+# ---- reference test's input generator, convolve_test.c:15-45 ----
+def lcg_floats(n, state=0):
+    out = np.zeros(n, dtype=np.float32)
+    u32 = np.zeros(1, dtype=np.uint32)
+    for i in range(n):
+        state = (1103515245 * state + 12345) & 0x7FFFFFFF
+        u = state
+        e = 112 + ((u ^ (u >> 8)) & 15)
+        r = (u & 0x007FFFFF) | ((u & 0x00800000) << 8) | ((e & 0xFF) << 23)
+        u32[0] = r
+        out[i] = u32.view(np.float32)[0]
+    return out, state
+
+
+def ref_close(a, b, delta=1e-5, eps=1e-5):
+    """compare_floats(), convolve_test.c:76-96"""
+    a = np.asarray(a, dtype=np.float32)
+    b = np.asarray(b, dtype=np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ok = (np.abs(a - b) < delta) | (np.abs(1.0 - a / b) < eps)
+    return bool(ok.all())
+
+
+@pytest.mark.parametrize("h_len", [4, 8, 12, 16, 20, 24])
+@pytest.mark.parametrize("kind", ["real", "complex"])
+def test_convolve_reference_known_answer(golden_dir, h_len, kind):
+    g = np.load(os.path.join(golden_dir, "convolve_golden.npz"))
+    x, st = lcg_floats(200)
+    h, _ = lcg_floats(50, st)
+    start, ln = h_len - 1, 100 - (h_len - 1)
+    y = O.convolve(x.view(np.complex64), h.view(np.complex64)[:h_len], start, ln, kind == "complex")
+    ref = g[f"y_ref_{kind}_base_{h_len}"]
+    assert len(ref) == 2 * ln
+    assert ref_close(ref, y.view(np.float32))
+
+
+@pytest.mark.parametrize("h_len", [1, 4, 5, 8, 12, 16, 20, 24, 40, 64])
+@pytest.mark.parametrize("kind", ["real", "complex"])
+def test_convolve_vs_compiled_reference(golden_dir, h_len, kind):
+    v = np.load(os.path.join(golden_dir, "ref_arch_vectors.npz"))
+    x = v["x"].view(np.complex64)
+    h = v[f"h_{h_len}"].view(np.complex64)
+    start, ln = h_len - 1, 700 - (h_len - 1)
+    y = O.convolve(x, h, start, ln, kind == "complex").view(np.float32)
+    # generic-C build of the reference: same operand order -> bit-exact
+    assert np.array_equal(y, v[f"y_generic_{kind}_{h_len}"])
+    # SSE build: different summation order, reference's own tolerance scaled to the data
+    ref = v[f"y_sse_{kind}_{h_len}"]
+    assert np.max(np.abs(y - ref)) <= 1e-5 * np.max(np.abs(ref))
+
+
+def test_convert_short_float(golden_dir):
+    v = np.load(os.path.join(golden_dir, "ref_arch_vectors.npz"))
+    s = v["cvt_in"]
+    out = np.zeros(len(s), dtype=np.float32)
+    O.lib().orc_convert_short_float(out.ctypes.data, s.ctypes.data, len(s))
+    assert np.array_equal(out, v["cvt_generic"])
+    assert np.array_equal(out, v["cvt_sse"])
+
+
+def test_decimator_matches_reference_resampler(golden_dir):
+    v = np.load(os.path.join(golden_dir, "ref_arch_vectors.npz"))
+    L = O.lib()
+    r = L.orc_resampler_new(1, 4, 16, 1.0)
+    buf = np.ascontiguousarray(v["dec4_in"])
+    y = np.zeros(2 * 156, dtype=np.float32)
+    L.orc_resampler_rotate(r, buf[32:].ctypes.data, 624, y.ctypes.data, 156)
+    assert np.array_equal(y, v["dec4_generic"])
+    assert np.max(np.abs(y - v["dec4_sse"])) <= 1e-5 * np.max(np.abs(y))
+    # impulse at input 300 -> out[i] = g[315-4i]: exposes the reversed partition taps
+    imp = v["dec4_impulse_generic"].view(np.complex64)
+    taps = O.tables()["dec_taps"]
+    for i in range(75, 79):
+        assert imp[i].real == taps[315 - 4 * i]
+    L.orc_resampler_free(r)
+
+
+def test_resampler_65_48_matches_reference(golden_dir):
+    v = np.load(os.path.join(golden_dir, "ref_arch_vectors.npz"))
+    L = O.lib()
+    r = L.orc_resampler_new(65, 48, 16, 1.0)
+    buf = np.ascontiguousarray(v["rs6548_in"])
+    y = np.zeros(2 * 260, dtype=np.float32)
+    L.orc_resampler_rotate(r, buf[32:].ctypes.data, 192, y.ctypes.data, 260)
+    assert np.array_equal(y, v["rs6548_generic"])
+    assert np.max(np.abs(y - v["rs6548_sse"])) <= 1e-5 * np.max(np.abs(y))
+    L.orc_resampler_free(r)
+
+
+# ---- values dumped from the compiled reference (SSE build) ----
+def test_table_anchors():
+    t = O.tables()
+    gains = [(14.958575, 0.003145), (14.871485, -0.014816), (14.876348, -0.075098), (14.888629, -0.075098),
+             (14.943010, 0.055678), (14.956352, -0.048295), (15.077748, 0.012211), (15.067246, 0.084153)]
+    toas = [-1, -1, -1, -1, 1, 1, 1, -1]
+    for i in range(8):
+        m = t["midamble"][i]
+        assert m["n"] == 16
+        assert abs(m["gain"].real - gains[i][0]) < 3e-6 and abs(m["gain"].imag - gains[i][1]) < 3e-6
+        assert m["toa"] == toas[i] / 512.0
+    rach = [((35.715374, 0.155127), -0.005859), ((35.396175, -0.272141), -0.009766), ((35.331802, 0.108754), -0.005859)]
+    for i in range(3):
+        m = t["rach"][i]
+        assert m["n"] == 40
+        assert abs(m["gain"].real - rach[i][0][0]) < 1e-5 and abs(m["gain"].imag - rach[i][0][1]) < 1e-5
+        assert abs(m["toa"] - rach[i][1]) < 1e-6
+    assert t["sch"]["n"] == 64
+    assert abs(t["sch"]["gain"].real - 57.088936) < 3e-5 and abs(t["sch"]["gain"].imag + 0.002823) < 1e-5
+    assert abs(t["sch"]["toa"] + 0.009766) < 1e-6
+    assert abs(t["dummy"]["gain"].real - 13.659099) < 3e-6 and t["dummy"]["toa"] == 1 / 512.0
+    for i in range(8):
+        g = t["edge_midamble"][i]["gain"]
+        assert abs(g.real + 16.646780) < 2e-6 and abs(g.imag - 16.525934) < 2e-6
+    s = t["midamble"][0]["seq"]
+    assert s[0] == complex(-1, 0) and abs(s[1] - complex(6.12e-17, -1)) < 1e-18 and s[2].real == 1.0
+    np.testing.assert_allclose(t["pulse1_c0"], [0.0052078, 0.7070876, 0.7070876, 0.0052078], atol=5e-8)
+    dec = [-0.0000011, -0.0001773, -0.0015542, -0.0030354, 0.0101529, 0.0666594, 0.1694168, 0.2585389]
+    np.testing.assert_allclose(t["dec_taps"][:8], dec, atol=5e-8)
+    np.testing.assert_array_equal(t["dec_taps"][:8], t["dec_taps"][::-1][:8])
+    assert abs(float(t["dec_taps"].astype(np.float64).sum()) - 1.0) < 1e-6
+    df0 = t["delay_filt"][0]
+    assert df0[9] == 1.0 and np.all(np.abs(np.delete(df0, 9)) < 1e-15)
+    df32 = [0, -0.000091, 0.000668, -0.002866, 0.009240, -0.024902, 0.060830, -0.151246, 0.588012, 0.667994,
+            -0.222665, 0.117602, -0.064820, 0.033794, -0.015847, 0.006397, -0.002102, 0, 0, 0]
+    np.testing.assert_allclose(t["delay_filt"][32], df32, atol=6e-7)
+    st = t["sinc_table"]
+    assert st[0] == 1.0 and abs(st[1] - 0.9998996) < 5e-8 and abs(st[128]) < 1e-15 and abs(st[1023] + 0.0009774) < 5e-8
+    rr = t["rrot1"]
+    assert rr[0] == 1 and abs(rr[1] - complex(6.12e-17, -1)) < 1e-18 and rr[2].real == -1 and rr[3].imag == 1
+
+
+def test_captured_burst_known_answer(golden_dir):
+    """burst-gen.cpp:256-290: detectAnyBurst(sv, 7, 4.0, 4, TSC, 40) + demodAnyBurst on the 1500-sample capture."""
+    x = np.fromfile(os.path.join(golden_dir, "nb_chunk_tsc7.cfile"), dtype=np.complex64)
+    bits = np.fromfile(os.path.join(golden_dir, "demodbits_tsc7.s8"), dtype=np.int8)
+    assert len(x) == 1500 and len(bits) == 148
+    rc, e = O.detect_any_burst(x, 7, 4.0, 4, O.TSC, 40)
+    assert rc == O.TSC
+    # SURVEY.md Appendix A (compiled reference, SSE build)
+    assert e.toa == np.float32(12.535156)
+    assert abs(e.amp[0] + 0.00112989) < 1e-8 and abs(e.amp[1] - 0.00166411) < 1e-8
+    assert abs(e.ci - 6.460016) < 1e-5
+    soft = O.demod_any_burst(x, rc, 4, e)
+    assert len(soft) == 156
+    assert np.array_equal(soft[:148] > 0, bits > 0)          # 0/148 bit errors, SoftVector::bit() = (v > 0)
+
+
+def test_detect_rejects_noise_and_flags_clipping():
+    rng = np.random.default_rng(1)
+    noise = (rng.standard_normal(625) + 1j * rng.standard_normal(625)).astype(np.complex64) * 100
+    rc, e = O.detect_any_burst(noise, 0, 4.0, 4, O.TSC, 3)
+    assert rc == 0 and e.toa == 0 and e.amp[0] == 0
+    noise[100] = 31000
+    rc, e = O.detect_any_burst(noise, 0, 4.0, 4, O.TSC, 3)
+    assert rc == -O.SIGERR_CLIP
+    rc, _ = O.detect_any_burst(noise, 9, 4.0, 4, O.TSC, 3)
+    assert rc == -O.SIGERR_UNSUPPORTED
+
+
+def test_vector_slicer_and_trxd_packing():
+    src = np.array([-2.0, -1.0, -0.5, 0.0, 0.25, 1.0, 3.0], dtype=np.float32)
+    dst = np.zeros_like(src)
+    O.lib().orc_vector_slicer(dst.ctypes.data, src.ctypes.data, len(src))
+    np.testing.assert_array_equal(dst, [0, 0, 0.25, 0.5, 0.625, 1, 1])
+    assert O.lib().orc_trxd_toa256(1.5) == 384 and O.lib().orc_trxd_toa256(-0.25) == -63
+    assert O.lib().orc_trxd_ci_cb(9.589) == 96
+    u8 = np.zeros(len(dst), dtype=np.uint8)
+    O.lib().orc_trxd_soft_u8(u8.ctypes.data, dst.ctypes.data, len(dst))
+    np.testing.assert_array_equal(u8, [0, 0, 64, 128, 159, 255, 255])
