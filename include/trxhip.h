@@ -1,0 +1,164 @@
+/*
+ * trxhip.h -- C ABI of the MI355X (gfx950) receive-side burst DSP for osmo-trx.
+ *
+ * This is the thin extern "C" HIP seam that sits where the reference calls its burst DSP:
+ *
+ *   Transceiver::pullRadioVector()            Transceiver52M/Transceiver.cpp:665-815
+ *     energyDetect()                          Transceiver52M/sigProcLib.cpp:1573-1585   (Transceiver.cpp:725)
+ *     detectAnyBurst()                        Transceiver52M/sigProcLib.cpp:1926-1957   (Transceiver.cpp:768)
+ *     demodAnyBurst()                         Transceiver52M/sigProcLib.cpp:2130-2137   (Transceiver.cpp:786)
+ *     vectorSlicer()                          Transceiver52M/sigProcLib.cpp:546-556     (Transceiver.cpp:803)
+ *   convert_short_float()                     Transceiver52M/arch/common/convert.h:9    (radioInterface.cpp:344-348)
+ *   convolve_real()/convolve_complex()        Transceiver52M/arch/common/convolve.h:6-14
+ *   Channelizer::rotate()                     Transceiver52M/Channelizer.cpp:74-99
+ *   Resampler::rotate()                       Transceiver52M/Resampler.cpp:131-150
+ *
+ * The reference runs these one burst at a time on one CPU thread per ARFCN; here they are batched:
+ * one call processes N independent bursts that are resident in device memory (HBM).  The
+ * single-burst C++ signatures of sigProcLib.h are kept by the host shim in
+ * osmo_trx_amd/host/ (batch of 1 over this ABI); INTEGRATION.md shows the binding.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success or a negative
+ * TRXHIP_E* code and never throws.  Pointers named d_* are DEVICE pointers (hipMalloc / torch
+ * CUDA tensors); h_* are host pointers.  `stream` is a hipStream_t passed as void* (NULL = the
+ * default stream).  Calls on different contexts/streams may run concurrently from different
+ * host threads (one RxUpper thread per ARFCN in the reference, Transceiver.cpp:308-314).
+ */
+#ifndef TRXHIP_H
+#define TRXHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRXHIP_ABI_VERSION 1
+
+/* error codes */
+#define TRXHIP_OK          0
+#define TRXHIP_EINVAL     (-22)   /* bad argument */
+#define TRXHIP_ENOMEM     (-12)
+#define TRXHIP_ENODEV     (-19)   /* no usable gfx950 device / HIP runtime failure at init */
+#define TRXHIP_EIO        (-5)    /* HIP launch/runtime error (maps to pullRadioVector's -EIO, Transceiver.cpp:686) */
+#define TRXHIP_ENOTSUP    (-95)
+
+/* CorrType, sigProcLib.h:30-38 (same numeric values) */
+enum trxhip_corr_type {
+	TRXHIP_OFF = 0, TRXHIP_TSC = 1, TRXHIP_EXT_RACH = 2, TRXHIP_RACH = 3,
+	TRXHIP_SCH = 4, TRXHIP_EDGE = 5, TRXHIP_IDLE = 6
+};
+/* SignalError, sigProcLib.h:40-46: detect returns -TRXHIP_SIGERR_* */
+enum trxhip_signal_error {
+	TRXHIP_SIGERR_NONE = 0, TRXHIP_SIGERR_BOUNDS = 1, TRXHIP_SIGERR_CLIP = 2,
+	TRXHIP_SIGERR_UNSUPPORTED = 3, TRXHIP_SIGERR_INTERNAL = 4
+};
+
+#define TRXHIP_MAX_TOA        112   /* largest max_toa the kernels accept (reference default: 63 AB / 30 NB) */
+#define TRXHIP_MAX_BURST_LEN 1536   /* samples per burst the kernels accept (625 @4 SPS, 156/157 @1 SPS) */
+#define TRXHIP_BURST_THRESH   4.0f  /* BURST_THRESH, sigProcLib.h:54 */
+
+/* Per-burst input: what pullRadioVector() knows before calling detectAnyBurst()
+ * (expectedCorrType() Transceiver.cpp:513-601, mTSC, mMaxExpectedDelayAB/NB :757-758). 8 bytes. */
+typedef struct trxhip_burst_params {
+	uint8_t  type;      /* enum trxhip_corr_type expected for the slot */
+	uint8_t  tsc;       /* training sequence code 0..7 */
+	uint16_t max_toa;   /* search window, symbols */
+	uint32_t reserved;  /* must be 0 */
+} trxhip_burst_params;
+
+/* Per-burst output: estim_burst_params (sigProcLib.h:113-118) + what pullRadioVector() derives. 32 bytes. */
+typedef struct trxhip_burst_result {
+	int32_t rc;          /* detectAnyBurst(): CorrType (>0) | 0 (nothing found) | -SignalError */
+	float   toa;         /* ebp.toa, symbols */
+	float   amp_re;      /* ebp.amp */
+	float   amp_im;
+	float   ci;          /* ebp.ci, dB */
+	float   energy;      /* energyDetect(burst, 20*sps) */
+	float   rssi;        /* 20*log10(full_scale/sqrt(energy)), dBFS without rssi_offset (Transceiver.cpp:751) */
+	uint8_t tsc;         /* ebp.tsc */
+	uint8_t clip;        /* maxAmplitude() > 30000 (sigProcLib.cpp:1746-1750) */
+	uint8_t idle;        /* bi->idle */
+	uint8_t nbits_div4;  /* bi->nbits / 4: 37 (148 GMSK), 111 (444 8-PSK), 0 when idle */
+} trxhip_burst_result;
+
+typedef struct trxhip_ctx trxhip_ctx;   /* one per device; owns the device-resident tables */
+
+/* ---- lifetime: sigProcLibSetup()/sigProcLibDestroy(), sigProcLib.h:57-60; convolve_init()/convert_init() ---- */
+int  trxhip_abi_version(void);
+int  trxhip_device_count(void);                       /* number of visible HIP devices (0 if none) */
+/* Generates all tables on the host exactly as sigProcLibSetup() does (sigProcLib.cpp:2139-2172)
+ * and uploads them to device `device`.  Fails with TRXHIP_ENODEV when no GPU is usable: there is
+ * no CPU fallback. */
+int  trxhip_create(trxhip_ctx **out, int device);
+void trxhip_destroy(trxhip_ctx *ctx);
+const char *trxhip_strerror(int err);
+
+/* ---- table blob: generated once on rank 0, broadcast to the other ranks (RCCL), adopted there ---- */
+size_t trxhip_tables_size(void);                                      /* bytes of the device table blob */
+int  trxhip_tables_generate_host(void *h_blob, size_t size);          /* host-only: no GPU needed */
+int  trxhip_create_from_tables(trxhip_ctx **out, int device, const void *h_blob, size_t size);
+int  trxhip_tables_device_ptr(trxhip_ctx *ctx, void **d_blob);        /* for an in-place RCCL broadcast */
+uint64_t trxhip_tables_checksum(const void *h_blob, size_t size);     /* FNV-1a over the blob */
+
+/* ---- the hot path: batched pullRadioVector() DSP core ----
+ * For each burst b < n_bursts (independent):
+ *   int16 IQ -> fp32 (convert_short_float, no scaling) -> energyDetect -> rssi -> clip flag ->
+ *   detectAnyBurst(type,tsc,threshold,sps,max_toa) -> if rc>0: demodAnyBurst -> soft bits.
+ *   d_iq     : n_bursts * burst_len * 2 int16 (I,Q interleaved, burst-major), 4-byte aligned
+ *   d_params : n_bursts trxhip_burst_params
+ *   d_results: n_bursts trxhip_burst_result
+ *   d_soft   : n_bursts * soft_stride float32 (may be NULL to skip soft output).
+ *              slice != 0: rx_burst[] after vectorSlicer(), 0..1, first nbits valid (148) -- what
+ *              pullRadioVector() hands to TRXD; slice == 0: raw demodAnyBurst() SoftVector
+ *              (-1..+1; 156 values @4 SPS, burst_len @1 SPS, 444 for 8-PSK).  Unused tail and
+ *              undetected bursts are zero-filled.
+ *   sps      : 1 or 4; burst_len: 625 @4 SPS (>= 624), 156/157 @1 SPS
+ */
+int trxhip_detect_demod_batch(trxhip_ctx *ctx,
+			      const int16_t *d_iq, const trxhip_burst_params *d_params,
+			      trxhip_burst_result *d_results, float *d_soft,
+			      size_t n_bursts, int burst_len, int sps,
+			      float threshold, float full_scale,
+			      int soft_stride, int slice, void *stream);
+
+/* Same, from complex64 device samples (the form sigProcLib's detectAnyBurst()/demodAnyBurst() take). */
+int trxhip_detect_demod_batch_cf32(trxhip_ctx *ctx,
+				   const float *d_iq_cf32, const trxhip_burst_params *d_params,
+				   trxhip_burst_result *d_results, float *d_soft,
+				   size_t n_bursts, int burst_len, int sps,
+				   float threshold, float full_scale,
+				   int soft_stride, int slice, void *stream);
+
+/* TRXD v0/v1 payload packing on device, proto_trxd.c:36-66:
+ *   d_pkt: n_bursts * 156 bytes: [0..1] toa_int be16 (1/256 sym), [2] rssi u8 (-dBFS), [3..4] ci cB be16,
+ *          [5] tsc, [6] idle, [7] nbits/4, [8..155] 148 soft bits uint8 = round(rx_burst*255) */
+int trxhip_pack_trxd_batch(trxhip_ctx *ctx, const trxhip_burst_result *d_results, const float *d_soft_sliced,
+			   int soft_stride, uint8_t *d_pkt, size_t n_bursts, float rssi_offset, void *stream);
+
+/* ---- arch kernels, batched (arch/common/convolve.h:6-14, convert.h:9) ----
+ * y[b][i] = sum_k x[b][i + start - (h_len-1) + k] * h[k]  (correlation form, no tap flip), b < n_vec.
+ * x: n_vec * x_len complex64; the caller guarantees start >= h_len-1 and start+len <= x_len
+ * (the reference's bounds_check(), convolve_base.c:88-105 -> returns TRXHIP_EINVAL otherwise).
+ * h: h_len complex64 on device (imag ignored for _real). */
+int trxhip_convolve_real_batch(trxhip_ctx *ctx, const float *d_x, int x_len, const float *d_h, int h_len,
+			       float *d_y, int y_len, int start, int len, size_t n_vec, void *stream);
+int trxhip_convolve_complex_batch(trxhip_ctx *ctx, const float *d_x, int x_len, const float *d_h, int h_len,
+				  float *d_y, int y_len, int start, int len, size_t n_vec, void *stream);
+int trxhip_convert_short_float(trxhip_ctx *ctx, float *d_out, const int16_t *d_in, size_t len, void *stream);
+
+/* ---- Channelizer::rotate (M-path polyphase analysis bank + M-point DFT), batched over blocks ----
+ * d_in : n_blocks * block_len * m wideband samples as int16 IQ (a continuous stream; block j's
+ *        filter history is the tail of block j-1, zero for block 0 -- Channelizer.cpp:86-88)
+ * d_out: m * (n_blocks * block_len) complex64, channel-major (outputBuffer(chan), Channelizer.cpp:60-66) */
+int trxhip_channelize_batch(trxhip_ctx *ctx, const int16_t *d_in, float *d_out,
+			    size_t n_blocks, int m, int block_len, int h_len, void *stream);
+/* Resampler(p,q,16)::rotate over a continuous stream per channel: in n_in samples -> out n_in*p/q */
+int trxhip_resample_batch(trxhip_ctx *ctx, const float *d_in, float *d_out, size_t n_in, int p, int q,
+			  size_t n_chan, size_t in_stride, size_t out_stride, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRXHIP_H */

@@ -1,0 +1,285 @@
+// trx_aux_kernels.hip -- the kernels either side of the burst hot path (gfx950, wave64):
+//   * convert_short_float            arch/common/convert_base.c:27-31 (radioInterface.cpp:344-348)
+//   * convolve_real / _complex       arch/common/convolve_base.c:57-85, batched
+//   * Channelizer::rotate            Channelizer.cpp:74-99 (M = 4 polyphase bank + 4-point DFT)
+//   * Resampler::rotate              Resampler.cpp:131-150 (65/48 and 1/4)
+//   * TRXD payload packing           proto_trxd.c:36-66
+// All are streaming, HBM-bound kernels: coalesced loads, int16->fp32 fused into the load,
+// taps in LDS, sums in the reference's generic-C order (compiled with -ffp-contract=off).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "trx_tables.h"
+#include "../../include/trxhip.h"
+
+typedef float2 c32;
+
+// ------------------------------------------------------------------------------------------------
+// int16 -> fp32, no scaling.  4 shorts (8 B) in, 16 B out per thread-iteration.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+convert_short_float_kernel(float *__restrict__ out, const int16_t *__restrict__ in, size_t len)
+{
+	const size_t nvec = len / 4;
+	const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	const bool aligned = ((reinterpret_cast<uintptr_t>(in) & 7) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+	if (aligned) {
+		const short4 *in4 = reinterpret_cast<const short4 *>(in);
+		float4 *out4 = reinterpret_cast<float4 *>(out);
+		for (size_t i = tid; i < nvec; i += stride) {
+			const short4 s = in4[i];
+			out4[i] = make_float4((float)s.x, (float)s.y, (float)s.z, (float)s.w);
+		}
+		for (size_t i = nvec * 4 + tid; i < len; i += stride)
+			out[i] = (float)in[i];
+	} else {
+		for (size_t i = tid; i < len; i += stride)
+			out[i] = (float)in[i];
+	}
+}
+
+extern "C" int trx_launch_convert_short_float(float *d_out, const int16_t *d_in, size_t len, hipStream_t stream)
+{
+	if (len == 0)
+		return 0;
+	size_t blocks = (len / 4 + 255) / 256;
+	if (blocks > 2048) blocks = 2048;
+	if (blocks < 1) blocks = 1;
+	hipLaunchKernelGGL(convert_short_float_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d_out, d_in, len);
+	return hipGetLastError() == hipSuccess ? 0 : TRXHIP_EIO;
+}
+
+// ------------------------------------------------------------------------------------------------
+// batched correlation-form FIR:  y[v][i] = sum_k x[v][i + start - (H-1) + k] * h[k]
+// one thread per output sample, taps staged in LDS, sequential k (generic-C order)
+// ------------------------------------------------------------------------------------------------
+template <bool HCPLX>
+__global__ void __launch_bounds__(256)
+convolve_kernel(const c32 *__restrict__ x, int x_len, const c32 *__restrict__ h, int h_len,
+		c32 *__restrict__ y, int y_len, int start, int len, size_t n_vec)
+{
+	__shared__ c32 hs[256];
+	for (int k = threadIdx.x; k < h_len; k += blockDim.x)
+		hs[k] = h[k];
+	__syncthreads();
+	const size_t total = n_vec * (size_t)len;
+	for (size_t o = blockIdx.x * (size_t)blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+		const size_t v = o / len;
+		const int i = (int)(o - v * len);
+		const c32 *xp = x + v * (size_t)x_len + (i + start - (h_len - 1));
+		float yr = 0.0f, yi = 0.0f;
+		for (int k = 0; k < h_len; k++) {
+			const c32 xv = xp[k];
+			const c32 t = hs[k];
+			if (HCPLX) {                                  // mac_cmplx
+				yr += xv.x * t.x - xv.y * t.y;
+				yi += xv.x * t.y + xv.y * t.x;
+			} else {                                      // mac_real: imag of the tap ignored
+				yr += xv.x * t.x;
+				yi += xv.y * t.x;
+			}
+		}
+		y[v * (size_t)y_len + i] = make_float2(yr, yi);
+	}
+}
+
+extern "C" int trx_launch_convolve(const float *d_x, int x_len, const float *d_h, int h_len, int h_complex,
+				   float *d_y, int y_len, int start, int len, size_t n_vec, hipStream_t stream)
+{
+	const size_t total = n_vec * (size_t)len;
+	if (total == 0)
+		return 0;
+	size_t blocks = (total + 255) / 256;
+	if (blocks > 256 * 8) blocks = 256 * 8;
+	const c32 *x = reinterpret_cast<const c32 *>(d_x);
+	const c32 *h = reinterpret_cast<const c32 *>(d_h);
+	c32 *y = reinterpret_cast<c32 *>(d_y);
+	if (h_complex)
+		hipLaunchKernelGGL(convolve_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, x, x_len, h, h_len, y,
+				   y_len, start, len, n_vec);
+	else
+		hipLaunchKernelGGL(convolve_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, x, x_len, h, h_len, y,
+				   y_len, start, len, n_vec);
+	return hipGetLastError() == hipSuccess ? 0 : TRXHIP_EIO;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Channelizer(4, blockLen, 16)::rotate over a continuous wideband int16 stream.
+//   path p takes wideband samples (M-1-p), (M-1-p)+M, ...                 (deinterleave, :37-48)
+//   y_p[T] = sum_k xp[T-15+k] * sub_p[k]   with the previous block as history   (:86-94)
+//   X_c[T] = 4-point forward DFT over p of y_p[T]                          (cxvec_fft, :96)
+// Block boundaries of the reference are invisible in the maths (history carry == continuous stream,
+// zero history before the first sample), so one thread computes one output time T for all 4
+// channels: 4 x 16 real-tap FIRs + one radix-2 butterfly pair, inputs staged through LDS.
+// ------------------------------------------------------------------------------------------------
+#define CH_M 4
+#define CH_H 16
+#define CH_TPB 256
+
+__global__ void __launch_bounds__(CH_TPB)
+channelize_kernel(const uint32_t *__restrict__ in, c32 *__restrict__ out, size_t n_total,
+		  const trx_tables *__restrict__ tab)
+{
+	// wideband samples (T0-15)*4 .. (T0+TPB)*4 as fp32, stored per path: xs[p][t], t = T - (T0-15)
+	__shared__ c32 xs[CH_M][CH_TPB + CH_H];
+	__shared__ float taps[CH_M][CH_H];
+	if (threadIdx.x < CH_M * CH_H)
+		taps[threadIdx.x / CH_H][threadIdx.x % CH_H] = tab->chan_taps[threadIdx.x / CH_H][threadIdx.x % CH_H];
+
+	for (size_t T0 = (size_t)blockIdx.x * CH_TPB; T0 < n_total; T0 += (size_t)gridDim.x * CH_TPB) {
+		__syncthreads();
+		const long long first = ((long long)T0 - (CH_H - 1)) * CH_M;       // first wideband sample needed
+		const int nload = (CH_TPB + CH_H - 1) * CH_M;
+		for (int j = threadIdx.x; j < nload; j += CH_TPB) {
+			const long long s = first + j;
+			c32 v = make_float2(0.0f, 0.0f);
+			if (s >= 0 && (size_t)s < n_total * CH_M) {
+				const uint32_t u = in[s];
+				v = make_float2((float)(int16_t)(u & 0xffffu), (float)(int16_t)(u >> 16));
+			}
+			const int t = j / CH_M, n = j % CH_M;                          // sample n of time t -> path M-1-n
+			xs[CH_M - 1 - n][t] = v;
+		}
+		__syncthreads();
+		const size_t T = T0 + threadIdx.x;
+		if (T < n_total) {
+			c32 yp[CH_M];
+#pragma unroll
+			for (int p = 0; p < CH_M; p++) {
+				float yr = 0.0f, yi = 0.0f;
+#pragma unroll
+				for (int k = 0; k < CH_H; k++) {
+					const c32 x = xs[p][threadIdx.x + k];
+					const float g = taps[p][k];
+					yr += x.x * g;
+					yi += x.y * g;
+				}
+				yp[p] = make_float2(yr, yi);
+			}
+			// forward 4-point DFT, radix-2 butterflies (exact +-1 / +-j twiddles)
+			const c32 t1 = make_float2(yp[0].x + yp[2].x, yp[0].y + yp[2].y);
+			const c32 t2 = make_float2(yp[0].x - yp[2].x, yp[0].y - yp[2].y);
+			const c32 t3 = make_float2(yp[1].x + yp[3].x, yp[1].y + yp[3].y);
+			const c32 t4 = make_float2(yp[1].x - yp[3].x, yp[1].y - yp[3].y);
+			out[0 * n_total + T] = make_float2(t1.x + t3.x, t1.y + t3.y);
+			out[1 * n_total + T] = make_float2(t2.x + t4.y, t2.y - t4.x);   // t2 - j*t4
+			out[2 * n_total + T] = make_float2(t1.x - t3.x, t1.y - t3.y);
+			out[3 * n_total + T] = make_float2(t2.x - t4.y, t2.y + t4.x);   // t2 + j*t4
+		}
+	}
+}
+
+extern "C" int trx_launch_channelize(const int16_t *d_in, float *d_out, size_t n_total, const trx_tables *d_tab,
+				     hipStream_t stream)
+{
+	if (n_total == 0)
+		return 0;
+	size_t blocks = (n_total + CH_TPB - 1) / CH_TPB;
+	if (blocks > 256 * 8) blocks = 256 * 8;
+	hipLaunchKernelGGL(channelize_kernel, dim3((unsigned)blocks), dim3(CH_TPB), 0, stream,
+			   reinterpret_cast<const uint32_t *>(d_in), reinterpret_cast<c32 *>(d_out), n_total, d_tab);
+	return hipGetLastError() == hipSuccess ? 0 : TRXHIP_EIO;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Resampler(p, q, 16)::rotate over a continuous stream per channel:
+//   out[I] = sum_k in[n - 15 + k] * part[path][k],  n = (q*I)/p,  path = (q*I)%p     (Resampler.cpp:139-147,157-162)
+// (per-block processing with history splice in the reference == the continuous formula, because
+//  q*out_block == p*in_block; zero history before the first sample)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+resample_kernel(const c32 *__restrict__ in, c32 *__restrict__ out, size_t n_in, size_t n_out, int p, int q,
+		size_t n_chan, size_t in_stride, size_t out_stride, const float *__restrict__ parts)
+{
+	extern __shared__ float taps_s[];                                  // p x 16
+	for (int i = threadIdx.x; i < p * 16; i += blockDim.x)
+		taps_s[i] = parts[i];
+	__syncthreads();
+	const size_t total = n_chan * n_out;
+	for (size_t o = blockIdx.x * (size_t)blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+		const size_t c = o / n_out;
+		const size_t I = o - c * n_out;
+		const unsigned long long qi = (unsigned long long)q * I;
+		const long long n = (long long)(qi / p);
+		const int path = (int)(qi % p);
+		const float *h = taps_s + path * 16;
+		const c32 *x = in + c * in_stride;
+		float yr = 0.0f, yi = 0.0f;
+#pragma unroll
+		for (int k = 0; k < 16; k++) {
+			const long long j = n - 15 + k;
+			c32 xv = make_float2(0.0f, 0.0f);
+			if (j >= 0 && (size_t)j < n_in) xv = x[j];
+			yr += xv.x * h[k];
+			yi += xv.y * h[k];
+		}
+		out[c * out_stride + I] = make_float2(yr, yi);
+	}
+}
+
+extern "C" int trx_launch_resample(const float *d_in, float *d_out, size_t n_in, int p, int q, size_t n_chan,
+				   size_t in_stride, size_t out_stride, const trx_tables *d_tab, hipStream_t stream)
+{
+	const size_t n_out = n_in / q * p;
+	const size_t total = n_chan * n_out;
+	if (total == 0)
+		return 0;
+	const float *parts = (p == 65) ? &d_tab->rs6548_taps[0][0] : &d_tab->dec_taps[0];
+	size_t blocks = (total + 255) / 256;
+	if (blocks > 256 * 8) blocks = 256 * 8;
+	hipLaunchKernelGGL(resample_kernel, dim3((unsigned)blocks), dim3(256), (size_t)p * 16 * sizeof(float), stream,
+			   reinterpret_cast<const c32 *>(d_in), reinterpret_cast<c32 *>(d_out), n_in, n_out, p, q, n_chan,
+			   in_stride, out_stride, parts);
+	return hipGetLastError() == hipSuccess ? 0 : TRXHIP_EIO;
+}
+
+// ------------------------------------------------------------------------------------------------
+// TRXD payload packing (proto_trxd.c:36-66): one 156-byte record per burst, one wave per 4 bursts
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+pack_trxd_kernel(const trxhip_burst_result *__restrict__ res, const float *__restrict__ soft, int soft_stride,
+		 uint8_t *__restrict__ pkt, size_t n_bursts, float rssi_offset)
+{
+	const size_t total = n_bursts * 39;                                  // 39 dwords per record
+	uint32_t *out = reinterpret_cast<uint32_t *>(pkt);
+	for (size_t o = blockIdx.x * (size_t)blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+		const size_t b = o / 39;
+		const int wd = (int)(o - b * 39);
+		const trxhip_burst_result r = res[b];
+		uint32_t word;
+		if (wd == 0) {
+			const int toa_int = (int)((double)r.toa * 256.0 + 0.5);        // trxd_fill_v0_specific
+			double rssi = (double)r.rssi + (double)rssi_offset;
+			uint32_t rssi_u8 = (rssi >= 255.0 || rssi != rssi) ? 255u : (rssi <= 0.0 ? 0u : (uint32_t)rssi);
+			const int ci_cb = (int16_t)((double)(r.ci * 10) + 0.5);        // trxd_fill_v1_specific
+			word = ((uint32_t)(toa_int >> 8) & 0xffu) | (((uint32_t)toa_int & 0xffu) << 8) | (rssi_u8 << 16) |
+			       ((((uint32_t)ci_cb >> 8) & 0xffu) << 24);
+		} else if (wd == 1) {
+			const int ci_cb = (int16_t)((double)(r.ci * 10) + 0.5);
+			word = ((uint32_t)ci_cb & 0xffu) | ((uint32_t)r.tsc << 8) | ((uint32_t)r.idle << 16) |
+			       ((uint32_t)r.nbits_div4 << 24);
+		} else {
+			word = 0;
+			const float *s = soft + b * (size_t)soft_stride + (wd - 2) * 4;
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				const uint32_t u = r.idle ? 0u : (uint32_t)(uint8_t)round((double)s[k] * 255.0);   // normalized255
+				word |= u << (8 * k);
+			}
+		}
+		out[o] = word;
+	}
+}
+
+extern "C" int trx_launch_pack_trxd(const trxhip_burst_result *d_results, const float *d_soft, int soft_stride,
+				    uint8_t *d_pkt, size_t n_bursts, float rssi_offset, hipStream_t stream)
+{
+	if (n_bursts == 0)
+		return 0;
+	size_t blocks = (n_bursts * 39 + 255) / 256;
+	if (blocks > 256 * 8) blocks = 256 * 8;
+	hipLaunchKernelGGL(pack_trxd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d_results, d_soft, soft_stride,
+			   d_pkt, n_bursts, rssi_offset);
+	return hipGetLastError() == hipSuccess ? 0 : TRXHIP_EIO;
+}

@@ -1,0 +1,268 @@
+// trx_capi.cpp -- the extern "C" seam declared in include/trxhip.h.
+// Thin: argument checks, table upload, kernel launches.  No CPU fallback anywhere: when no HIP
+// device is usable trxhip_create() fails with TRXHIP_ENODEV and nothing else can be called.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "../../include/trxhip.h"
+#include "trx_tables.h"
+
+// kernel launchers (trx_kernels.hip, trx_aux_kernels.hip)
+extern "C" int trx_launch_pull(const void *d_iq, int cf32, const trxhip_burst_params *d_params,
+			       trxhip_burst_result *d_results, float *d_soft, const trx_tables *d_tab,
+			       size_t n_bursts, int L, int sps, float thresh, float full_scale,
+			       int soft_stride, int slice, int n_cu, hipStream_t stream);
+extern "C" int trx_launch_pack_trxd(const trxhip_burst_result *d_results, const float *d_soft, int soft_stride,
+				    uint8_t *d_pkt, size_t n_bursts, float rssi_offset, hipStream_t stream);
+extern "C" int trx_launch_convolve(const float *d_x, int x_len, const float *d_h, int h_len, int h_complex,
+				   float *d_y, int y_len, int start, int len, size_t n_vec, hipStream_t stream);
+extern "C" int trx_launch_convert_short_float(float *d_out, const int16_t *d_in, size_t len, hipStream_t stream);
+extern "C" int trx_launch_channelize(const int16_t *d_in, float *d_out, size_t n_total, const trx_tables *d_tab,
+				     hipStream_t stream);
+extern "C" int trx_launch_resample(const float *d_in, float *d_out, size_t n_in, int p, int q, size_t n_chan,
+				   size_t in_stride, size_t out_stride, const trx_tables *d_tab, hipStream_t stream);
+
+struct trxhip_ctx {
+	int device;
+	int n_cu;
+	trx_tables *d_tables;
+};
+
+static int with_device(const trxhip_ctx *ctx)
+{
+	return hipSetDevice(ctx->device) == hipSuccess ? 0 : TRXHIP_EIO;
+}
+
+extern "C" {
+
+int trxhip_abi_version(void) { return TRXHIP_ABI_VERSION; }
+
+int trxhip_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess)
+		return 0;
+	return n;
+}
+
+const char *trxhip_strerror(int err)
+{
+	switch (err) {
+	case TRXHIP_OK: return "ok";
+	case TRXHIP_EINVAL: return "invalid argument";
+	case TRXHIP_ENOMEM: return "out of device memory";
+	case TRXHIP_ENODEV: return "no usable HIP device (gfx950 required; there is no CPU fallback)";
+	case TRXHIP_EIO: return "HIP runtime / kernel launch error";
+	case TRXHIP_ENOTSUP: return "not supported";
+	default: return "unknown error";
+	}
+}
+
+size_t trxhip_tables_size(void) { return sizeof(trx_tables); }
+
+int trxhip_tables_generate_host(void *h_blob, size_t size)
+{
+	if (!h_blob || size != sizeof(trx_tables))
+		return TRXHIP_EINVAL;
+	return trx_tables_generate(static_cast<trx_tables *>(h_blob)) == 0 ? TRXHIP_OK : TRXHIP_EINVAL;
+}
+
+uint64_t trxhip_tables_checksum(const void *h_blob, size_t size)
+{
+	const unsigned char *p = static_cast<const unsigned char *>(h_blob);
+	uint64_t h = 1469598103934665603ull;          /* FNV-1a 64 */
+	for (size_t i = 0; i < size; i++) {
+		h ^= p[i];
+		h *= 1099511628211ull;
+	}
+	return h;
+}
+
+int trxhip_create_from_tables(trxhip_ctx **out, int device, const void *h_blob, size_t size)
+{
+	if (!out || !h_blob || size != sizeof(trx_tables))
+		return TRXHIP_EINVAL;
+	const trx_tables *t = static_cast<const trx_tables *>(h_blob);
+	if (t->magic != TRX_TABLES_MAGIC || t->version != TRX_TABLES_VERSION)
+		return TRXHIP_EINVAL;
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n)
+		return TRXHIP_ENODEV;
+	if (hipSetDevice(device) != hipSuccess)
+		return TRXHIP_ENODEV;
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) != hipSuccess)
+		return TRXHIP_ENODEV;
+
+	trxhip_ctx *ctx = new (std::nothrow) trxhip_ctx;
+	if (!ctx)
+		return TRXHIP_ENOMEM;
+	ctx->device = device;
+	ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+	ctx->d_tables = nullptr;
+	if (hipMalloc(reinterpret_cast<void **>(&ctx->d_tables), sizeof(trx_tables)) != hipSuccess) {
+		delete ctx;
+		return TRXHIP_ENOMEM;
+	}
+	if (hipMemcpy(ctx->d_tables, h_blob, sizeof(trx_tables), hipMemcpyHostToDevice) != hipSuccess) {
+		hipFree(ctx->d_tables);
+		delete ctx;
+		return TRXHIP_EIO;
+	}
+	*out = ctx;
+	return TRXHIP_OK;
+}
+
+int trxhip_create(trxhip_ctx **out, int device)
+{
+	if (!out)
+		return TRXHIP_EINVAL;
+	trx_tables *t = static_cast<trx_tables *>(malloc(sizeof(trx_tables)));
+	if (!t)
+		return TRXHIP_ENOMEM;
+	int rc = trx_tables_generate(t) == 0 ? TRXHIP_OK : TRXHIP_EINVAL;
+	if (rc == TRXHIP_OK)
+		rc = trxhip_create_from_tables(out, device, t, sizeof(trx_tables));
+	free(t);
+	return rc;
+}
+
+void trxhip_destroy(trxhip_ctx *ctx)
+{
+	if (!ctx)
+		return;
+	if (hipSetDevice(ctx->device) == hipSuccess && ctx->d_tables)
+		hipFree(ctx->d_tables);
+	delete ctx;
+}
+
+int trxhip_tables_device_ptr(trxhip_ctx *ctx, void **d_blob)
+{
+	if (!ctx || !d_blob)
+		return TRXHIP_EINVAL;
+	*d_blob = ctx->d_tables;
+	return TRXHIP_OK;
+}
+
+static int pull_common(trxhip_ctx *ctx, const void *d_iq, int cf32, const trxhip_burst_params *d_params,
+		       trxhip_burst_result *d_results, float *d_soft, size_t n_bursts, int burst_len, int sps,
+		       float threshold, float full_scale, int soft_stride, int slice, void *stream)
+{
+	if (!ctx)
+		return TRXHIP_EINVAL;
+	if (sps != 1 && sps != 4)
+		return TRXHIP_EINVAL;                                  /* sigProcLib.cpp:1740-1741 */
+	if (burst_len > TRXHIP_MAX_BURST_LEN || burst_len < 1 || (sps == 4 && burst_len < 624) ||
+	    (sps == 1 && burst_len > 190))
+		return TRXHIP_EINVAL;
+	if (d_soft && soft_stride < 1)
+		return TRXHIP_EINVAL;
+	if (n_bursts == 0)
+		return TRXHIP_OK;                                      /* empty batch: nothing to do */
+	if (!d_iq || !d_params || !d_results || n_bursts > 0xffffffffull)
+		return TRXHIP_EINVAL;
+	if ((reinterpret_cast<uintptr_t>(d_iq) & 3) != 0)
+		return TRXHIP_EINVAL;
+	if (with_device(ctx))
+		return TRXHIP_EIO;
+	return trx_launch_pull(d_iq, cf32, d_params, d_results, d_soft, ctx->d_tables, n_bursts, burst_len, sps,
+			       threshold, full_scale, soft_stride, slice, ctx->n_cu, static_cast<hipStream_t>(stream));
+}
+
+int trxhip_detect_demod_batch(trxhip_ctx *ctx, const int16_t *d_iq, const trxhip_burst_params *d_params,
+			      trxhip_burst_result *d_results, float *d_soft, size_t n_bursts, int burst_len, int sps,
+			      float threshold, float full_scale, int soft_stride, int slice, void *stream)
+{
+	return pull_common(ctx, d_iq, 0, d_params, d_results, d_soft, n_bursts, burst_len, sps, threshold, full_scale,
+			   soft_stride, slice, stream);
+}
+
+int trxhip_detect_demod_batch_cf32(trxhip_ctx *ctx, const float *d_iq, const trxhip_burst_params *d_params,
+				   trxhip_burst_result *d_results, float *d_soft, size_t n_bursts, int burst_len,
+				   int sps, float threshold, float full_scale, int soft_stride, int slice, void *stream)
+{
+	return pull_common(ctx, d_iq, 1, d_params, d_results, d_soft, n_bursts, burst_len, sps, threshold, full_scale,
+			   soft_stride, slice, stream);
+}
+
+int trxhip_pack_trxd_batch(trxhip_ctx *ctx, const trxhip_burst_result *d_results, const float *d_soft_sliced,
+			   int soft_stride, uint8_t *d_pkt, size_t n_bursts, float rssi_offset, void *stream)
+{
+	if (!ctx || !d_results || !d_soft_sliced || !d_pkt || soft_stride < 148)
+		return TRXHIP_EINVAL;
+	if (with_device(ctx))
+		return TRXHIP_EIO;
+	return trx_launch_pack_trxd(d_results, d_soft_sliced, soft_stride, d_pkt, n_bursts, rssi_offset,
+				    static_cast<hipStream_t>(stream));
+}
+
+static int conv_common(trxhip_ctx *ctx, const float *d_x, int x_len, const float *d_h, int h_len, int h_complex,
+		       float *d_y, int y_len, int start, int len, size_t n_vec, void *stream)
+{
+	if (!ctx || !d_x || !d_h || !d_y)
+		return TRXHIP_EINVAL;
+	/* bounds_check(), arch/common/convolve_base.c:88-105, plus the head-room rule */
+	if (x_len < 1 || h_len < 1 || y_len < 1 || len < 1 || h_len > 256)
+		return TRXHIP_EINVAL;
+	if (start + len > x_len || len > y_len || x_len < h_len || start < h_len - 1)
+		return TRXHIP_EINVAL;
+	if (with_device(ctx))
+		return TRXHIP_EIO;
+	return trx_launch_convolve(d_x, x_len, d_h, h_len, h_complex, d_y, y_len, start, len, n_vec,
+				   static_cast<hipStream_t>(stream));
+}
+
+int trxhip_convolve_real_batch(trxhip_ctx *ctx, const float *d_x, int x_len, const float *d_h, int h_len,
+			       float *d_y, int y_len, int start, int len, size_t n_vec, void *stream)
+{
+	return conv_common(ctx, d_x, x_len, d_h, h_len, 0, d_y, y_len, start, len, n_vec, stream);
+}
+
+int trxhip_convolve_complex_batch(trxhip_ctx *ctx, const float *d_x, int x_len, const float *d_h, int h_len,
+				  float *d_y, int y_len, int start, int len, size_t n_vec, void *stream)
+{
+	return conv_common(ctx, d_x, x_len, d_h, h_len, 1, d_y, y_len, start, len, n_vec, stream);
+}
+
+int trxhip_convert_short_float(trxhip_ctx *ctx, float *d_out, const int16_t *d_in, size_t len, void *stream)
+{
+	if (!ctx || !d_out || !d_in)
+		return TRXHIP_EINVAL;
+	if (with_device(ctx))
+		return TRXHIP_EIO;
+	return trx_launch_convert_short_float(d_out, d_in, len, static_cast<hipStream_t>(stream));
+}
+
+int trxhip_channelize_batch(trxhip_ctx *ctx, const int16_t *d_in, float *d_out, size_t n_blocks, int m,
+			    int block_len, int h_len, void *stream)
+{
+	if (!ctx || !d_in || !d_out || block_len < 1)
+		return TRXHIP_EINVAL;
+	if (m != 4 || h_len != 16)
+		return TRXHIP_ENOTSUP;                 /* the reference instantiates Channelizer(4, 192, 16) only */
+	if (with_device(ctx))
+		return TRXHIP_EIO;
+	return trx_launch_channelize(d_in, d_out, n_blocks * (size_t)block_len, ctx->d_tables,
+				     static_cast<hipStream_t>(stream));
+}
+
+int trxhip_resample_batch(trxhip_ctx *ctx, const float *d_in, float *d_out, size_t n_in, int p, int q,
+			  size_t n_chan, size_t in_stride, size_t out_stride, void *stream)
+{
+	if (!ctx || !d_in || !d_out)
+		return TRXHIP_EINVAL;
+	if (!((p == 65 && q == 48) || (p == 1 && q == 4)))
+		return TRXHIP_ENOTSUP;                 /* Resampler(65,48) radioInterfaceMulti.cpp:35-36; (1,4) sigProcLib.cpp:2161 */
+	if (n_in % q)
+		return TRXHIP_EINVAL;                  /* Resampler.cpp:100-104 */
+	if (with_device(ctx))
+		return TRXHIP_EIO;
+	return trx_launch_resample(d_in, d_out, n_in, p, q, n_chan, in_stride, out_stride, ctx->d_tables,
+				   static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,65 @@
+// trx_tables.h -- layout of the device-resident table blob shared by host table generation
+// (trx_tables.cpp) and the gfx950 kernels (trx_kernels.hip).
+//
+// The blob is what sigProcLibSetup() builds in the reference (Transceiver52M/sigProcLib.cpp:2139-2172):
+// decimator taps, 64 fractional-delay filters, the 1-SPS reverse GMSK rotation, all correlation
+// sequences with gain/toa, plus two derived tables that let the kernels avoid fp64 and divisions:
+//   * sincv[]   : sinc(M_PI_F * q/512) for q in [0,4096) -- every value interpolatePoint()
+//                 (sigProcLib.cpp:1100-1118) can request, because peakDetect() only visits positions
+//                 that are multiples of 1/512 (sigProcLib.cpp:1159-1175); XOR-swizzled for LDS banks
+//   * gain_inv, ci_den per sequence (Complex.h:144-150 inv(); sigProcLib.cpp:1629)
+// ~23 KB, generated once on the host (rank 0), broadcast over RCCL, resident in HBM/L2.
+#pragma once
+#include <stdint.h>
+
+struct trx_c32 { float re, im; };
+
+enum {
+	TRX_SEQ_TSC0   = 0,   // gMidambles[0..7]
+	TRX_SEQ_RACH0  = 8,   // gRACHSequences[0..2]
+	TRX_SEQ_DUMMY  = 11,  // gDummySequence
+	TRX_SEQ_EDGE0  = 12,  // gEdgeMidambles[0..7]
+	TRX_SEQ_SCH    = 20,  // gSCHSequence
+	TRX_NSEQ       = 21,
+	TRX_SEQ_MAXLEN = 64,
+	TRX_SINCV_LEN  = 4096,
+	TRX_DELAY_FILTS = 64,
+	TRX_DELAY_HLEN = 20,
+};
+
+struct trx_seq {
+	trx_c32 taps[TRX_SEQ_MAXLEN];  // conjugated rotated +-1 sequence (CorrelationSequence::sequence)
+	trx_c32 gain;                  // CorrelationSequence::gain
+	trx_c32 gain_inv;              // gain.inv()
+	float   ci_den;                // (N-1) * gain.abs()
+	float   toa;                   // CorrelationSequence::toa
+	int32_t n;                     // sequence length: 16 / 40 / 64
+	int32_t pad;
+};
+
+struct trx_tables {
+	uint32_t magic;                // 'TRXT'
+	uint32_t version;
+	float    dec_taps[16];                              // Resampler(1,4) partition 0 (reversed)
+	float    delay_filt[TRX_DELAY_FILTS][TRX_DELAY_HLEN];
+	trx_c32  rrot1[160];                                // GMSKReverseRotation1 (157 used)
+	float    c0_inv[8];                                 // EDGE equaliser, 5 taps used
+	trx_seq  seq[TRX_NSEQ];
+	float    sincv[TRX_SINCV_LEN];                      // index q ^ ((q >> 4) & 31)
+	float    chan_taps[4][16];                          // Channelizer(4,*,16) sub-filters (reversed)
+	float    rs6548_taps[65][16];                       // Resampler(65,48) partitions (reversed)
+};
+
+#define TRX_TABLES_MAGIC   0x54585254u
+#define TRX_TABLES_VERSION 1u
+
+// XOR swizzle of the sincv index: conflict-free LDS gathers both for lanes whose positions differ
+// by multiples of 16/512 (coarse bisection levels) and by 1/512 steps (fine levels).
+static inline
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+int trx_sincv_swz(int q) { return q ^ ((q >> 4) & 31); }
+
+// Host-side generation (no GPU needed).  Returns 0 on success.
+int trx_tables_generate(trx_tables *out);

@@ -1,0 +1,234 @@
+"""ctypes binding of libtrxhip.so (include/trxhip.h).  Plumbing only.
+
+Device memory, streams and torch.distributed come from PyTorch; every compute call goes through the
+C ABI with raw device pointers.  There is no CPU path here: if the library is not built, or no GPU is
+present, construction of TrxHip raises TrxHipError.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+
+# CorrType, sigProcLib.h:30-38
+OFF, TSC, EXT_RACH, RACH, SCH, EDGE, IDLE = range(7)
+
+PARAMS_DTYPE = np.dtype([("type", "u1"), ("tsc", "u1"), ("max_toa", "<u2"), ("reserved", "<u4")])
+RESULT_DTYPE = np.dtype([
+    ("rc", "<i4"), ("toa", "<f4"), ("amp_re", "<f4"), ("amp_im", "<f4"), ("ci", "<f4"),
+    ("energy", "<f4"), ("rssi", "<f4"), ("tsc", "u1"), ("clip", "u1"), ("idle", "u1"), ("nbits_div4", "u1"),
+])
+assert PARAMS_DTYPE.itemsize == 8 and RESULT_DTYPE.itemsize == 32
+
+TRXD_RECORD_BYTES = 156
+
+
+class TrxHipError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(PKG, "lib", "libtrxhip.so")
+
+
+_LIB = None
+
+# every symbol include/trxhip.h declares: (name, restype, argtypes)
+_VP, _I, _F, _SZ = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+SYMBOLS = {
+    "trxhip_abi_version": (_I, []),
+    "trxhip_device_count": (_I, []),
+    "trxhip_create": (_I, [C.POINTER(_VP), _I]),
+    "trxhip_destroy": (None, [_VP]),
+    "trxhip_strerror": (C.c_char_p, [_I]),
+    "trxhip_tables_size": (_SZ, []),
+    "trxhip_tables_generate_host": (_I, [_VP, _SZ]),
+    "trxhip_create_from_tables": (_I, [C.POINTER(_VP), _I, _VP, _SZ]),
+    "trxhip_tables_device_ptr": (_I, [_VP, C.POINTER(_VP)]),
+    "trxhip_tables_checksum": (C.c_uint64, [_VP, _SZ]),
+    "trxhip_detect_demod_batch": (_I, [_VP, _VP, _VP, _VP, _VP, _SZ, _I, _I, _F, _F, _I, _I, _VP]),
+    "trxhip_detect_demod_batch_cf32": (_I, [_VP, _VP, _VP, _VP, _VP, _SZ, _I, _I, _F, _F, _I, _I, _VP]),
+    "trxhip_pack_trxd_batch": (_I, [_VP, _VP, _VP, _I, _VP, _SZ, _F, _VP]),
+    "trxhip_convolve_real_batch": (_I, [_VP, _VP, _I, _VP, _I, _VP, _I, _I, _I, _SZ, _VP]),
+    "trxhip_convolve_complex_batch": (_I, [_VP, _VP, _I, _VP, _I, _VP, _I, _I, _I, _SZ, _VP]),
+    "trxhip_convert_short_float": (_I, [_VP, _VP, _VP, _SZ, _VP]),
+    "trxhip_channelize_batch": (_I, [_VP, _VP, _VP, _SZ, _I, _I, _I, _VP]),
+    "trxhip_resample_batch": (_I, [_VP, _VP, _VP, _SZ, _I, _I, _SZ, _SZ, _SZ, _VP]),
+}
+
+
+def load_library():
+    """dlopen libtrxhip.so and bind every symbol of include/trxhip.h.  Raises if it is not built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise TrxHipError(f"{path} is not built (run `python -m osmo_trx_amd.build`); there is no CPU fallback")
+    try:
+        L = C.CDLL(path)
+    except OSError as e:  # pragma: no cover
+        raise TrxHipError(f"cannot load {path}: {e}") from e
+    for name, (res, args) in SYMBOLS.items():
+        f = getattr(L, name)  # AttributeError if the export is missing
+        f.restype = res
+        f.argtypes = args
+    _LIB = L
+    return L
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = load_library().trxhip_strerror(rc).decode()
+        raise TrxHipError(f"{what} failed: {rc} ({msg})")
+
+
+def generate_tables_host():
+    """The table blob as bytes (host-only; works without a GPU)."""
+    L = load_library()
+    n = L.trxhip_tables_size()
+    buf = (C.c_ubyte * n)()
+    _check(L.trxhip_tables_generate_host(buf, n), "trxhip_tables_generate_host")
+    return bytes(buf)
+
+
+def tables_checksum(blob):
+    L = load_library()
+    b = (C.c_ubyte * len(blob)).from_buffer_copy(blob)
+    return int(L.trxhip_tables_checksum(b, len(blob)))
+
+
+class TrxHip:
+    """One context per GPU (owns the device-resident tables).  All tensors are torch CUDA tensors."""
+
+    def __init__(self, device=0, tables_blob=None):
+        import torch
+        self.torch = torch
+        self.L = load_library()
+        if not torch.cuda.is_available():
+            raise TrxHipError("no GPU visible: osmo_trx_amd has no CPU fallback")
+        self.device = int(device)
+        h = _VP()
+        if tables_blob is None:
+            _check(self.L.trxhip_create(C.byref(h), self.device), "trxhip_create")
+        else:
+            b = (C.c_ubyte * len(tables_blob)).from_buffer_copy(tables_blob)
+            _check(self.L.trxhip_create_from_tables(C.byref(h), self.device, b, len(tables_blob)),
+                   "trxhip_create_from_tables")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.trxhip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- helpers -------------------------------------------------------------------------------
+    def _stream(self, stream=None):
+        if stream is None:
+            stream = self.torch.cuda.current_stream(self.device)
+        return _VP(stream.cuda_stream)
+
+    def _dev(self, t, dtype=None):
+        torch = self.torch
+        assert t.is_cuda and t.device.index == self.device and t.is_contiguous(), "need a contiguous tensor on this GPU"
+        if dtype is not None:
+            assert t.dtype == dtype, (t.dtype, dtype)
+        return _VP(t.data_ptr())
+
+    def tables_device_tensor(self):
+        """uint8 view-less copy target for an in-place RCCL broadcast: (ptr, nbytes)."""
+        p = _VP()
+        _check(self.L.trxhip_tables_device_ptr(self.h, C.byref(p)), "trxhip_tables_device_ptr")
+        return p.value, int(self.L.trxhip_tables_size())
+
+    def params_tensor(self, params_np):
+        """PARAMS_DTYPE[n] numpy -> uint8[n, 8] device tensor."""
+        torch = self.torch
+        a = np.ascontiguousarray(params_np, dtype=PARAMS_DTYPE).view(np.uint8).reshape(-1, 8)
+        return torch.from_numpy(a.copy()).to(f"cuda:{self.device}")
+
+    # ---- hot path ------------------------------------------------------------------------------
+    def detect_demod(self, iq, params, sps=4, threshold=4.0, full_scale=32767.0, soft_stride=148, slice_bits=True,
+                     results=None, soft=None, stream=None, want_soft=True):
+        """iq: int16[n, burst_len, 2] or complex64[n, burst_len] (device).  params: uint8[n, 8] (device).
+        Returns (results uint8[n, 32], soft float32[n, soft_stride]) device tensors."""
+        torch = self.torch
+        n = iq.shape[0]
+        burst_len = iq.shape[1]
+        dev = f"cuda:{self.device}"
+        if results is None:
+            results = torch.empty((n, 32), dtype=torch.uint8, device=dev)
+        if soft is None and want_soft:
+            soft = torch.empty((n, soft_stride), dtype=torch.float32, device=dev)
+        assert params.shape == (n, 8) and params.dtype == torch.uint8
+        sp = self._dev(soft, torch.float32) if soft is not None else _VP(0)
+        if iq.dtype == torch.int16:
+            assert iq.shape[2] == 2
+            fn = self.L.trxhip_detect_demod_batch
+            ip = self._dev(iq, torch.int16)
+        elif iq.dtype == torch.complex64:
+            fn = self.L.trxhip_detect_demod_batch_cf32
+            ip = self._dev(iq)
+        else:
+            raise TrxHipError(f"unsupported IQ dtype {iq.dtype}")
+        rc = fn(self.h, ip, self._dev(params), self._dev(results), sp, n, burst_len, sps,
+                threshold, full_scale, soft_stride, 1 if slice_bits else 0, self._stream(stream))
+        _check(rc, "trxhip_detect_demod_batch")
+        return results, soft
+
+    @staticmethod
+    def results_to_numpy(results):
+        return results.cpu().numpy().view(RESULT_DTYPE).reshape(-1)
+
+    def pack_trxd(self, results, soft, rssi_offset=0.0, stream=None):
+        torch = self.torch
+        n = results.shape[0]
+        pkt = torch.empty((n, TRXD_RECORD_BYTES), dtype=torch.uint8, device=results.device)
+        rc = self.L.trxhip_pack_trxd_batch(self.h, self._dev(results), self._dev(soft, torch.float32), soft.shape[1],
+                                           self._dev(pkt), n, rssi_offset, self._stream(stream))
+        _check(rc, "trxhip_pack_trxd_batch")
+        return pkt
+
+    # ---- arch kernels ---------------------------------------------------------------------------
+    def convolve(self, x, h, start, length, complex_taps, stream=None):
+        """x: complex64[n_vec, x_len], h: complex64[h_len] -> complex64[n_vec, length]"""
+        torch = self.torch
+        n_vec, x_len = x.shape
+        y = torch.empty((n_vec, length), dtype=torch.complex64, device=x.device)
+        fn = self.L.trxhip_convolve_complex_batch if complex_taps else self.L.trxhip_convolve_real_batch
+        rc = fn(self.h, self._dev(x), x_len, self._dev(h), h.shape[0], self._dev(y), length, start, length, n_vec,
+                self._stream(stream))
+        _check(rc, "trxhip_convolve_batch")
+        return y
+
+    def convert_short_float(self, s, stream=None):
+        torch = self.torch
+        out = torch.empty(s.shape, dtype=torch.float32, device=s.device)
+        _check(self.L.trxhip_convert_short_float(self.h, self._dev(out), self._dev(s, torch.int16), s.numel(),
+                                                 self._stream(stream)), "trxhip_convert_short_float")
+        return out
+
+    def channelize(self, wide_iq, n_blocks, m=4, block_len=192, h_len=16, stream=None):
+        """wide_iq: int16[n_blocks*block_len*m, 2] -> complex64[m, n_blocks*block_len]"""
+        torch = self.torch
+        out = torch.empty((m, n_blocks * block_len), dtype=torch.complex64, device=wide_iq.device)
+        _check(self.L.trxhip_channelize_batch(self.h, self._dev(wide_iq, torch.int16), self._dev(out), n_blocks, m,
+                                              block_len, h_len, self._stream(stream)), "trxhip_channelize_batch")
+        return out
+
+    def resample(self, x, p, q, stream=None):
+        """x: complex64[n_chan, n_in] -> complex64[n_chan, n_in*p/q]"""
+        torch = self.torch
+        n_chan, n_in = x.shape
+        n_out = n_in // q * p
+        out = torch.empty((n_chan, n_out), dtype=torch.complex64, device=x.device)
+        _check(self.L.trxhip_resample_batch(self.h, self._dev(x), self._dev(out), n_in, p, q, n_chan, n_in, n_out,
+                                            self._stream(stream)), "trxhip_resample_batch")
+        return out

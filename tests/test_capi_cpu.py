@@ -1,0 +1,118 @@
+"""CPU tests of the product's host side: the C-ABI library loads and exports every symbol that
+include/trxhip.h declares, its host-generated table blob is bit-identical to the oracle's tables, and
+it refuses to run without a GPU (no CPU fallback).  No compute calls here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from osmo_trx_amd import trxhip
+from osmo_trx_amd import build as trx_build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    trx_build.build_lib()
+    return trxhip.load_library()
+
+
+def header_functions():
+    txt = open(os.path.join(ROOT, "include", "trxhip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(trxhip_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = header_functions()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/trxhip.h but not exported"
+    assert sorted(trxhip.SYMBOLS) == names
+    assert lib.trxhip_abi_version() == 1
+
+
+# device blob layout (osmo_trx_amd/csrc/trx_tables.h)
+SEQ = np.dtype([("taps", "<c8", 64), ("gain", "<c8"), ("gain_inv", "<c8"), ("ci_den", "<f4"), ("toa", "<f4"),
+                ("n", "<i4"), ("pad", "<i4")])
+BLOB = np.dtype([("magic", "<u4"), ("version", "<u4"), ("dec_taps", "<f4", 16), ("delay_filt", "<f4", (64, 20)),
+                 ("rrot1", "<c8", 160), ("c0_inv", "<f4", 8), ("seq", SEQ, 21), ("sincv", "<f4", 4096),
+                 ("chan_taps", "<f4", (4, 16)), ("rs6548_taps", "<f4", (65, 16))])
+
+
+def test_tables_bit_identical_to_oracle(lib):
+    blob = trxhip.generate_tables_host()
+    assert len(blob) == BLOB.itemsize == lib.trxhip_tables_size()
+    t = np.frombuffer(blob, dtype=BLOB)[0]
+    o = O.tables()
+    assert t["magic"] == 0x54585254
+    assert np.array_equal(t["dec_taps"], o["dec_taps"])
+    assert np.array_equal(t["delay_filt"], o["delay_filt"])
+    assert np.array_equal(t["rrot1"][:157].view(np.float32), o["rrot1"].view(np.float32))
+    assert np.array_equal(t["c0_inv"][:5], o["c0_inv"])
+
+    def same(seq, ref):
+        assert seq["n"] == ref["n"]
+        assert np.array_equal(seq["taps"][: ref["n"]].view(np.float32), ref["seq"].view(np.float32))
+        assert np.complex64(seq["gain"]) == np.complex64(ref["gain"])
+        assert np.float32(seq["toa"]) == np.float32(ref["toa"])
+
+    for i in range(8):
+        same(t["seq"][i], o["midamble"][i])
+        same(t["seq"][12 + i], o["edge_midamble"][i])
+    for i in range(3):
+        same(t["seq"][8 + i], o["rach"][i])
+    same(t["seq"][11], o["dummy"])
+    same(t["seq"][20], o["sch"])
+    # derived tables: sincv[q ^ ((q>>4)&31)] = sinc LUT of M_PI_F*q/512 (sigProcLib.cpp:990-998)
+    st = o["sinc_table"]
+    pi_f = np.float32(np.pi)
+    for q in list(range(0, 4096, 37)) + [0, 1, 4, 511, 512, 2048, 4095]:
+        x = np.float32(pi_f * np.float32(q / 512.0))
+        v = np.float64(abs(x)) / (8 * np.pi) * 1024
+        ref = 0.0 if np.float64(abs(x)) >= 8 * np.pi else st[int(np.floor(np.float32(v)))]
+        assert t["sincv"][q ^ ((q >> 4) & 31)] == np.float32(ref), q
+    # resampler / channelizer partitions against the oracle's restatements
+    L = O.lib()
+    r = L.orc_resampler_new(65, 48, 16, 1.0)
+    for path in (0, 1, 17, 64):
+        ref = np.ctypeslib.as_array(L.orc_resampler_partition(r, path), shape=(16,))
+        assert np.array_equal(t["rs6548_taps"][path], ref)
+    L.orc_resampler_free(r)
+    c = L.orc_channelizer_new(4, 192, 16)
+    for path in range(4):
+        ref = np.ctypeslib.as_array(L.orc_channelizer_subfilter(c, path), shape=(16,))
+        assert np.array_equal(t["chan_taps"][path], ref)
+    L.orc_channelizer_free(c)
+
+
+def test_checksum_is_stable(lib):
+    a = trxhip.generate_tables_host()
+    b = trxhip.generate_tables_host()
+    assert a == b and trxhip.tables_checksum(a) == trxhip.tables_checksum(b)
+    assert trxhip.tables_checksum(a[:-1] + bytes([a[-1] ^ 1])) != trxhip.tables_checksum(a)
+
+
+def test_no_cpu_fallback(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    h = C.c_void_p()
+    assert lib.trxhip_create(C.byref(h), 0) == -19          # TRXHIP_ENODEV
+    assert lib.trxhip_device_count() == 0
+    with pytest.raises(trxhip.TrxHipError):
+        trxhip.TrxHip(0)
+
+
+def test_product_never_imports_oracle():
+    """The shipped package must not reference oracle/ in any form."""
+    pkg = os.path.join(ROOT, "osmo_trx_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                assert "oracle_lib" not in txt and "trx_oracle" not in txt and "liboracle" not in txt, f

@@ -1,0 +1,162 @@
+"""GPU parity tests (pytest -m gpu): the HIP path, called through the C ABI (include/trxhip.h), against
+the CPU oracle on the same seeded synthetic IQ and against the reference's golden fixtures.
+
+Bars (BASELINE.json north_star: <=1e-4 relative on TOA / RSSI / soft bits):
+  * rc, tsc, clip/idle flags, TOA, amp, soft bits: BIT-EXACT vs the generic-C-order oracle (decisions and
+    every FIR sum keep the reference's operand order; kernels are built with -ffp-contract=off)
+  * energy (tree-summed on the GPU): <= 1e-6 relative;  RSSI (log10): <= 1e-5 dB absolute
+  * C/I (device log2f): <= 2e-5 dB absolute
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def trx():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from osmo_trx_amd import TrxHip
+    return TrxHip(0)
+
+
+def run_gpu(trx, iq, params, sps, soft_stride=148, slice_bits=True, **kw):
+    d_iq = iq.to("cuda:0") if not iq.is_cuda else iq
+    d_p = trx.params_tensor(params)
+    res, soft = trx.detect_demod(d_iq, d_p, sps=sps, soft_stride=soft_stride, slice_bits=slice_bits, **kw)
+    torch.cuda.synchronize()
+    return trx.results_to_numpy(res), soft.cpu().numpy()
+
+
+def check_parity(g_res, g_soft, o_res, o_soft):
+    for f in ("rc", "tsc", "clip", "idle", "nbits_div4"):
+        assert np.array_equal(g_res[f], o_res[f]), f
+    for f in ("toa", "amp_re", "amp_im"):
+        assert np.array_equal(g_res[f], o_res[f]), f
+    assert np.array_equal(g_soft, o_soft)
+    np.testing.assert_allclose(g_res["energy"], o_res["energy"], rtol=1e-6, atol=0)
+    fin = np.isfinite(o_res["rssi"])
+    np.testing.assert_allclose(g_res["rssi"][fin], o_res["rssi"][fin], rtol=0, atol=1e-5)
+    assert np.array_equal(np.isfinite(g_res["rssi"]), fin)
+    np.testing.assert_allclose(g_res["ci"], o_res["ci"], rtol=0, atol=2e-5)
+
+
+def test_normal_bursts_4sps_all_tsc(trx):
+    """BASELINE.json configs[1] at an oracle-sized batch: all 8 TSCs, noise-only and clipped bursts included."""
+    from osmo_trx_amd import synth
+    iq, params, truth = synth.make_normal_bursts(4096, "cpu", 4)
+    o_res, o_soft = O.pull_batch(iq.numpy(), 4, params)
+    g_res, g_soft = run_gpu(trx, iq, params, 4)
+    assert (o_res["rc"] > 0).sum() > 3500 and (o_res["rc"] == 0).sum() > 100
+    check_parity(g_res, g_soft, o_res, o_soft)
+
+
+def test_normal_bursts_wide_window_raw_soft(trx):
+    from osmo_trx_amd import synth
+    iq, params, _ = synth.make_normal_bursts(1024, "cpu", 4, seed=11, max_toa=63, delay_sym=(-2.0, 40.0))
+    o_res, o_soft = O.pull_batch(iq.numpy(), 4, params, soft_stride=156, slice_bits=False)
+    g_res, g_soft = run_gpu(trx, iq, params, 4, soft_stride=156, slice_bits=False)
+    assert (o_res["rc"] > 0).sum() > 800
+    check_parity(g_res, g_soft, o_res, o_soft)
+
+
+@pytest.mark.parametrize("ext", [False, True])
+def test_access_bursts(trx, ext):
+    """BASELINE.json configs[2]: RACH correlation sweep, max_toa 63; EXT_RACH tries TS0/1/2, first hit wins."""
+    from osmo_trx_amd import synth
+    iq, params, _ = synth.make_access_bursts(2048, "cpu", ext=ext)
+    o_res, o_soft = O.pull_batch(iq.numpy(), 4, params)
+    g_res, g_soft = run_gpu(trx, iq, params, 4)
+    assert (o_res["rc"] > 0).sum() > 1800
+    check_parity(g_res, g_soft, o_res, o_soft)
+
+
+def test_mixed_types_idle_off_edge_fallthrough(trx):
+    from osmo_trx_amd import synth
+    iq, params = synth.make_mixed_bursts(2048, "cpu")
+    params = synth.make_idle_off_mix(params)
+    params["type"][5::32] = O.EDGE          # EDGE slots carrying GMSK bursts: falls through to TSC (sigProcLib.cpp:1933-1941)
+    params["tsc"][9::64] = 9                # invalid TSC -> -SIGERR_UNSUPPORTED
+    o_res, o_soft = O.pull_batch(iq.numpy(), 4, params)
+    g_res, g_soft = run_gpu(trx, iq, params, 4)
+    assert set(np.unique(o_res["rc"])) >= {-3, 0, 1, 3}
+    check_parity(g_res, g_soft, o_res, o_soft)
+
+
+@pytest.mark.parametrize("burst_len", [156, 157])
+def test_normal_bursts_1sps_tsc0(trx, burst_len):
+    """BASELINE.json configs[0]: 1k normal bursts, 1 SPS, TSC0 (the reference's CPU-runnable case)."""
+    from osmo_trx_amd import synth
+    iq, params, _ = synth.make_normal_bursts(1000, "cpu", 1, tsc=0, amp_range=(8000, 8000), snr_range=(10, 30),
+                                             delay_sym=(0, 3), p_noise=0.02, p_clip=0.01, burst_len=burst_len)
+    o_res, o_soft = O.pull_batch(iq.numpy(), 1, params)
+    g_res, g_soft = run_gpu(trx, iq, params, 1)
+    assert (o_res["rc"] > 0).sum() > 950
+    check_parity(g_res, g_soft, o_res, o_soft)
+    o_res, o_soft = O.pull_batch(iq.numpy(), 1, params, soft_stride=burst_len, slice_bits=False)
+    g_res, g_soft = run_gpu(trx, iq, params, 1, soft_stride=burst_len, slice_bits=False)
+    check_parity(g_res, g_soft, o_res, o_soft)
+
+
+def test_captured_burst_golden(trx, golden_dir):
+    """The reference's captured burst (utils/va-test) straight through the HIP path as complex64:
+    detectAnyBurst(sv, 7, 4.0, 4, TSC, 40) + demodAnyBurst, 1500 samples (burst-gen.cpp:274-290)."""
+    x = np.fromfile(os.path.join(golden_dir, "nb_chunk_tsc7.cfile"), dtype=np.complex64)
+    bits = np.fromfile(os.path.join(golden_dir, "demodbits_tsc7.s8"), dtype=np.int8)
+    params = np.zeros(1, dtype=O.PARAMS_DTYPE)
+    params["type"], params["tsc"], params["max_toa"] = O.TSC, 7, 40
+    d_iq = torch.from_numpy(x.copy()).view(1, 1500).to("cuda:0")
+    g_res, g_soft = run_gpu(trx, d_iq, params, 4, soft_stride=156, slice_bits=False, full_scale=1.0)
+    r = g_res[0]
+    assert r["rc"] == O.TSC
+    assert r["toa"] == np.float32(12.535156)                       # SURVEY.md Appendix A (compiled reference)
+    assert abs(r["amp_re"] + 0.00112989) < 1e-8 and abs(r["amp_im"] - 0.00166411) < 1e-8
+    assert abs(r["ci"] - 6.460016) < 2e-5
+    assert np.array_equal(g_soft[0, :148] > 0, bits > 0)           # 0/148 bit errors
+    rc, e = O.detect_any_burst(x, 7, 4.0, 4, O.TSC, 40)
+    o_soft = O.demod_any_burst(x, rc, 4, e)
+    assert np.array_equal(g_soft[0], o_soft)
+
+
+def test_full_size_properties(trx):
+    """BASELINE.json configs[1] at full size (1M bursts on the device): size-independent properties.
+    (a) batch-position independence: a shuffled copy of the batch gives the shuffled results;
+    (b) a random sample of the 1M results matches the oracle bit-for-bit;
+    (c) detection statistics: every burst with signal is found, no noise-only burst passes with a sane C/I."""
+    from osmo_trx_amd import synth
+    n = 1 << 20
+    iq, params, truth = synth.make_normal_bursts(n, "cuda:0", 4)
+    d_p = trx.params_tensor(params)
+    res, soft = trx.detect_demod(iq, d_p, sps=4)
+    perm = torch.randperm(n, device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(3))
+    res2, soft2 = trx.detect_demod(iq[perm].contiguous(), d_p[perm].contiguous(), sps=4)
+    torch.cuda.synchronize()
+    assert torch.equal(res[perm], res2) and torch.equal(soft[perm], soft2)
+    r = trx.results_to_numpy(res)
+    sig = ~truth["noise_only"]
+    assert (r["rc"][sig & ~truth["clipped"]] == 1).mean() > 0.9995
+    assert (r["rc"][truth["noise_only"]] > 0).mean() < 0.02
+    ok = (r["rc"] > 0) & sig
+    assert abs(np.mean(r["toa"][ok] - truth["delay_sym"][ok])) < 0.05
+    sel = np.random.default_rng(5).choice(n, 2048, replace=False)
+    o_res, o_soft = O.pull_batch(iq[torch.from_numpy(sel).to("cuda:0")].cpu().numpy(), 4, params[sel])
+    check_parity(r[sel], soft[torch.from_numpy(sel).to("cuda:0")].cpu().numpy(), o_res, o_soft)
+
+
+def test_argument_errors(trx):
+    iq = torch.zeros((4, 625, 2), dtype=torch.int16, device="cuda:0")
+    p = torch.zeros((4, 8), dtype=torch.uint8, device="cuda:0")
+    from osmo_trx_amd import TrxHipError
+    with pytest.raises(TrxHipError):
+        trx.detect_demod(iq, p, sps=2)
+    with pytest.raises(TrxHipError):
+        trx.detect_demod(iq[:, :600].contiguous(), p, sps=4)
+    # empty batch is a no-op
+    trx.detect_demod(iq[:0], p[:0], sps=4)
