@@ -1,0 +1,87 @@
+"""Multi-GPU plumbing: one process per GPU, bursts sharded by contiguous ranges, tables broadcast once.
+
+Bursts are independent: rank g of G owns bursts [g*N/G, (g+1)*N/G) and there is NO
+data-path collective.  The only collective is the init-time broadcast of the ~45 KB table blob from rank 0
+(RCCL over xGMI when the backend is "nccl", gloo in the CPU tests), verified by checksum on every rank.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import trxhip
+
+
+def env_world():
+    """(rank, local_rank, world_size) from the torchrun environment (1 process when unset)."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init_distributed(backend=None):
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_range(n_total, rank, world):
+    """Contiguous range of bursts owned by `rank`: [lo, hi)."""
+    lo = (n_total * rank) // world
+    hi = (n_total * (rank + 1)) // world
+    return lo, hi
+
+
+def broadcast_tables(device=None):
+    """Rank 0 generates the table blob on the host; everyone receives it (RCCL/gloo broadcast) and checks
+    the FNV-1a checksum.  Returns the blob as bytes."""
+    rank, _, world = env_world()
+    size = int(trxhip.load_library().trxhip_tables_size())
+    if world == 1 or not dist.is_initialized():
+        return trxhip.generate_tables_host()
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    if rank == 0:
+        blob = trxhip.generate_tables_host()
+        t = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+        ck = torch.tensor([trxhip.tables_checksum(blob) & 0x7FFFFFFFFFFFFFFF], dtype=torch.int64, device=dev)
+    else:
+        t = torch.zeros(size, dtype=torch.uint8, device=dev)
+        ck = torch.zeros(1, dtype=torch.int64, device=dev)
+    dist.broadcast(t, src=0)
+    dist.broadcast(ck, src=0)
+    blob = t.cpu().numpy().tobytes()
+    if (trxhip.tables_checksum(blob) & 0x7FFFFFFFFFFFFFFF) != int(ck.item()):
+        raise trxhip.TrxHipError(f"rank {rank}: table blob checksum mismatch after broadcast")
+    return blob
+
+
+def max_over_ranks(value, device=None):
+    rank, _, world = env_world()
+    if world == 1 or not dist.is_initialized():
+        return float(value)
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value, device=None):
+    rank, _, world = env_world()
+    if world == 1 or not dist.is_initialized():
+        return float(value)
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def barrier():
+    if dist.is_initialized():
+        dist.barrier()

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output (gpurun_out/prof_*) into the small files committed under profiles/.
+
+  python profiles/summarize.py <tag>      e.g. r01a
+Reads  gpurun_out/prof_stats/<tag>_kernel_stats.csv        (rocprofv3 --kernel-trace --stats)
+       gpurun_out/prof_fetch/<tag>_counter_collection.csv  (rocprofv3 --pmc FETCH_SIZE)
+       gpurun_out/prof_write/<tag>_counter_collection.csv  (rocprofv3 --pmc WRITE_SIZE)
+Writes profiles/<tag>_kernel_stats.csv (verbatim), profiles/<tag>_pmc.json, and profiles/pmc_traffic.json
+(the per-burst HBM traffic bench.py reports in roofline.traffic).
+
+HBM bytes follow MI355X_MICROARCH.md "HBM": bytes = counter * 1024; on gfx950 FETCH_SIZE reports half of
+the bytes of a coalesced streaming read, so the read side is doubled (checked here against the known
+2500 B/burst input: 2 x FETCH = 1.02 x algorithmic); WRITE_SIZE is used as is (1.02 x algorithmic).
+"""
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "gpurun_out")
+KERNEL = "burst_pull_kernel<4, false>"
+
+
+def counter(path, name):
+    vals = []
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if KERNEL in row["Kernel_Name"] and row["Counter_Name"] == name:
+                vals.append(float(row["Counter_Value"]))
+    return vals
+
+
+def main(tag, bursts=1 << 20):
+    shutil.copyfile(os.path.join(G, "prof_stats", f"{tag}_kernel_stats.csv"),
+                    os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"))
+    stats = {}
+    with open(os.path.join(G, "prof_stats", f"{tag}_kernel_stats.csv")) as f:
+        for row in csv.DictReader(f):
+            if KERNEL in row["Name"]:
+                stats = {"calls": int(row["Calls"]), "avg_ns": float(row["AverageNs"]), "min_ns": int(row["MinNs"]),
+                         "max_ns": int(row["MaxNs"])}
+    fetch = counter(os.path.join(G, "prof_fetch", f"{tag}_counter_collection.csv"), "FETCH_SIZE")
+    write = counter(os.path.join(G, "prof_write", f"{tag}_counter_collection.csv"), "WRITE_SIZE")
+    fetch_b = 2.0 * 1024.0 * sum(fetch) / len(fetch)        # gfx950 half-count correction
+    write_b = 1024.0 * sum(write) / len(write)
+    out = {
+        "tag": tag, "kernel": KERNEL, "bursts_per_launch": bursts, "kernel_trace": stats,
+        "FETCH_SIZE_KB_raw_avg": sum(fetch) / len(fetch), "WRITE_SIZE_KB_avg": sum(write) / len(write),
+        "hbm_read_bytes_per_launch": fetch_b, "hbm_write_bytes_per_launch": write_b,
+        "hbm_bytes_per_burst": (fetch_b + write_b) / bursts,
+        "algorithmic_bytes_per_burst": 3132,
+        "note": "read side = 2 x FETCH_SIZE x 1024 (gfx950 half-count, MI355X_MICROARCH.md HBM section); "
+                "separate --pmc passes for FETCH_SIZE and WRITE_SIZE",
+    }
+    json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_pmc.json"), "w"), indent=1)
+    json.dump({"tag": tag, "hbm_bytes_per_burst": out["hbm_bytes_per_burst"]},
+              open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"))
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

@@ -1,0 +1,73 @@
+"""world_size-2 gloo tests (CPU): the N>1 path of bench.py -- contiguous sharding with no data-path
+collective, and the init-time table broadcast with checksum verification."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, json
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from osmo_trx_amd import shard, trxhip
+rank, local_rank, world = shard.init_distributed("gloo")
+assert world == 2 and dist.get_backend() == "gloo"
+blob = shard.broadcast_tables()                      # rank 0 generates, rank 1 receives + verifies checksum
+ck = trxhip.tables_checksum(blob)
+lo, hi = shard.shard_range(1000003, rank, world)
+tot = shard.sum_over_ranks(hi - lo)
+mx = shard.max_over_ranks(float(rank + 1))
+shard.barrier()
+print(json.dumps({"rank": rank, "ck": ck, "lo": lo, "hi": hi, "tot": tot, "mx": mx, "n": len(blob)}))
+dist.destroy_process_group()
+'''
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_rank_table_broadcast_and_sharding(tmp_path):
+    from osmo_trx_amd import build as trx_build, trxhip
+    trx_build.build_lib()
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=240)
+        assert p.returncode == 0, e[-2000:]
+        import json
+        outs.append(json.loads(o.strip().splitlines()[-1]))
+    outs.sort(key=lambda d: d["rank"])
+    local = trxhip.generate_tables_host()
+    assert outs[0]["ck"] == outs[1]["ck"] == trxhip.tables_checksum(local)
+    assert outs[0]["n"] == len(local)
+    assert outs[0]["lo"] == 0 and outs[0]["hi"] == outs[1]["lo"] and outs[1]["hi"] == 1000003
+    assert outs[0]["tot"] == outs[1]["tot"] == 1000003
+    assert outs[0]["mx"] == outs[1]["mx"] == 2.0
+
+
+def test_shard_ranges_partition_exactly():
+    from osmo_trx_amd import shard
+    for n in (0, 1, 7, 8, 1 << 20, 8388608, 1000003):
+        for world in (1, 2, 4, 8):
+            r = [shard.shard_range(n, k, world) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(r[k][1] == r[k + 1][0] for k in range(world - 1))
+            sizes = [b - a for a, b in r]
+            assert max(sizes) - min(sizes) <= 1
