@@ -27,6 +27,7 @@
 // differ at the last-ulp level.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "trx_tables.h"
 #include "../../include/trxhip.h"
@@ -35,6 +36,9 @@
 #define TRX_PAD 20                 // zero samples kept on both sides of a burst in LDS
 #define TRX_DEC_LEN 160            // decimated burst (156 used)
 #define TRX_CORR_MAX 128           // head + tail <= 16 + TRXHIP_MAX_TOA
+#define TRX_CZ_PAD 12              // zero samples either side of the correlation (interpolatePoint reach)
+#define TRX_CZ_LEN (TRX_CZ_PAD + TRX_CORR_MAX + TRX_CZ_PAD)
+#define TRX_SINCV_LDS (TRX_SINCV_LEN + 32)   // + zero tail: q = 4096 is addressed when the fraction is 0
 #define TRX_CLIP_THRESH 30000.0f   // sigProcLib.cpp:49
 #define TRX_WPB 8                  // waves (= bursts in flight) per workgroup
 
@@ -53,6 +57,11 @@ __device__ __forceinline__ void wave_sync()
 }
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// value held by lane `l` (l wave-uniform): v_readlane_b32, no LDS round trip
+__device__ __forceinline__ float lane_val(float v, int l)
+{
+	return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), __builtin_amdgcn_readfirstlane(l)));
+}
 __device__ __forceinline__ float unif(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 
 // Complex.h:113 norm2(): i*i + r*r
@@ -80,7 +89,7 @@ __device__ __forceinline__ float wave_sum(float v)
 struct WaveLds {
 	c32 *xs;      // [TRX_PAD + L + TRX_PAD]   burst, later overwritten in place by the delayed+scaled burst
 	c32 *dec;     // [TRX_DEC_LEN]             1-SPS burst (decimated) ; zero beyond 156
-	c32 *corr;    // [TRX_CORR_MAX]
+	c32 *corr;    // [TRX_CZ_LEN]  zero-padded correlation
 };
 
 struct SeqWin {   // one detectGeneralBurst() call: sequence + window (sigProcLib.cpp:1732-1771)
@@ -90,62 +99,74 @@ struct SeqWin {   // one detectGeneralBurst() call: sequence + window (sigProcLi
 
 // ------------------------------------------------------------------------------------------------
 // interpolatePoint() for one candidate position per lane (sigProcLib.cpp:1100-1118)
-//   ix512 = position in 1/512 symbol units; corr[0..size) in LDS; sincv = swizzled LDS table
+//   cz    = zero-padded correlation in LDS: cz[i] = corr[i] for 0 <= i < size-1, 0 elsewhere in
+//           [-TRX_CZ_PAD, size + TRX_CZ_PAD).  The reference sums i in [max(0,fl-10), min(size-1,fl+11)):
+//           note the last sample (size-1) is never used (":1105 end = size-1; i < end"), hence zeroed.
+//   ix512 = position in 1/512 symbol units (multiples of 1/512 are all peakDetect() ever asks for)
+//   sincv = swizzled LDS table, sincv[swz(q)] = sinc(M_PI_F * q/512), 0 for q >= 4096
+// Of the 21 taps only i = fl-7 .. fl+8 can be non-zero (|i - ix| < 8, the LUT is 0 beyond 8*pi);
+// dropping the others only drops additions of +-0.  q = |i*512 - ix512| is affine in the tap index on
+// either side of the peak, so the LUT address is one per-lane base plus a compile-time offset.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ c32 interp_point(const c32 *corr, int size, int ix512, const float *sincv)
+__device__ __forceinline__ c32 interp_point(const c32 *cz, int ix512, const float *sincv)
 {
 	const int fl = ix512 >> 9;                       // floor(ix)
-	int start = fl - 10;
-	if (start < 0) start = 0;
-	int end = fl + 11;
-	if ((unsigned)end > (unsigned)(size - 1)) end = size - 1;
+	const int f = ix512 & 511;                       // fractional part * 512
+	const int fs = trx_sincv_swz(f);                 // taps i <= fl : q = 512*(fl-i) + f
+	const int g = 512 - f;                           // taps i >  fl : q = 512*(i-fl-1) + (512 - f)
+	const int gs = (f == 0) ? 512 : trx_sincv_swz(g);
+	const c32 *c = cz + (fl - 7);
+	const float *sa = sincv + fs;
+	const float *sb = sincv + gs;
 	c32 p = make_float2(0.0f, 0.0f);
 #pragma unroll
-	for (int t = 0; t < 21; t++) {
-		const int i = fl - 10 + t;
-		const bool ok = (i >= start) && (i < end);
-		const int ic = ok ? i : 0;
-		int q = i * 512 - ix512;                     // (i - ix) * 512, exact
-		q = q < 0 ? -q : q;
-		const float s = (q < TRX_SINCV_LEN) ? sincv[trx_sincv_swz(q & (TRX_SINCV_LEN - 1))] : 0.0f;
-		const c32 c = corr[ic];
-		if (ok) {                                    // pVal += inSig[i] * sinc(M_PI_F*(i-ix))
-			p.x += c.x * s;
-			p.y += c.y * s;
-		}
+	for (int u = 0; u < 8; u++) {                    // i = fl-7 .. fl   (k = 7 .. 0)
+		const c32 v = c[u];
+		const float w = sa[512 * (7 - u)];
+		p.x += v.x * w;
+		p.y += v.y * w;
+	}
+#pragma unroll
+	for (int u = 0; u < 8; u++) {                    // i = fl+1 .. fl+8 (k = 0 .. 7)
+		const c32 v = c[8 + u];
+		const float w = sb[512 * u];
+		p.x += v.x * w;
+		p.y += v.y * w;
 	}
 	return p;
+}
+
+// earlyIndex offset (1/512 units) of heap node n of a bisection subtree whose first step is `inc0`:
+// node n = (1<<L) + p - 1 at level L with path bits p (MSB first, 1 = "+incr"):
+//   off = sum_{j<L} (+-)(inc0 >> j) = ((4*p*inc0) >> L) - (2*inc0 - ((2*inc0) >> L))
+__device__ __forceinline__ int node_offset(int n, int inc0)
+{
+	const int L = 31 - __clz(n + 1);
+	const int p = n + 1 - (1 << L);
+	return ((4 * p * inc0) >> L) - (2 * inc0 - ((2 * inc0) >> L));
 }
 
 // ------------------------------------------------------------------------------------------------
 // peakDetect() (sigProcLib.cpp:1141-1186) with the early/late bisection expanded across lanes.
 // All lanes return the same (toa512, value).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void peak_detect_spec(const c32 *corr, int size, int max_idx, const float *sincv,
+__device__ __forceinline__ void peak_detect_spec(const c32 *cz, int max_idx, const float *sincv,
 						  int lane, int *toa512_out, c32 *val_out)
 {
-	int E = (max_idx - 1) << 9;                      // earlyIndex * 512
+	int E = (max_idx - 1) * 512;                     // earlyIndex * 512
 	bool tie = false;
 
-	// ---- round A: levels 0..4 (incr = 1/2 .. 1/32): heap node n = (1<<L)+p-1, lanes 2n (early), 2n+1 (late)
+	// ---- round A: levels 0..4 (incr = 1/2 .. 1/32): heap node n on lanes 2n (early) and 2n+1 (late)
 	{
-		const int n = lane >> 1;
-		int L = 31 - __clz(n + 1);                   // level of this lane's node
-		int p = n + 1 - (1 << L);
-		int off = 0;
-		for (int j = 0; j < L; j++) {                // offset of the node's earlyIndex
-			const int bit = (p >> (L - 1 - j)) & 1;
-			off += bit ? (256 >> j) : -(256 >> j);
-		}
-		const int ix = E + off + ((lane & 1) ? 1024 : 0);
+		const int ix = E + node_offset(lane >> 1, 256) + ((lane & 1) ? 1024 : 0);
 		float nv = 0.0f;
 		if (lane < 62)
-			nv = norm2(interp_point(corr, size, ix, sincv));
+			nv = norm2(interp_point(cz, ix, sincv));
 		int node = 0;
 #pragma unroll
 		for (int Lw = 0; Lw < 5; Lw++) {
-			const float ne = __shfl(nv, 2 * node, WAVE);
-			const float nl = __shfl(nv, 2 * node + 1, WAVE);
+			const float ne = lane_val(nv, 2 * node);
+			const float nl = lane_val(nv, 2 * node + 1);
 			if (!tie) {
 				if (ne < nl)      { E += (256 >> Lw); node = 2 * node + 2; }
 				else if (ne > nl) { E -= (256 >> Lw); node = 2 * node + 1; }
@@ -159,28 +180,19 @@ __device__ __forceinline__ void peak_detect_spec(const c32 *corr, int size, int 
 		// ---- round B: levels 5..8 (incr = 1/64 .. 1/512) on lanes 0..29, the 16 possible final
 		// positions (earlyIndex + 1) on lanes 32..47
 		int ix;
-		if (lane < 32) {
-			const int n = lane >> 1;
-			int L = 31 - __clz(n + 1);
-			int p = n + 1 - (1 << L);
-			int off = 0;
-			for (int j = 0; j < L; j++) {
-				const int bit = (p >> (L - 1 - j)) & 1;
-				off += bit ? (8 >> j) : -(8 >> j);
-			}
-			ix = E + off + ((lane & 1) ? 1024 : 0);
-		} else {
+		if (lane < 32)
+			ix = E + node_offset(lane >> 1, 8) + ((lane & 1) ? 1024 : 0);
+		else
 			ix = E + (2 * (lane & 15) - 15) + 512;
-		}
 		c32 pv = make_float2(0.0f, 0.0f);
 		if (lane < 30 || (lane >= 32 && lane < 48))
-			pv = interp_point(corr, size, ix, sincv);
+			pv = interp_point(cz, ix, sincv);
 		const float nv = norm2(pv);
 		int node = 0, offB = 0;
 #pragma unroll
 		for (int Lw = 0; Lw < 4; Lw++) {
-			const float ne = __shfl(nv, 2 * node, WAVE);
-			const float nl = __shfl(nv, 2 * node + 1, WAVE);
+			const float ne = lane_val(nv, 2 * node);
+			const float nl = lane_val(nv, 2 * node + 1);
 			if (!tie) {
 				if (ne < nl)      { offB += (8 >> Lw); node = 2 * node + 2; }
 				else if (ne > nl) { offB -= (8 >> Lw); node = 2 * node + 1; }
@@ -190,12 +202,12 @@ __device__ __forceinline__ void peak_detect_spec(const c32 *corr, int size, int 
 		E += offB;
 		final_ix = E + 512;
 		const int src = 32 + ((offB + 15) >> 1);     // lane that evaluated this final position
-		val.x = __shfl(pv.x, src, WAVE);
-		val.y = __shfl(pv.y, src, WAVE);
+		val.x = lane_val(pv.x, src);
+		val.y = lane_val(pv.y, src);
 	}
 	if (tie) {                                        // rare: equal early/late power -> loop left early
 		final_ix = E + 512;
-		val = interp_point(corr, size, final_ix, sincv);
+		val = interp_point(cz, final_ix, sincv);
 	}
 	*toa512_out = final_ix;
 	*val_out = val;
@@ -205,33 +217,42 @@ __device__ __forceinline__ void peak_detect_spec(const c32 *corr, int size, int 
 // detectBurst() on the 1-SPS signal `sig[0..sig_len)` (sigProcLib.cpp:1649-1709), corr in LDS.
 // Returns rc (1 / 0); on 1 fills toa (symbols, before "- head"), amp, ci.  Wave-uniform.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int detect_burst(const c32 *sig, int sig_len, c32 *corr, const trx_seq *__restrict__ sq,
+__device__ __forceinline__ int detect_burst(const c32 *sig, int sig_len, c32 *cz, const trx_seq *__restrict__ sq,
 					     float thresh, int start, int len, const float *sincv, int lane,
 					     float *toa_out, c32 *amp_out, float *ci_out)
 {
 	const int N = sq->n;
 
 	// ---- correlate: corr[i] = sum_k SIG(i + start - (N-1) + k) * seq[k]   (:1674, convolve_base.c:72-85)
+	// N is 16 (TSC/EDGE/dummy), 40 (RACH) or 64 (SCH): tap loop unrolled by 8 so the LDS reads pipeline
 	for (int i = lane; i < len; i += WAVE) {
 		float yr = 0.0f, yi = 0.0f;
 		const int base = i + start - (N - 1);
-		for (int k = 0; k < N; k++) {
-			const int j = base + k;
-			c32 x = make_float2(0.0f, 0.0f);
-			if (j >= 0 && j < sig_len) x = sig[j];
-			const float hr = sq->taps[k].re, hi = sq->taps[k].im;   // wave-uniform -> scalar loads
-			yr += x.x * hr - x.y * hi;
-			yi += x.x * hi + x.y * hr;
+		for (int k0 = 0; k0 < N; k0 += 8) {
+			c32 x[8];
+#pragma unroll
+			for (int u = 0; u < 8; u++) {
+				const int j = base + k0 + u;
+				x[u] = (j >= 0 && j < sig_len) ? sig[j] : make_float2(0.0f, 0.0f);
+			}
+#pragma unroll
+			for (int u = 0; u < 8; u++) {
+				const float hr = sq->taps[k0 + u].re, hi = sq->taps[k0 + u].im;   // wave-uniform -> scalar loads
+				yr += x[u].x * hr - x[u].y * hi;
+				yi += x[u].x * hi + x[u].y * hr;
+			}
 		}
-		corr[i] = make_float2(yr, yi);
+		cz[i] = make_float2(yr, yi);
 	}
+	if (lane < TRX_CZ_PAD)
+		cz[len + lane] = make_float2(0.0f, 0.0f);          // right zero pad (len varies per burst)
 	wave_sync();
 
 	// ---- fastPeakDetect (:1120-1139): first strict maximum of |corr|^2
 	float best = 0.0f;
 	int bidx = -1;
 	for (int i = lane; i < len; i += WAVE) {
-		const float v = norm2(corr[i]);
+		const float v = norm2(cz[i]);
 		if (v > best) { best = v; bidx = i; }
 	}
 #pragma unroll
@@ -246,7 +267,7 @@ __device__ __forceinline__ int detect_burst(const c32 *sig, int sig_len, c32 *co
 	const float toa0 = (float)bidx;
 	if ((toa0 < 3.0f) || (toa0 > (float)(len - 3)))   // :1683
 		return 0;
-	const c32 amp0 = corr[bidx];
+	const c32 amp0 = cz[bidx];
 
 	// ---- computePeakRatio (:1541-1571), sequential sum (it gates a decision)
 	{
@@ -255,8 +276,8 @@ __device__ __forceinline__ int detect_burst(const c32 *sig, int sig_len, c32 *co
 		const int peak = bidx;                       // rint(toa) of an integer
 #pragma unroll
 		for (int i = 2; i <= 5; i++) {
-			if (peak - i >= 0)  { avg += norm2(corr[peak - i]); num++; }
-			if (peak + i < len) { avg += norm2(corr[peak + i]); num++; }
+			if (peak - i >= 0)  { avg += norm2(cz[peak - i]); num++; }
+			if (peak + i < len) { avg += norm2(cz[peak + i]); num++; }
 		}
 		if (num < 5)
 			return 0;
@@ -269,7 +290,12 @@ __device__ __forceinline__ int detect_burst(const c32 *sig, int sig_len, c32 *co
 	// ---- peakDetect (:1695): refined TOA (multiple of 1/512) and interpolated correlation value
 	int toa512;
 	c32 xcorr;
-	peak_detect_spec(corr, len, bidx, sincv, lane, &toa512, &xcorr);
+	// interpolatePoint() never reads the last correlation sample (:1105, :1109): zero it in the padded copy
+	wave_sync();
+	if (lane == 0)
+		cz[len - 1] = make_float2(0.0f, 0.0f);
+	wave_sync();
+	peak_detect_spec(cz, bidx, sincv, lane, &toa512, &xcorr);
 	toa512 = uni(toa512);
 	xcorr.x = unif(xcorr.x);
 	xcorr.y = unif(xcorr.y);
@@ -282,9 +308,11 @@ __device__ __forceinline__ int detect_burst(const c32 *sig, int sig_len, c32 *co
 		const int rt = (toa512 >= 0) ? ((toa512 + 256) >> 9) : -((-toa512 + 256) >> 9);
 		const int ps = start + 1 - N + rt;
 		if (ps >= 0 && ps + N <= sig_len) {
+			// S = sum_i |sig[ps+i]|^2 in index order: lane i squares one sample, the sum walks the lanes
+			const float pw = norm2(sig[ps + (lane < N ? lane : 0)]);
 			float S = 0.0f;
 			for (int i = 0; i < N; i++)
-				S += norm2(sig[ps + i]);
+				S += lane_val(pw, i);
 			S /= (float)N;
 			const float C = norm2(xcorr) / sq->ci_den;
 			ci = 3.0103f * log2f(C / (S - C));
@@ -300,8 +328,8 @@ __device__ __forceinline__ int detect_burst(const c32 *sig, int sig_len, c32 *co
 // ------------------------------------------------------------------------------------------------
 // the hot kernel
 // ------------------------------------------------------------------------------------------------
-template <int SPS, bool CF32>
-__global__ void __launch_bounds__(TRX_WPB * WAVE)
+template <int SPS, bool CF32, int NLD, int WPB>
+__global__ void __launch_bounds__(WPB * WAVE, (WPB == 8) ? 4 : 3)
 burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__restrict__ params,
 		  trxhip_burst_result *__restrict__ results, float *__restrict__ soft,
 		  const trx_tables *__restrict__ tab,
@@ -315,22 +343,55 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 	// ---- LDS carve: [sincv 16 KB | per-wave slices]
 	float *sincv = reinterpret_cast<float *>(smem);
 	const int xs_len = TRX_PAD + L + TRX_PAD;
-	const int slice_c32 = ((xs_len + 1) & ~1) + TRX_DEC_LEN + TRX_CORR_MAX;
-	c32 *wbase = reinterpret_cast<c32 *>(smem + TRX_SINCV_LEN * sizeof(float)) + (size_t)wave * slice_c32;
+	const int slice_c32 = ((xs_len + 1) & ~1) + TRX_DEC_LEN + TRX_CZ_LEN;
+	c32 *wbase = reinterpret_cast<c32 *>(smem + TRX_SINCV_LDS * sizeof(float)) + (size_t)wave * slice_c32;
 	WaveLds w;
 	w.xs = wbase;
 	w.dec = wbase + ((xs_len + 1) & ~1);
 	w.corr = w.dec + TRX_DEC_LEN;
 
 	// one-time staging (block-wide): sinc LUT; zero this wave's pads
-	for (int i = threadIdx.x; i < TRX_SINCV_LEN; i += blockDim.x)
-		sincv[i] = tab->sincv[i];
+	for (int i = threadIdx.x; i < TRX_SINCV_LDS; i += blockDim.x)
+		sincv[i] = (i < TRX_SINCV_LEN) ? tab->sincv[i] : 0.0f;
 	for (int i = lane; i < slice_c32; i += WAVE)
 		wbase[i] = make_float2(0.0f, 0.0f);
 	__syncthreads();
 
 	const unsigned total_waves = gridDim.x * waves_per_block;
-	for (unsigned b = blockIdx.x * waves_per_block + wave; b < n_bursts; b += total_waves) {
+	const unsigned first = blockIdx.x * waves_per_block + wave;
+
+	// Software prefetch: the raw samples of this wave's NEXT burst sit in registers (NLD dwords per lane,
+	// coalesced 256 B per wave-load) while the current burst is being processed, so the ~1-2 us HBM
+	// latency is hidden behind compute instead of being paid serially per burst.  NLD == 0: generic
+	// burst lengths, plain loop.
+	uint32_t pre_i[NLD > 0 ? NLD : 1];
+	c32 pre_c[(NLD > 0 && CF32) ? NLD : 1];
+	auto prefetch = [&](unsigned bb) {
+		if (CF32) {
+			const c32 *src = reinterpret_cast<const c32 *>(iq_) + (size_t)bb * L;
+#pragma unroll
+			for (int r = 0; r < NLD; r++) {
+				const int i = r * WAVE + lane;
+				pre_c[r] = (i < L) ? src[i] : make_float2(0.0f, 0.0f);
+			}
+		} else {
+			const uint32_t *src = reinterpret_cast<const uint32_t *>(iq_) + (size_t)bb * L;
+#pragma unroll
+			for (int r = 0; r < NLD; r++) {
+				const int i = r * WAVE + lane;
+				pre_i[r] = (i < L) ? src[i] : 0u;
+			}
+		}
+	};
+	if (NLD > 0 && first < n_bursts)
+		prefetch(first);
+
+	const int lane_outer = lane;
+	for (unsigned b = first; b < n_bursts; b += total_waves) {
+		// Re-materialise the lane id per burst: keeps the compiler from hoisting every lane-derived
+		// address/predicate of every phase out of this loop (which cost ~70 spilled VGPRs).
+		int lane_opaque = lane_outer;
+		const int lane = lane_opaque;
 		const trxhip_burst_params prm = params[b];
 		const int type = uni(prm.type);
 		const int tsc = uni(prm.tsc);
@@ -342,25 +403,40 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 		int out_tsc = 0, clip = 0, idle = 1, nbits = 0;
 		float *so = soft ? soft + (size_t)b * soft_stride : nullptr;
 
-		if (type != TRXHIP_OFF) {                                   // Transceiver.cpp:704-707
-			// ---- phase 0: HBM -> fp32 LDS (convert_short_float fused into the load), clip scan
-			float amax = 0.0f;
-			if (CF32) {
-				const c32 *src = reinterpret_cast<const c32 *>(iq_) + (size_t)b * L;
-				for (int i = lane; i < L; i += WAVE) {
-					const c32 v = src[i];
-					w.xs[TRX_PAD + i] = v;
-					amax = fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y)));
-				}
-			} else {
-				const uint32_t *src = reinterpret_cast<const uint32_t *>(iq_) + (size_t)b * L;
-				for (int i = lane; i < L; i += WAVE) {
-					const uint32_t u = src[i];
-					const c32 v = make_float2((float)(int16_t)(u & 0xffffu), (float)(int16_t)(u >> 16));
+		// ---- phase 0: HBM -> fp32 LDS (convert_short_float fused into the load), clip scan
+		float amax = 0.0f;
+		if (NLD > 0) {
+#pragma unroll
+			for (int r = 0; r < NLD; r++) {
+				const int i = r * WAVE + lane;
+				if (i < L) {
+					c32 v;
+					if (CF32) v = pre_c[r];
+					else v = make_float2((float)(int16_t)(pre_i[r] & 0xffffu), (float)(int16_t)(pre_i[r] >> 16));
 					w.xs[TRX_PAD + i] = v;
 					amax = fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y)));
 				}
 			}
+			if (b + total_waves < n_bursts)
+				prefetch(b + total_waves);
+		} else if (CF32) {
+			const c32 *src = reinterpret_cast<const c32 *>(iq_) + (size_t)b * L;
+			for (int i = lane; i < L; i += WAVE) {
+				const c32 v = src[i];
+				w.xs[TRX_PAD + i] = v;
+				amax = fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y)));
+			}
+		} else {
+			const uint32_t *src = reinterpret_cast<const uint32_t *>(iq_) + (size_t)b * L;
+			for (int i = lane; i < L; i += WAVE) {
+				const uint32_t u = src[i];
+				const c32 v = make_float2((float)(int16_t)(u & 0xffffu), (float)(int16_t)(u >> 16));
+				w.xs[TRX_PAD + i] = v;
+				amax = fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y)));
+			}
+		}
+
+		if (type != TRXHIP_OFF) {                                   // Transceiver.cpp:704-707
 			amax = wave_max(amax);                                  // maxAmplitude(), :1711-1722
 			clip = amax > TRX_CLIP_THRESH;
 			wave_sync();
@@ -439,7 +515,7 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 					}
 
 					float t; c32 a; float cc;
-					const int hit = detect_burst(sig, sig_len, w.corr, sq, thresh, start, len, sincv, lane, &t, &a, &cc);
+					const int hit = detect_burst(sig, sig_len, w.corr + TRX_CZ_PAD, sq, thresh, start, len, sincv, lane, &t, &a, &cc);
 					wave_sync();
 					if (hit) {
 						rc = 1;
@@ -484,20 +560,27 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 				const c32 *xp = w.xs + TRX_PAD + mc - 9;
 				if (use_filt) {
 					// fshift[m] = sum_k X(m - 9 + k) * h[k]  (convolve NO_DELAY, 20 real taps; :1060)
+					// tap-outer / output-inner: each output still accumulates k = 0..19 in order, but only a
+					// sliding window of R samples (+ R accumulators) is live instead of all R+19 inputs
+					constexpr int D = 3;                                    // LDS read-ahead, in taps
 					c32 xr[R + 19];
 #pragma unroll
-					for (int t = 0; t < R + 19; t++)
-						xr[t] = xp[t];
+					for (int j = 0; j < R; j++)
+						yv[j] = make_float2(0.0f, 0.0f);
 #pragma unroll
-					for (int j = 0; j < R; j++) {
-						float yr = 0.0f, yi = 0.0f;
+					for (int j = 0; j < R - 1 + D; j++)
+						xr[j] = xp[j];
 #pragma unroll
-						for (int k = 0; k < 20; k++) {
-							const float h = hf[k];
-							yr += xr[j + k].x * h;
-							yi += xr[j + k].y * h;
+					for (int k = 0; k < 20; k++) {
+						const float h = hf[k];
+						if (R - 1 + D + k < R + 19)
+							xr[R - 1 + D + k] = xp[R - 1 + D + k];
+#pragma unroll
+						for (int j = 0; j < R; j++) {
+							yv[j].x += xr[j + k].x * h;
+							yv[j].y += xr[j + k].y * h;
 						}
-						yv[j] = make_float2(yr, yi);
+						__builtin_amdgcn_sched_barrier(0);              // keep the window short: no load hoisting
 					}
 				} else {
 #pragma unroll
@@ -599,8 +682,8 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 extern "C" size_t trx_pull_lds_bytes(int L, int waves_per_block)
 {
 	const int xs_len = TRX_PAD + L + TRX_PAD;
-	const size_t slice_c32 = ((xs_len + 1) & ~1) + TRX_DEC_LEN + TRX_CORR_MAX;
-	return TRX_SINCV_LEN * sizeof(float) + (size_t)waves_per_block * slice_c32 * sizeof(c32);
+	const size_t slice_c32 = ((xs_len + 1) & ~1) + TRX_DEC_LEN + TRX_CZ_LEN;
+	return TRX_SINCV_LDS * sizeof(float) + (size_t)waves_per_block * slice_c32 * sizeof(c32);
 }
 
 extern "C" int trx_launch_pull(const void *d_iq, int cf32, const trxhip_burst_params *d_params,
@@ -610,7 +693,12 @@ extern "C" int trx_launch_pull(const void *d_iq, int cf32, const trxhip_burst_pa
 {
 	if (n_bursts == 0)
 		return 0;
-	const int wpb = TRX_WPB;
+	static int wpb_env = -1;
+	if (wpb_env < 0) {
+		const char *e = getenv("TRXHIP_WPB");           // tuning knob: waves (bursts in flight) per workgroup
+		wpb_env = (e && atoi(e) == 8) ? 8 : 4;
+	}
+	const int wpb = wpb_env;
 	const size_t lds = trx_pull_lds_bytes(L, wpb);
 	if (lds > 160 * 1024)
 		return TRXHIP_EINVAL;
@@ -621,9 +709,9 @@ extern "C" int trx_launch_pull(const void *d_iq, int cf32, const trxhip_burst_pa
 	size_t grid = (size_t)n_cu * blocks_per_cu;
 	if (grid > need) grid = need;
 
-#define LAUNCH(SPS_, CF_)                                                                                       \
+#define LAUNCH(SPS_, CF_, NLD_)                                                                                 \
 	do {                                                                                                    \
-		auto k = burst_pull_kernel<SPS_, CF_>;                                                          \
+		auto k = (wpb == 8) ? burst_pull_kernel<SPS_, CF_, NLD_, 8> : burst_pull_kernel<SPS_, CF_, NLD_, 4>; \
 		if (lds > 64 * 1024 &&                                                                           \
 		    hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
 			return TRXHIP_EIO;                                                                      \
@@ -631,8 +719,13 @@ extern "C" int trx_launch_pull(const void *d_iq, int cf32, const trxhip_burst_pa
 				   d_soft, d_tab, (unsigned)n_bursts, L, thresh, full_scale, soft_stride, slice); \
 	} while (0)
 
-	if (sps == 4) { if (cf32) LAUNCH(4, true); else LAUNCH(4, false); }
-	else          { if (cf32) LAUNCH(1, true); else LAUNCH(1, false); }
+	// NLD = dword loads per lane held in registers for the prefetched burst (0 = generic length, no prefetch)
+	if (sps == 4) {
+		if (L <= 640) { if (cf32) LAUNCH(4, true, 10); else LAUNCH(4, false, 10); }
+		else          { if (cf32) LAUNCH(4, true, 0);  else LAUNCH(4, false, 0); }
+	} else {
+		if (cf32) LAUNCH(1, true, 3); else LAUNCH(1, false, 3);
+	}
 #undef LAUNCH
 	return hipGetLastError() == hipSuccess ? 0 : TRXHIP_EIO;
 }
