@@ -53,6 +53,15 @@ def build_lib(force=False, verbose=False):
     return LIB
 
 
+def build_diag(force=False):
+    """Profiling-only variant with the phase-ablation hooks (-DTRX_DIAG); never loaded by the product."""
+    out = os.path.join(LIBDIR, "libtrxhip_diag.so")
+    srcs = [os.path.join(CSRC, s) for s in LIB_SOURCES]
+    if force or _stale(out, srcs + [os.path.join(CSRC, "trx_tables.h")]):
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-DTRX_DIAG"] + COMMON + ["-o", out] + srcs)
+    return out
+
+
 def build_host(force=False):
     """C++ host shim (sigProcLib.h-compatible API over the C ABI) + its test/demo executables."""
     built = []

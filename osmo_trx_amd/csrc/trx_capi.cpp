@@ -156,8 +156,8 @@ static int pull_common(trxhip_ctx *ctx, const void *d_iq, int cf32, const trxhip
 		return TRXHIP_EINVAL;
 	if (sps != 1 && sps != 4)
 		return TRXHIP_EINVAL;                                  /* sigProcLib.cpp:1740-1741 */
-	if (burst_len > TRXHIP_MAX_BURST_LEN || burst_len < 1 || (sps == 4 && burst_len < 624) ||
-	    (sps == 1 && burst_len > 190))
+	if (burst_len > TRXHIP_MAX_BURST_LEN || (sps == 4 && burst_len < 624) ||
+	    (sps == 1 && (burst_len < 148 || burst_len > 192)))
 		return TRXHIP_EINVAL;
 	if (d_soft && soft_stride < 1)
 		return TRXHIP_EINVAL;

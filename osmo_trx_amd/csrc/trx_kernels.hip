@@ -1,30 +1,34 @@
 // trx_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels for osmo-trx's receive-side burst DSP.
 //
-// Hot kernel: burst_pull_kernel<SPS> = the DSP core of Transceiver::pullRadioVector()
+// Hot kernel: burst_pull_kernel = the DSP core of Transceiver::pullRadioVector()
 // (Transceiver52M/Transceiver.cpp:724-803): convert_short_float -> energyDetect -> clip check ->
 // detectAnyBurst -> demodAnyBurst -> vectorSlicer, for a batch of independent bursts.
 //
 // Mapping (MI355X-first, not a translation of the SSE code):
-//   * ONE WAVEFRONT (64 lanes) PER BURST, persistent waves grid-striding over the batch; a burst
-//     (625 x int16 IQ = 2500 B) is read from HBM exactly once with coalesced dword loads, converted
-//     to fp32 in flight and kept in that wave's private LDS slice (~7.6 KB) until its soft bits and
-//     32-byte result record are written: zero intermediate HBM traffic.
-//   * waves never synchronise with each other after the one-time staging of the sinc-interpolation
-//     table into LDS; intra-wave ordering relies on wave-lockstep LDS execution (wave_sync()).
-//   * FIR phases are register-blocked (fractional-delay: 10 outputs x 20 taps per lane from 29 LDS
-//     reads); wave-uniform taps/training sequences come in through the scalar cache (SGPR operands),
-//     per-lane gathers (sinc LUT) from a bank-swizzled LDS table.
-//   * peak/TOA: argmax by __shfl_xor butterfly; the reference's 9-step early/late bisection
-//     (19 data-dependent sinc interpolations) is evaluated SPECULATIVELY: the binary decision tree is
-//     expanded across lanes (2 rounds: levels 0-4, then 5-8 + the 16 possible final positions), each
-//     lane doing one sequential 21-tap interpolation, then the path is walked with lane shuffles.
-//   * no MFMA: these are short 1-D real/complex convolutions (<= 40 taps), HBM/VALU/LDS work.
+//   * ONE WAVEFRONT (64 lanes) PER BURST, persistent waves grid-striding over the batch, 12 waves per
+//     workgroup = one workgroup per CU.  A burst (625 x int16 IQ = 2500 B) is read from HBM exactly once
+//     with coalesced dword loads that are software-prefetched one burst ahead, converted to fp32 in
+//     flight and kept in that wave's private LDS slice (~8 KB) until its soft bits and 32-byte result
+//     record are written: zero intermediate HBM traffic (measured: 1.02 x algorithmic bytes).
+//   * every table the path touches (sinc LUT, 64 fractional-delay filters, decimator taps, training
+//     sequences, reverse rotation) is staged ONCE per workgroup into LDS (26 KB); wave-uniform taps are
+//     LDS broadcast reads, per-lane gathers (sinc LUT) use a bank-swizzled layout.
+//   * waves never synchronise with each other after that staging; intra-wave ordering relies on
+//     wave-lockstep LDS execution (wave_sync()).
+//   * the kernel is VALU-issue bound (not HBM bound: ~26 FLOP/B), so the code is organised to spend
+//     vector instructions on the FIR arithmetic only: reductions are DPP (v_max/v_add with row/bcast
+//     controls), arg-max and the TOA bisection walk are v_cmp ballots consumed by the scalar unit,
+//     range checks are replaced by zero-padded LDS buffers.
+//   * peak/TOA: the reference's 9-step early/late bisection (19 data-dependent sinc interpolations) is
+//     evaluated SPECULATIVELY: the binary decision tree is expanded across lanes (2 rounds: levels 0-4,
+//     then 5-8 + the 16 possible final positions), each lane doing one sequential 16-tap interpolation.
+//   * no MFMA: these are short 1-D real/complex convolutions (<= 40 taps).
 //
 // Numerics: every sum that feeds a DECISION (correlation, peak ratio, bisection compares, filter
 // choice) is accumulated in the reference's generic-C order (arch/common/convolve_base.c:28-54) and
 // the file is compiled with -ffp-contract=off, so rc / TOA / amp / soft bits are bit-identical to the
-// generic-C reference.  Only energyDetect (tree-summed, <=1e-6 rel), log2f (C/I) and log10 (RSSI)
-// differ at the last-ulp level.
+// generic-C reference.  Only energyDetect (tree-summed), log2f (C/I) and log10f (RSSI) differ at the
+// 1e-6 level.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -34,18 +38,35 @@
 
 #define WAVE 64
 #define TRX_PAD 20                 // zero samples kept on both sides of a burst in LDS
-#define TRX_DEC_LEN 160            // decimated burst (156 used)
+#define TRX_DEC_LEN 208            // decimated burst: 156 samples + zero tail up to start+len (<= 199)
 #define TRX_CORR_MAX 128           // head + tail <= 16 + TRXHIP_MAX_TOA
 #define TRX_CZ_PAD 12              // zero samples either side of the correlation (interpolatePoint reach)
 #define TRX_CZ_LEN (TRX_CZ_PAD + TRX_CORR_MAX + TRX_CZ_PAD)
 #define TRX_SINCV_LDS (TRX_SINCV_LEN + 32)   // + zero tail: q = 4096 is addressed when the fraction is 0
 #define TRX_CLIP_THRESH 30000.0f   // sigProcLib.cpp:49
-#define TRX_WPB 8                  // waves (= bursts in flight) per workgroup
+#define TRX_WPB 12                 // waves (= bursts in flight) per workgroup; one workgroup per CU
+
+// LDS-resident sequence table: [8 TSC x 16][3 RACH x 40][8 EDGE x 16] taps, then 19 headers of 8 floats
+#define LSEQ_TSC(s)   ((s) * 16)
+#define LSEQ_RACH(i)  (128 + (i) * 40)
+#define LSEQ_EDGE(s)  (248 + (s) * 16)
+#define LSEQ_TAPS     376
+#define LSEQ_NHDR     19
+#define TRX_TABLES_LDS_FLOATS (TRX_SINCV_LDS + TRX_DELAY_FILTS * TRX_DELAY_HLEN + 2 * 160 + 16 + 2 * LSEQ_TAPS + 8 * LSEQ_NHDR)
+#define TRX_TABLES_LDS_BYTES (TRX_TABLES_LDS_FLOATS * 4)
 
 typedef float2 c32;
 
+// Diagnostic build only (-DTRX_DIAG, libtrxhip_diag.so): the upper bits of `slice` carry a phase-ablation
+// mask so that per-phase cost can be measured on the GPU.  The product library is built without it.
+#ifdef TRX_DIAG
+#define ABL(bit) ((slice >> (8 + (bit))) & 1)
+#else
+#define ABL(bit) 0
+#endif
+
 // ------------------------------------------------------------------------------------------------
-// small helpers
+// wave-level helpers
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void wave_sync()
 {
@@ -57,45 +78,58 @@ __device__ __forceinline__ void wave_sync()
 }
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-// value held by lane `l` (l wave-uniform): v_readlane_b32, no LDS round trip
+__device__ __forceinline__ float unif(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+// value held by lane `l` (l wave-uniform): v_readlane_b32
 __device__ __forceinline__ float lane_val(float v, int l)
 {
 	return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), __builtin_amdgcn_readfirstlane(l)));
 }
-__device__ __forceinline__ float unif(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
+// DPP move: lanes without a valid source keep their own value
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp(float v)
+{
+	return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+#define DPP_QUAD_XOR1   0xB1   // quad_perm:[1,0,3,2]
+#define DPP_QUAD_XOR2   0x4E   // quad_perm:[2,3,0,1]
+#define DPP_HALF_MIRROR 0x141
+#define DPP_ROW_MIRROR  0x140
+#define DPP_BCAST15     0x142
+#define DPP_BCAST31     0x143
+
+// wave-wide max / sum in 6 DPP-fed VALU ops; result taken from lane 63
+__device__ __forceinline__ float wave_max(float v)
+{
+	v = fmaxf(v, dpp<DPP_QUAD_XOR1, 0xf>(v));
+	v = fmaxf(v, dpp<DPP_QUAD_XOR2, 0xf>(v));
+	v = fmaxf(v, dpp<DPP_HALF_MIRROR, 0xf>(v));
+	v = fmaxf(v, dpp<DPP_ROW_MIRROR, 0xf>(v));
+	v = fmaxf(v, dpp<DPP_BCAST15, 0xa>(v));
+	v = fmaxf(v, dpp<DPP_BCAST31, 0xc>(v));
+	return lane_val(v, 63);
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+	v += dpp<DPP_QUAD_XOR1, 0xf>(v);
+	v += dpp<DPP_QUAD_XOR2, 0xf>(v);
+	v += dpp<DPP_HALF_MIRROR, 0xf>(v);
+	v += dpp<DPP_ROW_MIRROR, 0xf>(v);
+	{
+		// rows 1,3 += row 0,2 totals; rows 2,3 += (rows 0+1) total.  Masked-out rows must add 0.
+		const float t = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_BCAST15, 0xa, 0xf, false));
+		v += t;
+		const float u = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_BCAST31, 0xc, 0xf, false));
+		v += u;
+	}
+	return lane_val(v, 63);
+}
 
 // Complex.h:113 norm2(): i*i + r*r
 __device__ __forceinline__ float norm2(c32 v) { return v.y * v.y + v.x * v.x; }
 // Complex.h:74 operator*(Complex)
 __device__ __forceinline__ c32 cmul(c32 a, c32 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-
-__device__ __forceinline__ float wave_max(float v)
-{
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1)
-		v = fmaxf(v, __shfl_xor(v, o, WAVE));
-	return v;
-}
-
-__device__ __forceinline__ float wave_sum(float v)
-{
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1)
-		v += __shfl_xor(v, o, WAVE);
-	return v;
-}
-
-// per-wave LDS carve
-struct WaveLds {
-	c32 *xs;      // [TRX_PAD + L + TRX_PAD]   burst, later overwritten in place by the delayed+scaled burst
-	c32 *dec;     // [TRX_DEC_LEN]             1-SPS burst (decimated) ; zero beyond 156
-	c32 *corr;    // [TRX_CZ_LEN]  zero-padded correlation
-};
-
-struct SeqWin {   // one detectGeneralBurst() call: sequence + window (sigProcLib.cpp:1732-1771)
-	int seq;      // index into tables->seq
-	int target, head, tail;
-};
 
 // ------------------------------------------------------------------------------------------------
 // interpolatePoint() for one candidate position per lane (sigProcLib.cpp:1100-1118)
@@ -146,6 +180,29 @@ __device__ __forceinline__ int node_offset(int n, int inc0)
 	return ((4 * p * inc0) >> L) - (2 * inc0 - ((2 * inc0) >> L));
 }
 
+// One round of the speculative bisection: lanes 2n / 2n+1 hold |interp(early)|^2 / |interp(late)|^2 of
+// heap node n.  Each even lane compares with its odd neighbour (one DPP move); the two v_cmp results are
+// ballots the scalar unit walks: no further vector work.  Returns the accumulated step; sets `tie` at
+// ":1170 else break".
+template <int LEVELS>
+__device__ __forceinline__ int walk_tree(float nv, int inc0, bool &tie)
+{
+	const float other = dpp<DPP_QUAD_XOR1, 0xf>(nv);               // even lane <- late, odd lane <- early
+	const unsigned long long lt = __ballot(nv < other);            // even bits: early < late
+	const unsigned long long gt = __ballot(nv > other);            // even bits: early > late
+	int node = 0, off = 0;
+#pragma unroll
+	for (int Lw = 0; Lw < LEVELS; Lw++) {
+		if (!tie) {
+			const int bit = 2 * node;
+			if ((lt >> bit) & 1ull)      { off += (inc0 >> Lw); node = 2 * node + 2; }
+			else if ((gt >> bit) & 1ull) { off -= (inc0 >> Lw); node = 2 * node + 1; }
+			else tie = true;
+		}
+	}
+	return off;
+}
+
 // ------------------------------------------------------------------------------------------------
 // peakDetect() (sigProcLib.cpp:1141-1186) with the early/late bisection expanded across lanes.
 // All lanes return the same (toa512, value).
@@ -159,20 +216,8 @@ __device__ __forceinline__ void peak_detect_spec(const c32 *cz, int max_idx, con
 	// ---- round A: levels 0..4 (incr = 1/2 .. 1/32): heap node n on lanes 2n (early) and 2n+1 (late)
 	{
 		const int ix = E + node_offset(lane >> 1, 256) + ((lane & 1) ? 1024 : 0);
-		float nv = 0.0f;
-		if (lane < 62)
-			nv = norm2(interp_point(cz, ix, sincv));
-		int node = 0;
-#pragma unroll
-		for (int Lw = 0; Lw < 5; Lw++) {
-			const float ne = lane_val(nv, 2 * node);
-			const float nl = lane_val(nv, 2 * node + 1);
-			if (!tie) {
-				if (ne < nl)      { E += (256 >> Lw); node = 2 * node + 2; }
-				else if (ne > nl) { E -= (256 >> Lw); node = 2 * node + 1; }
-				else tie = true;                      // "else break", :1170
-			}
-		}
+		const float nv = norm2(interp_point(cz, ix, sincv));     // lanes 62,63 evaluate a harmless extra node
+		E += walk_tree<5>(nv, 256, tie);
 	}
 	int final_ix;
 	c32 val;
@@ -184,21 +229,9 @@ __device__ __forceinline__ void peak_detect_spec(const c32 *cz, int max_idx, con
 			ix = E + node_offset(lane >> 1, 8) + ((lane & 1) ? 1024 : 0);
 		else
 			ix = E + (2 * (lane & 15) - 15) + 512;
-		c32 pv = make_float2(0.0f, 0.0f);
-		if (lane < 30 || (lane >= 32 && lane < 48))
-			pv = interp_point(cz, ix, sincv);
+		const c32 pv = interp_point(cz, ix, sincv);
 		const float nv = norm2(pv);
-		int node = 0, offB = 0;
-#pragma unroll
-		for (int Lw = 0; Lw < 4; Lw++) {
-			const float ne = lane_val(nv, 2 * node);
-			const float nl = lane_val(nv, 2 * node + 1);
-			if (!tie) {
-				if (ne < nl)      { offB += (8 >> Lw); node = 2 * node + 2; }
-				else if (ne > nl) { offB -= (8 >> Lw); node = 2 * node + 1; }
-				else tie = true;
-			}
-		}
+		const int offB = walk_tree<4>(nv, 8, tie);
 		E += offB;
 		final_ix = E + 512;
 		const int src = 32 + ((offB + 15) >> 1);     // lane that evaluated this final position
@@ -214,17 +247,20 @@ __device__ __forceinline__ void peak_detect_spec(const c32 *cz, int max_idx, con
 }
 
 // ------------------------------------------------------------------------------------------------
-// detectBurst() on the 1-SPS signal `sig[0..sig_len)` (sigProcLib.cpp:1649-1709), corr in LDS.
+// detectBurst() on the 1-SPS signal `sig` (sigProcLib.cpp:1649-1709); correlation kept in LDS (cz).
+//   PADDED: sig is readable (zero) over the whole correlation window, no range checks (4 SPS: dec[])
+//   taps  : LDS, wave-uniform -> broadcast reads; hdr: {gain.re, gain.im, ginv.re, ginv.im, ci_den, toa}
 // Returns rc (1 / 0); on 1 fills toa (symbols, before "- head"), amp, ci.  Wave-uniform.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int detect_burst(const c32 *sig, int sig_len, c32 *cz, const trx_seq *__restrict__ sq,
-					     float thresh, int start, int len, const float *sincv, int lane,
-					     float *toa_out, c32 *amp_out, float *ci_out)
+template <bool PADDED>
+__device__ __forceinline__ int detect_burst(const c32 *sig, int sig_len, c32 *cz, const c32 *taps, const float *hdr,
+					     int N, float thresh, int start, int len, const float *sincv, int lane,
+					     float *toa_out, c32 *amp_out, float *ci_out, int slice)
 {
-	const int N = sq->n;
-
 	// ---- correlate: corr[i] = sum_k SIG(i + start - (N-1) + k) * seq[k]   (:1674, convolve_base.c:72-85)
-	// N is 16 (TSC/EDGE/dummy), 40 (RACH) or 64 (SCH): tap loop unrolled by 8 so the LDS reads pipeline
+	// N is 16 (TSC/EDGE) or 40 (RACH): tap loop unrolled by 8 so the LDS reads pipeline
+	float best = 0.0f;                               // fastPeakDetect state, fused into the same pass
+	int bidx = -1;
 	for (int i = lane; i < len; i += WAVE) {
 		float yr = 0.0f, yi = 0.0f;
 		const int base = i + start - (N - 1);
@@ -233,51 +269,49 @@ __device__ __forceinline__ int detect_burst(const c32 *sig, int sig_len, c32 *cz
 #pragma unroll
 			for (int u = 0; u < 8; u++) {
 				const int j = base + k0 + u;
-				x[u] = (j >= 0 && j < sig_len) ? sig[j] : make_float2(0.0f, 0.0f);
+				if (PADDED) x[u] = sig[j];
+				else x[u] = (j >= 0 && j < sig_len) ? sig[j] : make_float2(0.0f, 0.0f);
 			}
 #pragma unroll
 			for (int u = 0; u < 8; u++) {
-				const float hr = sq->taps[k0 + u].re, hi = sq->taps[k0 + u].im;   // wave-uniform -> scalar loads
-				yr += x[u].x * hr - x[u].y * hi;
-				yi += x[u].x * hi + x[u].y * hr;
+				const c32 h = taps[k0 + u];
+				yr += x[u].x * h.x - x[u].y * h.y;
+				yi += x[u].x * h.y + x[u].y * h.x;
 			}
 		}
-		cz[i] = make_float2(yr, yi);
-	}
-	if (lane < TRX_CZ_PAD)
-		cz[len + lane] = make_float2(0.0f, 0.0f);          // right zero pad (len varies per burst)
-	wave_sync();
-
-	// ---- fastPeakDetect (:1120-1139): first strict maximum of |corr|^2
-	float best = 0.0f;
-	int bidx = -1;
-	for (int i = lane; i < len; i += WAVE) {
-		const float v = norm2(cz[i]);
+		const c32 y = make_float2(yr, yi);
+		cz[i] = y;
+		// fastPeakDetect (:1120-1139): first strict maximum of |corr|^2 (per lane: i ascending)
+		const float v = norm2(y);
 		if (v > best) { best = v; bidx = i; }
 	}
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1) {
-		const float ov = __shfl_xor(best, o, WAVE);
-		const int oi = __shfl_xor(bidx, o, WAVE);
-		if (ov > best || (ov == best && oi >= 0 && (bidx < 0 || oi < bidx))) { best = ov; bidx = oi; }
-	}
-	bidx = uni(bidx);
-	if (bidx < 0)
+	if (lane < TRX_CZ_PAD)
+		cz[len + lane] = make_float2(0.0f, 0.0f);    // right zero pad (len varies per burst)
+
+	// arg-max across lanes: wave max (DPP), then the lowest index holding it (ballot + scalar ff1)
+	const float m = wave_max(best);
+	if (!(m > 0.0f))
 		return 0;                                    // toa = -1 < 3
-	const float toa0 = (float)bidx;
-	if ((toa0 < 3.0f) || (toa0 > (float)(len - 3)))   // :1683
+	{
+		const unsigned long long hit = __ballot(best == m);
+		const unsigned long long hit_lo = __ballot(best == m && bidx == lane);
+		bidx = hit_lo ? (__ffsll((unsigned long long)hit_lo) - 1) : (64 + __ffsll((unsigned long long)hit) - 1);
+	}
+	if ((bidx < 3) || (bidx > len - 3))               // :1683
 		return 0;
+	wave_sync();
 	const c32 amp0 = cz[bidx];
 
-	// ---- computePeakRatio (:1541-1571), sequential sum (it gates a decision)
+	// ---- computePeakRatio (:1541-1571): terms in the reference's order; out-of-range terms read the
+	// zero pads (adding +0 is exact), their count is arithmetic
 	{
-		int num = 0;
 		float avg = 0.0f;
-		const int peak = bidx;                       // rint(toa) of an integer
+		int num = 0;
 #pragma unroll
 		for (int i = 2; i <= 5; i++) {
-			if (peak - i >= 0)  { avg += norm2(cz[peak - i]); num++; }
-			if (peak + i < len) { avg += norm2(cz[peak + i]); num++; }
+			avg += norm2(cz[bidx - i]);
+			avg += norm2(cz[bidx + i]);              // bidx + i >= len reads zeros (pad = 12 > 5)
+			num += (bidx - i >= 0) + (bidx + i < len);
 		}
 		if (num < 5)
 			return 0;
@@ -291,11 +325,12 @@ __device__ __forceinline__ int detect_burst(const c32 *sig, int sig_len, c32 *cz
 	int toa512;
 	c32 xcorr;
 	// interpolatePoint() never reads the last correlation sample (:1105, :1109): zero it in the padded copy
-	wave_sync();
 	if (lane == 0)
 		cz[len - 1] = make_float2(0.0f, 0.0f);
 	wave_sync();
-	peak_detect_spec(cz, bidx, sincv, lane, &toa512, &xcorr);
+	if (ABL(1)) { toa512 = bidx * 512; xcorr = amp0; }
+	else
+		peak_detect_spec(cz, bidx, sincv, lane, &toa512, &xcorr);
 	toa512 = uni(toa512);
 	xcorr.x = unif(xcorr.x);
 	xcorr.y = unif(xcorr.y);
@@ -314,13 +349,13 @@ __device__ __forceinline__ int detect_burst(const c32 *sig, int sig_len, c32 *cz
 			for (int i = 0; i < N; i++)
 				S += lane_val(pw, i);
 			S /= (float)N;
-			const float C = norm2(xcorr) / sq->ci_den;
+			const float C = norm2(xcorr) / hdr[4];
 			ci = 3.0103f * log2f(C / (S - C));
 		}
 	}
 
-	*amp_out = cmul(xcorr, make_float2(sq->gain_inv.re, sq->gain_inv.im));   // xcorr / sync->gain  (:1701)
-	*toa_out = toa - sq->toa;                                              // :1704
+	*amp_out = cmul(xcorr, make_float2(hdr[2], hdr[3]));   // xcorr / sync->gain  (:1701)
+	*toa_out = toa - hdr[5];                                 // :1704
 	*ci_out = ci;
 	return 1;
 }
@@ -328,8 +363,8 @@ __device__ __forceinline__ int detect_burst(const c32 *sig, int sig_len, c32 *cz
 // ------------------------------------------------------------------------------------------------
 // the hot kernel
 // ------------------------------------------------------------------------------------------------
-template <int SPS, bool CF32, int NLD, int WPB>
-__global__ void __launch_bounds__(WPB * WAVE, (WPB == 8) ? 4 : 3)
+template <int SPS, bool CF32, int NLD>
+__global__ void __launch_bounds__(TRX_WPB * WAVE, 3)
 burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__restrict__ params,
 		  trxhip_burst_result *__restrict__ results, float *__restrict__ soft,
 		  const trx_tables *__restrict__ tab,
@@ -340,19 +375,43 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 	const int wave = threadIdx.x >> 6;
 	const int waves_per_block = blockDim.x >> 6;
 
-	// ---- LDS carve: [sincv 16 KB | per-wave slices]
-	float *sincv = reinterpret_cast<float *>(smem);
+	// ---- LDS carve: [tables][per-wave slices]
+	float *sincv = reinterpret_cast<float *>(smem);                 // [4128] swizzled sinc LUT
+	float *dfilt = sincv + TRX_SINCV_LDS;                          // [64][20] fractional-delay filters
+	c32 *rrot = reinterpret_cast<c32 *>(dfilt + TRX_DELAY_FILTS * TRX_DELAY_HLEN);   // [160] reverse rotation
+	float *gdec = reinterpret_cast<float *>(rrot + 160);           // [16] decimator taps
+	c32 *lseq = reinterpret_cast<c32 *>(gdec + 16);                // [376] training sequences
+	float *lhdr = reinterpret_cast<float *>(lseq + LSEQ_TAPS);     // [19][8] sequence headers
 	const int xs_len = TRX_PAD + L + TRX_PAD;
-	const int slice_c32 = ((xs_len + 1) & ~1) + TRX_DEC_LEN + TRX_CZ_LEN;
-	c32 *wbase = reinterpret_cast<c32 *>(smem + TRX_SINCV_LDS * sizeof(float)) + (size_t)wave * slice_c32;
-	WaveLds w;
-	w.xs = wbase;
-	w.dec = wbase + ((xs_len + 1) & ~1);
-	w.corr = w.dec + TRX_DEC_LEN;
+	const int xs_alloc = (xs_len + 1) & ~1;
+	const int slice_c32 = xs_alloc + TRX_DEC_LEN + TRX_CZ_LEN;
+	c32 *wbase = reinterpret_cast<c32 *>(smem + TRX_TABLES_LDS_BYTES) + (size_t)wave * slice_c32;
+	c32 *const xs = wbase + TRX_PAD;                               // burst sample 0
+	c32 *const dec = wbase + xs_alloc;                             // 1-SPS (decimated) burst, zero tail
+	c32 *const cz = dec + TRX_DEC_LEN + TRX_CZ_PAD;                // zero-padded correlation
 
-	// one-time staging (block-wide): sinc LUT; zero this wave's pads
+	// ---- one-time staging (workgroup-wide) of every table; zero this wave's slice (pads stay zero)
 	for (int i = threadIdx.x; i < TRX_SINCV_LDS; i += blockDim.x)
 		sincv[i] = (i < TRX_SINCV_LEN) ? tab->sincv[i] : 0.0f;
+	for (int i = threadIdx.x; i < TRX_DELAY_FILTS * TRX_DELAY_HLEN; i += blockDim.x)
+		dfilt[i] = (&tab->delay_filt[0][0])[i];
+	for (int i = threadIdx.x; i < 160; i += blockDim.x)
+		rrot[i] = make_float2(tab->rrot1[i].re, tab->rrot1[i].im);
+	if (threadIdx.x < 16)
+		gdec[threadIdx.x] = tab->dec_taps[threadIdx.x];
+	for (int i = threadIdx.x; i < LSEQ_TAPS; i += blockDim.x) {
+		int s, k;
+		if (i < 128)      { s = TRX_SEQ_TSC0 + i / 16;          k = i % 16; }
+		else if (i < 248) { s = TRX_SEQ_RACH0 + (i - 128) / 40; k = (i - 128) % 40; }
+		else              { s = TRX_SEQ_EDGE0 + (i - 248) / 16; k = (i - 248) % 16; }
+		lseq[i] = make_float2(tab->seq[s].taps[k].re, tab->seq[s].taps[k].im);
+	}
+	for (int i = threadIdx.x; i < 8 * LSEQ_NHDR; i += blockDim.x) {
+		// header of LDS sequence slot: slots 0-7 TSC, 8-10 RACH, 11-18 EDGE
+		const int slot = i / 8;
+		const int s = (slot < 8) ? TRX_SEQ_TSC0 + slot : (slot < 11) ? TRX_SEQ_RACH0 + (slot - 8) : TRX_SEQ_EDGE0 + (slot - 11);
+		lhdr[i] = reinterpret_cast<const float *>(&tab->seq[s].gain)[i % 8];
+	}
 	for (int i = lane; i < slice_c32; i += WAVE)
 		wbase[i] = make_float2(0.0f, 0.0f);
 	__syncthreads();
@@ -360,42 +419,38 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 	const unsigned total_waves = gridDim.x * waves_per_block;
 	const unsigned first = blockIdx.x * waves_per_block + wave;
 
-	// Software prefetch: the raw samples of this wave's NEXT burst sit in registers (NLD dwords per lane,
-	// coalesced 256 B per wave-load) while the current burst is being processed, so the ~1-2 us HBM
-	// latency is hidden behind compute instead of being paid serially per burst.  NLD == 0: generic
-	// burst lengths, plain loop.
+	// Software prefetch: the raw samples and the parameter word of this wave's NEXT burst sit in
+	// registers (NLD dwords per lane, coalesced 256 B per wave-load) while the current burst is
+	// processed, so the HBM latency is hidden behind compute.  NLD == 0: generic burst lengths, plain loop.
 	uint32_t pre_i[NLD > 0 ? NLD : 1];
 	c32 pre_c[(NLD > 0 && CF32) ? NLD : 1];
+	uint32_t pre_prm = 0u;                                         // {type u8, tsc u8, max_toa u16}
 	auto prefetch = [&](unsigned bb) {
+		pre_prm = reinterpret_cast<const uint32_t *>(params)[2 * (size_t)bb];
 		if (CF32) {
 			const c32 *src = reinterpret_cast<const c32 *>(iq_) + (size_t)bb * L;
 #pragma unroll
 			for (int r = 0; r < NLD; r++) {
 				const int i = r * WAVE + lane;
-				pre_c[r] = (i < L) ? src[i] : make_float2(0.0f, 0.0f);
+				pre_c[r] = (r < NLD - 1 || i < L) ? src[i] : make_float2(0.0f, 0.0f);
 			}
 		} else {
 			const uint32_t *src = reinterpret_cast<const uint32_t *>(iq_) + (size_t)bb * L;
 #pragma unroll
 			for (int r = 0; r < NLD; r++) {
 				const int i = r * WAVE + lane;
-				pre_i[r] = (i < L) ? src[i] : 0u;
+				pre_i[r] = (r < NLD - 1 || i < L) ? src[i] : 0u;   // host guarantees L > 64*(NLD-1)
 			}
 		}
 	};
-	if (NLD > 0 && first < n_bursts)
+	if (first < n_bursts)
 		prefetch(first);
 
-	const int lane_outer = lane;
 	for (unsigned b = first; b < n_bursts; b += total_waves) {
-		// Re-materialise the lane id per burst: keeps the compiler from hoisting every lane-derived
-		// address/predicate of every phase out of this loop (which cost ~70 spilled VGPRs).
-		int lane_opaque = lane_outer;
-		const int lane = lane_opaque;
-		const trxhip_burst_params prm = params[b];
-		const int type = uni(prm.type);
-		const int tsc = uni(prm.tsc);
-		int max_toa = uni(prm.max_toa);
+		const unsigned prm0 = (unsigned)uni((int)pre_prm);
+		const int type = prm0 & 0xff;
+		const int tsc = (prm0 >> 8) & 0xff;
+		const int max_toa = prm0 >> 16;
 
 		int rc = 0;
 		float toa = 0.0f, ci = 0.0f, energy = 0.0f, rssi = 0.0f;
@@ -403,57 +458,56 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 		int out_tsc = 0, clip = 0, idle = 1, nbits = 0;
 		float *so = soft ? soft + (size_t)b * soft_stride : nullptr;
 
-		// ---- phase 0: HBM -> fp32 LDS (convert_short_float fused into the load), clip scan
-		float amax = 0.0f;
+		// ---- phase 0: registers -> fp32 LDS (convert_short_float, arch/common/convert_base.c:27-31, fused
+		// into the load); clip scan (maxAmplitude) and energyDetect partial sums ride on the same values
+		float amax = 0.0f, epart = 0.0f;
+		int win = 20 * SPS;                                         // energyDetect window (:725), stride 4 (:1582)
+		if (win > L) win = L;
 		if (NLD > 0) {
 #pragma unroll
 			for (int r = 0; r < NLD; r++) {
 				const int i = r * WAVE + lane;
-				if (i < L) {
+				if (r < NLD - 1 || i < L) {
 					c32 v;
 					if (CF32) v = pre_c[r];
 					else v = make_float2((float)(int16_t)(pre_i[r] & 0xffffu), (float)(int16_t)(pre_i[r] >> 16));
-					w.xs[TRX_PAD + i] = v;
+					xs[i] = v;
 					amax = fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y)));
+					if (r * WAVE < 4 * 20 * SPS)                    // compile-time: rounds that can hold samples 4i, i < win
+						if ((lane & 3) == 0 && i < 4 * win)
+							epart += norm2(v);
 				}
 			}
 			if (b + total_waves < n_bursts)
 				prefetch(b + total_waves);
-		} else if (CF32) {
-			const c32 *src = reinterpret_cast<const c32 *>(iq_) + (size_t)b * L;
-			for (int i = lane; i < L; i += WAVE) {
-				const c32 v = src[i];
-				w.xs[TRX_PAD + i] = v;
-				amax = fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y)));
-			}
 		} else {
-			const uint32_t *src = reinterpret_cast<const uint32_t *>(iq_) + (size_t)b * L;
+			if (b + total_waves < n_bursts)
+				pre_prm = reinterpret_cast<const uint32_t *>(params)[2 * (size_t)(b + total_waves)];
 			for (int i = lane; i < L; i += WAVE) {
-				const uint32_t u = src[i];
-				const c32 v = make_float2((float)(int16_t)(u & 0xffffu), (float)(int16_t)(u >> 16));
-				w.xs[TRX_PAD + i] = v;
+				c32 v;
+				if (CF32) {
+					v = (reinterpret_cast<const c32 *>(iq_) + (size_t)b * L)[i];
+				} else {
+					const uint32_t u = (reinterpret_cast<const uint32_t *>(iq_) + (size_t)b * L)[i];
+					v = make_float2((float)(int16_t)(u & 0xffffu), (float)(int16_t)(u >> 16));
+				}
+				xs[i] = v;
 				amax = fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y)));
+				if ((i & 3) == 0 && i < 4 * win)
+					epart += norm2(v);
 			}
 		}
 
 		if (type != TRXHIP_OFF) {                                   // Transceiver.cpp:704-707
 			amax = wave_max(amax);                                  // maxAmplitude(), :1711-1722
 			clip = amax > TRX_CLIP_THRESH;
+			// energyDetect(burst, 20*sps) (:1573-1585), tree-summed; RSSI (Transceiver.cpp:741,751) in fp32
+			energy = wave_sum(epart) / (float)win;
+			if (!ABL(2))
+				rssi = 6.02059991f * __log2f(full_scale / sqrtf(energy));  // 20*log10(x) = 20*log10(2)*log2(x), v_log_f32
 			wave_sync();
 
-			// ---- energyDetect(burst, 20*sps) (:1573-1585): stride 4 regardless of sps; tree-summed
-			{
-				int win = 20 * SPS;
-				if (win > L) win = L;
-				float e = 0.0f;
-				for (int i = lane; i < win; i += WAVE)
-					e += norm2(w.xs[TRX_PAD + 4 * i]);
-				energy = wave_sum(e) / (float)win;
-				const float avg = sqrtf(energy);                    // Transceiver.cpp:741 (one path)
-				rssi = (float)(20.0 * log10((double)full_scale / (double)avg));   // :751
-			}
-
-			if (type != TRXHIP_IDLE) {                              // Transceiver.cpp:754-755
+			if (type != TRXHIP_IDLE && !ABL(3)) {                   // Transceiver.cpp:754-755
 				// ---- detectAnyBurst (:1926-1957): up to 3 candidate windows, first hit wins
 				int ncand = 0;
 				rc = 0;
@@ -466,31 +520,25 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 					ncand = (type == TRXHIP_EXT_RACH) ? 3 : 1;                 // :1791
 				}
 
-				const c32 *sig;
-				int sig_len;
-				if (SPS == 4) {
-					sig = w.dec;
-					sig_len = 156;
-				} else {
-					sig = w.xs + TRX_PAD;
-					sig_len = L;
-				}
-
 				int dec_lo = 1 << 30, dec_hi = 0;                 // decimated range already computed
 				int det_type = 0;
 				for (int c = 0; c < ncand; c++) {
-					SeqWin cw;
-					if (type == TRXHIP_RACH || type == TRXHIP_EXT_RACH)
-						cw = { TRX_SEQ_RACH0 + c, 48, 8, 8 + max_toa };            // :1788-1790
-					else if (type == TRXHIP_EDGE && c == 0)
-						cw = { TRX_SEQ_EDGE0 + tsc, 82, 6, 6 + max_toa };           // :1915-1918
-					else
-						cw = { TRX_SEQ_TSC0 + tsc, 82, 10, 6 + max_toa };           // :1896-1899
-					const trx_seq *sq = &tab->seq[cw.seq];
-					const int N = sq->n;
-					const int start = cw.target - cw.head - 1;             // :1752
-					const int len = cw.head + cw.tail;                     // :1753
+					// one detectGeneralBurst() call (:1732-1771): sequence + window
+					int slot, target, head, tail, N;
+					if (type == TRXHIP_RACH || type == TRXHIP_EXT_RACH) {
+						slot = 8 + c; target = 48; head = 8; tail = 8 + max_toa; N = 40;       // :1788-1790
+					} else if (type == TRXHIP_EDGE && c == 0) {
+						slot = 11 + tsc; target = 82; head = 6; tail = 6 + max_toa; N = 16;    // :1915-1918
+					} else {
+						slot = tsc; target = 82; head = 10; tail = 6 + max_toa; N = 16;        // :1896-1899
+					}
+					const c32 *taps = lseq + ((slot < 8) ? LSEQ_TSC(slot) : (slot < 11) ? LSEQ_RACH(slot - 8) : LSEQ_EDGE(slot - 11));
+					const float *hdr = lhdr + 8 * slot;
+					const int start = target - head - 1;                   // :1752
+					const int len = head + tail;                           // :1753
 
+					float t; c32 a; float cc;
+					int hit;
 					if (SPS == 4) {
 						// downsampleBurst (:1587-1601) restricted to what correlate/computeCI read:
 						// dec[i] = sum_k xs[4i-15+k] * g[k], i in [lo, hi)
@@ -498,33 +546,32 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 						int hi = start + len;     if (hi > 156) hi = 156;
 						if (lo < dec_lo || hi > dec_hi) {
 							for (int i = lo + lane; i < hi; i += WAVE) {
-								const c32 *xp = w.xs + TRX_PAD + 4 * i - 15;
+								const c32 *xp = xs + 4 * i - 15;
 								float yr = 0.0f, yi = 0.0f;
 #pragma unroll
 								for (int k = 0; k < 16; k++) {
 									const c32 x = xp[k];
-									const float g = tab->dec_taps[k];
+									const float g = gdec[k];
 									yr += x.x * g;
 									yi += x.y * g;
 								}
-								w.dec[i] = make_float2(yr, yi);
+								dec[i] = make_float2(yr, yi);
 							}
 							dec_lo = lo; dec_hi = hi;
 							wave_sync();
 						}
+						hit = detect_burst<true>(dec, 156, cz, taps, hdr, N, thresh, start, len, sincv, lane, &t, &a, &cc, slice);
+					} else {
+						hit = detect_burst<false>(xs, L, cz, taps, hdr, N, thresh, start, len, sincv, lane, &t, &a, &cc, slice);
 					}
-
-					float t; c32 a; float cc;
-					const int hit = detect_burst(sig, sig_len, w.corr + TRX_CZ_PAD, sq, thresh, start, len, sincv, lane, &t, &a, &cc);
 					wave_sync();
 					if (hit) {
 						rc = 1;
-						toa = t - (float)cw.head;                          // :1768
+						toa = t - (float)head;                             // :1768
 						amp = a;
 						ci = cc;
-						const int s = cw.seq;
-						if (s >= TRX_SEQ_RACH0 && s < TRX_SEQ_RACH0 + 3) { out_tsc = s - TRX_SEQ_RACH0; det_type = type; }
-						else if (s >= TRX_SEQ_EDGE0) { out_tsc = tsc; det_type = TRXHIP_EDGE; }
+						if (slot >= 8 && slot < 11) { out_tsc = slot - 8; det_type = type; }
+						else if (slot >= 11) { out_tsc = tsc; det_type = TRXHIP_EDGE; }
 						else { out_tsc = tsc; det_type = TRXHIP_TSC; }
 						break;
 					}
@@ -535,14 +582,14 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 		}
 
 		// ---- demodAnyBurst -> demodGmskBurst (:2055-2072) ----
-		if (rc > 0 && rc != TRXHIP_EDGE) {
+		if (rc > 0 && rc != TRXHIP_EDGE && !ABL(0)) {
 			// demodCommon (:2030-2048): delayVector(burst, -toa*sps), scaleVector(1/amp)
 			const float delay = -toa * (float)SPS;
 			const int whole = (int)floorf(delay);
 			const float frac = delay - (float)whole;
-			const bool use_filt = (double)fabsf(frac) > 1e-2;              // :1056
+			const bool use_filt = ((double)fabsf(frac) > 1e-2) && !ABL(4);  // :1056
 			const int fidx = use_filt ? (int)floorf(frac * (float)TRX_DELAY_FILTS) : 0;   // :1057
-			const float *hf = tab->delay_filt[uni(fidx)];
+			const float4 *hf4 = reinterpret_cast<const float4 *>(dfilt + uni(fidx) * TRX_DELAY_HLEN);
 			// (complex) 1.0 / amp = (1,0) * amp.inv()   (Complex.h:75,144-150)
 			const float an = norm2(amp);
 			const c32 ainv = make_float2(amp.x / an, -amp.y / an);
@@ -557,11 +604,17 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 				int mc = m0;
 				if (mc < -10) mc = -10;
 				if (mc > L) mc = L;
-				const c32 *xp = w.xs + TRX_PAD + mc - 9;
+				const c32 *xp = xs + mc - 9;
 				if (use_filt) {
 					// fshift[m] = sum_k X(m - 9 + k) * h[k]  (convolve NO_DELAY, 20 real taps; :1060)
 					// tap-outer / output-inner: each output still accumulates k = 0..19 in order, but only a
 					// sliding window of R samples (+ R accumulators) is live instead of all R+19 inputs
+					float hh[TRX_DELAY_HLEN];
+#pragma unroll
+					for (int q = 0; q < TRX_DELAY_HLEN / 4; q++) {          // 5 LDS broadcast reads
+						const float4 h4 = hf4[q];
+						hh[4 * q + 0] = h4.x; hh[4 * q + 1] = h4.y; hh[4 * q + 2] = h4.z; hh[4 * q + 3] = h4.w;
+					}
 					constexpr int D = 3;                                    // LDS read-ahead, in taps
 					c32 xr[R + 19];
 #pragma unroll
@@ -572,7 +625,7 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 						xr[j] = xp[j];
 #pragma unroll
 					for (int k = 0; k < 20; k++) {
-						const float h = hf[k];
+						const float h = hh[k];
 						if (R - 1 + D + k < R + 19)
 							xr[R - 1 + D + k] = xp[R - 1 + D + k];
 #pragma unroll
@@ -590,7 +643,7 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 #pragma unroll
 				for (int j = 0; j < R; j++) {
 					const int m = m0 + j;
-					const bool ok = (mc == m0) && (m >= 0) && (m < L);
+					const bool ok = (mc == m0) && ((unsigned)m < (unsigned)L);
 					const c32 v = ok ? yv[j] : make_float2(0.0f, 0.0f);
 					yv[j] = cmul(v, scale);                                 // scaleVector (:1198-1205)
 				}
@@ -601,7 +654,7 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 #pragma unroll
 				for (int j = 0; j < R; j++)
 					if (n0 + j < n_out)
-						w.xs[TRX_PAD + n0 + j] = yv[j];
+						xs[n0 + j] = yv[j];
 			}
 			wave_sync();
 
@@ -610,33 +663,29 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 			nbits = 148;
 			idle = 0;
 			if (so) {
-				const int nwrite = slice ? nbits : nsoft;
+				const int nwrite = (slice & 1) ? nbits : nsoft;
 				for (int i = lane; i < soft_stride; i += WAVE) {
 					float sv = 0.0f;
-					if (i < nwrite) {
+					if (i < nwrite && !ABL(5)) {
 						c32 d;
 						if (SPS == 4) {
-							const c32 *xp = w.xs + TRX_PAD + 4 * i - 15;
+							const c32 *xp = xs + 4 * i - 15;
 							float yr = 0.0f, yi = 0.0f;
 #pragma unroll
 							for (int k = 0; k < 16; k++) {
 								const c32 x = xp[k];
-								const float g = tab->dec_taps[k];
+								const float g = gdec[k];
 								yr += x.x * g;
 								yi += x.y * g;
 							}
 							d = make_float2(yr, yi);
 						} else {
-							d = w.xs[TRX_PAD + i];
+							d = xs[i];
 						}
-						const trx_c32 r = tab->rrot1[i];
-						sv = r.re * d.x - r.im * d.y;                       // real(rot * x)  (:2066-2068)
-						if (slice) {                                        // vectorSlicer (:546-556)
-							float o = 0.5f * (sv + 1.0f);           // exact in fp32, as the double product
-							if (o > 1.0f) o = 1.0f;
-							else if (o < 0.0f) o = 0.0f;
-							sv = o;
-						}
+						const c32 r = rrot[i];
+						sv = r.x * d.x - r.y * d.y;                         // real(rot * x)  (:2066-2068)
+						if (slice & 1)                                      // vectorSlicer (:546-556): clamp(0.5*(s+1), 0, 1)
+							sv = __builtin_amdgcn_fmed3f(0.5f * (sv + 1.0f), 0.0f, 1.0f);
 					}
 					so[i] = sv;
 				}
@@ -657,20 +706,16 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 
 		// ---- result record: 32 bytes, one dword per lane 0..7
 		if (lane < 8) {
-			uint32_t word;
-			switch (lane) {
-			case 0: word = (uint32_t)rc; break;
-			case 1: word = __float_as_uint(rc > 0 ? toa : 0.0f); break;
-			case 2: word = __float_as_uint(rc > 0 ? amp.x : 0.0f); break;
-			case 3: word = __float_as_uint(rc > 0 ? amp.y : 0.0f); break;
-			case 4: word = __float_as_uint(rc > 0 ? ci : 0.0f); break;
-			case 5: word = __float_as_uint(energy); break;
-			case 6: word = __float_as_uint(rssi); break;
-			default:
-				word = (uint32_t)(rc > 0 ? out_tsc : 0) | ((uint32_t)clip << 8) | ((uint32_t)idle << 16) |
-				       ((uint32_t)(nbits / 4) << 24);
-				break;
-			}
+			const bool det = rc > 0;
+			uint32_t word = (uint32_t)rc;
+			word = (lane == 1) ? __float_as_uint(det ? toa : 0.0f) : word;
+			word = (lane == 2) ? __float_as_uint(det ? amp.x : 0.0f) : word;
+			word = (lane == 3) ? __float_as_uint(det ? amp.y : 0.0f) : word;
+			word = (lane == 4) ? __float_as_uint(det ? ci : 0.0f) : word;
+			word = (lane == 5) ? __float_as_uint(energy) : word;
+			word = (lane == 6) ? __float_as_uint(rssi) : word;
+			word = (lane == 7) ? ((uint32_t)(det ? out_tsc : 0) | ((uint32_t)clip << 8) | ((uint32_t)idle << 16) |
+					      ((uint32_t)(nbits / 4) << 24)) : word;
 			reinterpret_cast<uint32_t *>(results + b)[lane] = word;
 		}
 	}
@@ -683,7 +728,7 @@ extern "C" size_t trx_pull_lds_bytes(int L, int waves_per_block)
 {
 	const int xs_len = TRX_PAD + L + TRX_PAD;
 	const size_t slice_c32 = ((xs_len + 1) & ~1) + TRX_DEC_LEN + TRX_CZ_LEN;
-	return TRX_SINCV_LDS * sizeof(float) + (size_t)waves_per_block * slice_c32 * sizeof(c32);
+	return TRX_TABLES_LDS_BYTES + (size_t)waves_per_block * slice_c32 * sizeof(c32);
 }
 
 extern "C" int trx_launch_pull(const void *d_iq, int cf32, const trxhip_burst_params *d_params,
@@ -693,25 +738,20 @@ extern "C" int trx_launch_pull(const void *d_iq, int cf32, const trxhip_burst_pa
 {
 	if (n_bursts == 0)
 		return 0;
-	static int wpb_env = -1;
-	if (wpb_env < 0) {
-		const char *e = getenv("TRXHIP_WPB");           // tuning knob: waves (bursts in flight) per workgroup
-		wpb_env = (e && atoi(e) == 8) ? 8 : 4;
-	}
-	const int wpb = wpb_env;
+	// as many waves per workgroup as the 160 KB of LDS admit (12 at L = 625), one workgroup per CU
+	int wpb = TRX_WPB;
+	while (wpb > 1 && trx_pull_lds_bytes(L, wpb) > 160 * 1024)
+		wpb--;
 	const size_t lds = trx_pull_lds_bytes(L, wpb);
 	if (lds > 160 * 1024)
 		return TRXHIP_EINVAL;
-	int blocks_per_cu = (int)((160 * 1024) / lds);
-	if (blocks_per_cu > 8) blocks_per_cu = 8;
-	if (blocks_per_cu < 1) blocks_per_cu = 1;
 	size_t need = (n_bursts + wpb - 1) / wpb;
-	size_t grid = (size_t)n_cu * blocks_per_cu;
+	size_t grid = (size_t)n_cu * (size_t)((160 * 1024) / lds);
 	if (grid > need) grid = need;
 
 #define LAUNCH(SPS_, CF_, NLD_)                                                                                 \
 	do {                                                                                                    \
-		auto k = (wpb == 8) ? burst_pull_kernel<SPS_, CF_, NLD_, 8> : burst_pull_kernel<SPS_, CF_, NLD_, 4>; \
+		auto k = burst_pull_kernel<SPS_, CF_, NLD_>;                                                    \
 		if (lds > 64 * 1024 &&                                                                           \
 		    hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
 			return TRXHIP_EIO;                                                                      \

@@ -29,7 +29,8 @@ class TrxHipError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(PKG, "lib", "libtrxhip.so")
+    # TRXHIP_LIB: profiling override (e.g. the -DTRX_DIAG build); default = the product library
+    return os.environ.get("TRXHIP_LIB") or os.path.join(PKG, "lib", "libtrxhip.so")
 
 
 _LIB = None
@@ -156,7 +157,7 @@ class TrxHip:
 
     # ---- hot path ------------------------------------------------------------------------------
     def detect_demod(self, iq, params, sps=4, threshold=4.0, full_scale=32767.0, soft_stride=148, slice_bits=True,
-                     results=None, soft=None, stream=None, want_soft=True):
+                     results=None, soft=None, stream=None, want_soft=True, _diag_mask=0):
         """iq: int16[n, burst_len, 2] or complex64[n, burst_len] (device).  params: uint8[n, 8] (device).
         Returns (results uint8[n, 32], soft float32[n, soft_stride]) device tensors."""
         torch = self.torch
@@ -179,7 +180,7 @@ class TrxHip:
         else:
             raise TrxHipError(f"unsupported IQ dtype {iq.dtype}")
         rc = fn(self.h, ip, self._dev(params), self._dev(results), sp, n, burst_len, sps,
-                threshold, full_scale, soft_stride, 1 if slice_bits else 0, self._stream(stream))
+                threshold, full_scale, soft_stride, (1 if slice_bits else 0) | (int(_diag_mask) << 8), self._stream(stream))
         _check(rc, "trxhip_detect_demod_batch")
         return results, soft
 
