@@ -131,6 +131,21 @@ int trxhip_detect_demod_batch_cf32(trxhip_ctx *ctx,
 				   float threshold, float full_scale,
 				   int soft_stride, int slice, void *stream);
 
+/* demodAnyBurst() on its own (sigProcLib.h:151-152): the caller supplies, per burst, the CorrType
+ * (d_params[b].type; EDGE is reported as detected-only, 8-PSK demodulation is not built yet) and the
+ * estim_burst_params it got from detection as d_ebp[b] = {toa, amp_re, amp_im, unused} (16-byte aligned).
+ * Detection is skipped; d_soft receives the soft bits, d_results echoes the parameters. */
+int trxhip_demod_batch_cf32(trxhip_ctx *ctx, const float *d_iq_cf32, const trxhip_burst_params *d_params,
+			    const float *d_ebp, trxhip_burst_result *d_results, float *d_soft,
+			    size_t n_bursts, int burst_len, int sps, int soft_stride, int slice, void *stream);
+
+/* energyDetect() on its own (sigProcLib.h:105, sigProcLib.cpp:1573-1585): mean |x|^2 of `window` samples at
+ * stride 4 from sample 0 of each burst (complex64); d_energy: n_bursts floats. */
+int trxhip_energy_detect_batch_cf32(trxhip_ctx *ctx, const float *d_iq_cf32, size_t n_bursts, int burst_len,
+				    unsigned window, float *d_energy, void *stream);
+/* vectorSlicer() (sigProcLib.h:63): dest = clamp(0.5*(src+1), 0, 1), device arrays */
+int trxhip_vector_slicer(trxhip_ctx *ctx, float *d_dest, const float *d_src, size_t len, void *stream);
+
 /* TRXD v0/v1 payload packing on device, proto_trxd.c:36-66:
  *   d_pkt: n_bursts * 156 bytes: [0..1] toa_int be16 (1/256 sym), [2] rssi u8 (-dBFS), [3..4] ci cB be16,
  *          [5] tsc, [6] idle, [7] nbits/4, [8..155] 148 soft bits uint8 = round(rx_burst*255) */

@@ -283,3 +283,58 @@ extern "C" int trx_launch_pack_trxd(const trxhip_burst_result *d_results, const 
 			   d_pkt, n_bursts, rssi_offset);
 	return hipGetLastError() == hipSuccess ? 0 : TRXHIP_EIO;
 }
+
+// ------------------------------------------------------------------------------------------------
+// energyDetect() as a stand-alone call (sigProcLib.cpp:1573-1585): one wave per burst, mean |x|^2 over
+// `window` samples taken at stride 4 from sample 0 (window clamped to the burst length as the reference does)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+energy_detect_kernel(const c32 *__restrict__ x, size_t n_bursts, int burst_len, unsigned window, float *__restrict__ out)
+{
+	const int lane = threadIdx.x & 63;
+	const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
+	const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+	if (window > (unsigned)burst_len) window = burst_len;
+	for (size_t b = wave; b < n_bursts; b += nwaves) {
+		float e = 0.0f;
+		for (unsigned i = lane; i < window; i += 64) {
+			const c32 v = x[b * (size_t)burst_len + 4 * (size_t)i];
+			e += v.y * v.y + v.x * v.x;
+		}
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1)
+			e += __shfl_xor(e, o, 64);
+		if (lane == 0)
+			out[b] = window ? e / (float)window : 0.0f;
+	}
+}
+
+extern "C" int trx_launch_energy_detect(const float *d_x, size_t n_bursts, int burst_len, unsigned window, float *d_out,
+					hipStream_t stream)
+{
+	if (n_bursts == 0)
+		return 0;
+	size_t blocks = (n_bursts + 3) / 4;
+	if (blocks > 2048) blocks = 2048;
+	hipLaunchKernelGGL(energy_detect_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
+			   reinterpret_cast<const c32 *>(d_x), n_bursts, burst_len, window, d_out);
+	return hipGetLastError() == hipSuccess ? 0 : TRXHIP_EIO;
+}
+
+// vectorSlicer() (sigProcLib.cpp:546-556): dest = clamp(0.5 * (src + 1), 0, 1)
+__global__ void __launch_bounds__(256)
+vector_slicer_kernel(float *__restrict__ dst, const float *__restrict__ src, size_t len)
+{
+	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x)
+		dst[i] = __builtin_amdgcn_fmed3f(0.5f * (src[i] + 1.0f), 0.0f, 1.0f);
+}
+
+extern "C" int trx_launch_vector_slicer(float *d_dst, const float *d_src, size_t len, hipStream_t stream)
+{
+	if (len == 0)
+		return 0;
+	size_t blocks = (len + 255) / 256;
+	if (blocks > 2048) blocks = 2048;
+	hipLaunchKernelGGL(vector_slicer_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d_dst, d_src, len);
+	return hipGetLastError() == hipSuccess ? 0 : TRXHIP_EIO;
+}

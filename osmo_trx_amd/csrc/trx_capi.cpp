@@ -13,7 +13,7 @@
 
 // kernel launchers (trx_kernels.hip, trx_aux_kernels.hip)
 extern "C" int trx_launch_pull(const void *d_iq, int cf32, const trxhip_burst_params *d_params,
-			       trxhip_burst_result *d_results, float *d_soft, const trx_tables *d_tab,
+			       trxhip_burst_result *d_results, float *d_soft, const trx_tables *d_tab, const float *d_ebp_in,
 			       size_t n_bursts, int L, int sps, float thresh, float full_scale,
 			       int soft_stride, int slice, int n_cu, hipStream_t stream);
 extern "C" int trx_launch_pack_trxd(const trxhip_burst_result *d_results, const float *d_soft, int soft_stride,
@@ -25,6 +25,10 @@ extern "C" int trx_launch_channelize(const int16_t *d_in, float *d_out, size_t n
 				     hipStream_t stream);
 extern "C" int trx_launch_resample(const float *d_in, float *d_out, size_t n_in, int p, int q, size_t n_chan,
 				   size_t in_stride, size_t out_stride, const trx_tables *d_tab, hipStream_t stream);
+
+extern "C" int trx_launch_energy_detect(const float *d_x, size_t n_bursts, int burst_len, unsigned window, float *d_out,
+					hipStream_t stream);
+extern "C" int trx_launch_vector_slicer(float *d_dst, const float *d_src, size_t len, hipStream_t stream);
 
 struct trxhip_ctx {
 	int device;
@@ -149,7 +153,7 @@ int trxhip_tables_device_ptr(trxhip_ctx *ctx, void **d_blob)
 }
 
 static int pull_common(trxhip_ctx *ctx, const void *d_iq, int cf32, const trxhip_burst_params *d_params,
-		       trxhip_burst_result *d_results, float *d_soft, size_t n_bursts, int burst_len, int sps,
+		       const float *d_ebp_in, trxhip_burst_result *d_results, float *d_soft, size_t n_bursts, int burst_len, int sps,
 		       float threshold, float full_scale, int soft_stride, int slice, void *stream)
 {
 	if (!ctx)
@@ -169,7 +173,7 @@ static int pull_common(trxhip_ctx *ctx, const void *d_iq, int cf32, const trxhip
 		return TRXHIP_EINVAL;
 	if (with_device(ctx))
 		return TRXHIP_EIO;
-	return trx_launch_pull(d_iq, cf32, d_params, d_results, d_soft, ctx->d_tables, n_bursts, burst_len, sps,
+	return trx_launch_pull(d_iq, cf32, d_params, d_results, d_soft, ctx->d_tables, d_ebp_in, n_bursts, burst_len, sps,
 			       threshold, full_scale, soft_stride, slice, ctx->n_cu, static_cast<hipStream_t>(stream));
 }
 
@@ -177,7 +181,7 @@ int trxhip_detect_demod_batch(trxhip_ctx *ctx, const int16_t *d_iq, const trxhip
 			      trxhip_burst_result *d_results, float *d_soft, size_t n_bursts, int burst_len, int sps,
 			      float threshold, float full_scale, int soft_stride, int slice, void *stream)
 {
-	return pull_common(ctx, d_iq, 0, d_params, d_results, d_soft, n_bursts, burst_len, sps, threshold, full_scale,
+	return pull_common(ctx, d_iq, 0, d_params, nullptr, d_results, d_soft, n_bursts, burst_len, sps, threshold, full_scale,
 			   soft_stride, slice, stream);
 }
 
@@ -185,8 +189,18 @@ int trxhip_detect_demod_batch_cf32(trxhip_ctx *ctx, const float *d_iq, const trx
 				   trxhip_burst_result *d_results, float *d_soft, size_t n_bursts, int burst_len,
 				   int sps, float threshold, float full_scale, int soft_stride, int slice, void *stream)
 {
-	return pull_common(ctx, d_iq, 1, d_params, d_results, d_soft, n_bursts, burst_len, sps, threshold, full_scale,
+	return pull_common(ctx, d_iq, 1, d_params, nullptr, d_results, d_soft, n_bursts, burst_len, sps, threshold, full_scale,
 			   soft_stride, slice, stream);
+}
+
+int trxhip_demod_batch_cf32(trxhip_ctx *ctx, const float *d_iq, const trxhip_burst_params *d_params,
+			    const float *d_ebp, trxhip_burst_result *d_results, float *d_soft, size_t n_bursts,
+			    int burst_len, int sps, int soft_stride, int slice, void *stream)
+{
+	if (n_bursts > 0 && (!d_ebp || (reinterpret_cast<uintptr_t>(d_ebp) & 15) != 0))
+		return TRXHIP_EINVAL;
+	return pull_common(ctx, d_iq, 1, d_params, d_ebp, d_results, d_soft, n_bursts, burst_len, sps,
+			   TRXHIP_BURST_THRESH, 1.0f, soft_stride, slice, stream);
 }
 
 int trxhip_pack_trxd_batch(trxhip_ctx *ctx, const trxhip_burst_result *d_results, const float *d_soft_sliced,
@@ -235,6 +249,31 @@ int trxhip_convert_short_float(trxhip_ctx *ctx, float *d_out, const int16_t *d_i
 	if (with_device(ctx))
 		return TRXHIP_EIO;
 	return trx_launch_convert_short_float(d_out, d_in, len, static_cast<hipStream_t>(stream));
+}
+
+int trxhip_energy_detect_batch_cf32(trxhip_ctx *ctx, const float *d_iq, size_t n_bursts, int burst_len,
+				    unsigned window, float *d_energy, void *stream)
+{
+	if (!ctx || burst_len < 1)
+		return TRXHIP_EINVAL;
+	if (n_bursts == 0)
+		return TRXHIP_OK;
+	if (!d_iq || !d_energy)
+		return TRXHIP_EINVAL;
+	if (window > 0 && 4 * (size_t)(window > (unsigned)burst_len ? (unsigned)burst_len : window) - 3 > (size_t)burst_len)
+		return TRXHIP_EINVAL;                  /* the reference would read past the burst (sigProcLib.cpp:1580-1583) */
+	if (with_device(ctx))
+		return TRXHIP_EIO;
+	return trx_launch_energy_detect(d_iq, n_bursts, burst_len, window, d_energy, static_cast<hipStream_t>(stream));
+}
+
+int trxhip_vector_slicer(trxhip_ctx *ctx, float *d_dest, const float *d_src, size_t len, void *stream)
+{
+	if (!ctx || (len && (!d_dest || !d_src)))
+		return TRXHIP_EINVAL;
+	if (with_device(ctx))
+		return TRXHIP_EIO;
+	return trx_launch_vector_slicer(d_dest, d_src, len, static_cast<hipStream_t>(stream));
 }
 
 int trxhip_channelize_batch(trxhip_ctx *ctx, const int16_t *d_in, float *d_out, size_t n_blocks, int m,

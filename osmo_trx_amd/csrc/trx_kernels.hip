@@ -367,7 +367,7 @@ template <int SPS, bool CF32, int NLD>
 __global__ void __launch_bounds__(TRX_WPB * WAVE, 3)
 burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__restrict__ params,
 		  trxhip_burst_result *__restrict__ results, float *__restrict__ soft,
-		  const trx_tables *__restrict__ tab,
+		  const trx_tables *__restrict__ tab, const float4 *__restrict__ ebp_in,
 		  unsigned n_bursts, int L, float thresh, float full_scale, int soft_stride, int slice)
 {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -507,7 +507,14 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 				rssi = 6.02059991f * __log2f(full_scale / sqrtf(energy));  // 20*log10(x) = 20*log10(2)*log2(x), v_log_f32
 			wave_sync();
 
-			if (type != TRXHIP_IDLE && !ABL(3)) {                   // Transceiver.cpp:754-755
+			if (ebp_in) {
+				// demodAnyBurst() on its own (sigProcLib.h:151-152): the caller supplies type, toa and amp
+				const float4 e = ebp_in[b];
+				rc = (type == TRXHIP_OFF || type == TRXHIP_IDLE) ? 0 : type;
+				toa = unif(e.x);
+				amp = make_float2(unif(e.y), unif(e.z));
+				out_tsc = tsc;
+			} else if (type != TRXHIP_IDLE && !ABL(3)) {            // Transceiver.cpp:754-755
 				// ---- detectAnyBurst (:1926-1957): up to 3 candidate windows, first hit wins
 				int ncand = 0;
 				rc = 0;
@@ -732,7 +739,7 @@ extern "C" size_t trx_pull_lds_bytes(int L, int waves_per_block)
 }
 
 extern "C" int trx_launch_pull(const void *d_iq, int cf32, const trxhip_burst_params *d_params,
-			       trxhip_burst_result *d_results, float *d_soft, const trx_tables *d_tab,
+			       trxhip_burst_result *d_results, float *d_soft, const trx_tables *d_tab, const float *d_ebp_in,
 			       size_t n_bursts, int L, int sps, float thresh, float full_scale,
 			       int soft_stride, int slice, int n_cu, hipStream_t stream)
 {
@@ -756,7 +763,8 @@ extern "C" int trx_launch_pull(const void *d_iq, int cf32, const trxhip_burst_pa
 		    hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
 			return TRXHIP_EIO;                                                                      \
 		hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(wpb * WAVE), lds, stream, d_iq, d_params, d_results, \
-				   d_soft, d_tab, (unsigned)n_bursts, L, thresh, full_scale, soft_stride, slice); \
+				   d_soft, d_tab, reinterpret_cast<const float4 *>(d_ebp_in), (unsigned)n_bursts, L, thresh,     \
+				   full_scale, soft_stride, slice);                                             \
 	} while (0)
 
 	// NLD = dword loads per lane held in registers for the prefetched burst (0 = generic length, no prefetch)

@@ -1,0 +1,263 @@
+// sigProcLib.cpp -- host shim: the reference's sigProcLib receive-side API (sigProcLib.h) on top of the
+// C ABI of include/trxhip.h.  Every computation happens on the MI355X; this file only moves buffers
+// (hipMemcpyAsync on a per-thread stream) and converts between the reference's containers and the
+// C-ABI records.  Errors map to the reference's conventions: detectAnyBurst() -> -SIGERR_INTERNAL,
+// demodAnyBurst() -> NULL, pullRadioVectorBatch() -> -EIO (Transceiver.cpp:686).
+#include <hip/hip_runtime.h>
+
+#include <cerrno>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+#include "sigProcLib.h"
+#include "trxhip.h"
+
+namespace {
+
+trxhip_ctx *g_ctx = nullptr;
+std::mutex g_mu;
+
+// Per-thread device scratch: the reference calls detect/demod concurrently from one RxUpper thread per
+// ARFCN (Transceiver.cpp:308-314), so each thread gets its own stream and buffers.
+struct Scratch {
+	hipStream_t stream = nullptr;
+	void *d_iq = nullptr;
+	size_t iq_bytes = 0;
+	trxhip_burst_params *d_prm = nullptr;
+	trxhip_burst_result *d_res = nullptr;
+	float *d_soft = nullptr;
+	float *d_ebp = nullptr;
+	size_t cap = 0;                  /* bursts */
+	size_t soft_stride = 0;
+	/* detect -> demod hand-over for the batch-of-1 calls: the fused kernel already produced the soft bits */
+	const void *last_burst = nullptr;
+	size_t last_size = 0;
+	int last_sps = 0, last_rc = 0;
+	estim_burst_params last_ebp;
+	std::vector<float> last_soft;
+
+	bool ensure(size_t n, size_t iq_b, size_t stride)
+	{
+		if (!stream && hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess)
+			return false;
+		if (iq_b > iq_bytes) {
+			if (d_iq) hipFree(d_iq);
+			if (hipMalloc(&d_iq, iq_b) != hipSuccess) { d_iq = nullptr; iq_bytes = 0; return false; }
+			iq_bytes = iq_b;
+		}
+		if (n > cap || stride > soft_stride) {
+			if (d_prm) hipFree(d_prm);
+			if (d_res) hipFree(d_res);
+			if (d_soft) hipFree(d_soft);
+			if (d_ebp) hipFree(d_ebp);
+			size_t nn = n > cap ? n : cap, ss = stride > soft_stride ? stride : soft_stride;
+			if (hipMalloc((void **)&d_prm, nn * sizeof(trxhip_burst_params)) != hipSuccess ||
+			    hipMalloc((void **)&d_res, nn * sizeof(trxhip_burst_result)) != hipSuccess ||
+			    hipMalloc((void **)&d_soft, nn * ss * sizeof(float)) != hipSuccess ||
+			    hipMalloc((void **)&d_ebp, nn * 4 * sizeof(float)) != hipSuccess)
+				return false;
+			cap = nn;
+			soft_stride = ss;
+		}
+		return true;
+	}
+	~Scratch()
+	{
+		if (d_iq) hipFree(d_iq);
+		if (d_prm) hipFree(d_prm);
+		if (d_res) hipFree(d_res);
+		if (d_soft) hipFree(d_soft);
+		if (d_ebp) hipFree(d_ebp);
+		if (stream) hipStreamDestroy(stream);
+	}
+};
+thread_local Scratch tls;
+
+bool h2d(void *d, const void *h, size_t n, hipStream_t s) { return hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s) == hipSuccess; }
+bool d2h(void *h, const void *d, size_t n, hipStream_t s) { return hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s) == hipSuccess; }
+
+size_t soft_len(int sps, size_t burst_size) { return sps == 4 ? 156 : burst_size; }
+
+}  // namespace
+
+bool sigProcLibSetup()
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	if (g_ctx)
+		return true;
+	const char *dev = getenv("TRXHIP_DEVICE");
+	int rc = trxhip_create(&g_ctx, dev ? atoi(dev) : 0);
+	if (rc != TRXHIP_OK) {
+		fprintf(stderr, "sigProcLibSetup: %s\n", trxhip_strerror(rc));
+		g_ctx = nullptr;
+		return false;
+	}
+	return true;
+}
+
+void sigProcLibDestroy(void)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	trxhip_destroy(g_ctx);
+	g_ctx = nullptr;
+}
+
+void vectorSlicer(float *dest, const float *src, size_t len)
+{
+	Scratch &t = tls;
+	if (!g_ctx || !len || !t.ensure(1, 2 * len * sizeof(float), 1))
+		return;
+	float *d_src = static_cast<float *>(t.d_iq), *d_dst = d_src + len;
+	if (h2d(d_src, src, len * sizeof(float), t.stream) &&
+	    trxhip_vector_slicer(g_ctx, d_dst, d_src, len, t.stream) == TRXHIP_OK &&
+	    d2h(dest, d_dst, len * sizeof(float), t.stream))
+		hipStreamSynchronize(t.stream);
+}
+
+float energyDetect(const signalVector &rxBurst, unsigned windowLength)
+{
+	Scratch &t = tls;
+	if (!g_ctx || windowLength == 0 || !t.ensure(1, rxBurst.bytes(), 1))
+		return 0.0f;
+	float e = 0.0f;
+	if (!h2d(t.d_iq, rxBurst.begin(), rxBurst.bytes(), t.stream) ||
+	    trxhip_energy_detect_batch_cf32(g_ctx, static_cast<const float *>(t.d_iq), 1, (int)rxBurst.size(), windowLength,
+					    t.d_soft, t.stream) != TRXHIP_OK ||
+	    !d2h(&e, t.d_soft, sizeof(float), t.stream) || hipStreamSynchronize(t.stream) != hipSuccess)
+		return 0.0f;
+	return e;
+}
+
+int detectAnyBurst(const signalVector &burst, unsigned tsc, float threshold, int sps, CorrType type,
+		   unsigned max_toa, struct estim_burst_params *ebp)
+{
+	Scratch &t = tls;
+	t.last_burst = nullptr;
+	if ((sps != 1) && (sps != 4))
+		return -SIGERR_UNSUPPORTED;                    /* sigProcLib.cpp:1740-1741 */
+	if (!g_ctx || !ebp)
+		return -SIGERR_INTERNAL;
+	const size_t n = burst.size();
+	const size_t stride = soft_len(sps, n) < 156 ? 156 : soft_len(sps, n);
+	if (!t.ensure(1, burst.bytes(), stride))
+		return -SIGERR_INTERNAL;
+
+	trxhip_burst_params prm;
+	memset(&prm, 0, sizeof(prm));
+	prm.type = (uint8_t)type;
+	prm.tsc = (uint8_t)(tsc > 255 ? 255 : tsc);
+	prm.max_toa = (uint16_t)(max_toa > 65535 ? 65535 : max_toa);
+	trxhip_burst_result res;
+	t.last_soft.assign(stride, 0.0f);
+	if (!h2d(t.d_iq, burst.begin(), burst.bytes(), t.stream) || !h2d(t.d_prm, &prm, sizeof(prm), t.stream))
+		return -SIGERR_INTERNAL;
+	int rc = trxhip_detect_demod_batch_cf32(g_ctx, static_cast<const float *>(t.d_iq), t.d_prm, t.d_res, t.d_soft, 1,
+						(int)n, sps, threshold, 1.0f, (int)stride, 0 /* raw soft bits */, t.stream);
+	if (rc != TRXHIP_OK || !d2h(&res, t.d_res, sizeof(res), t.stream) ||
+	    !d2h(t.last_soft.data(), t.d_soft, stride * sizeof(float), t.stream) ||
+	    hipStreamSynchronize(t.stream) != hipSuccess)
+		return -SIGERR_INTERNAL;
+
+	ebp->amp = complex(res.amp_re, res.amp_im);
+	ebp->toa = res.toa;
+	ebp->ci = res.ci;
+	if (type == TSC || type == EDGE || type == IDLE)
+		ebp->tsc = (type == IDLE) ? 0 : (uint8_t)tsc;         /* sigProcLib.cpp:1901,1920,1874 */
+	if (res.rc > 0 && (type == RACH || type == EXT_RACH))
+		ebp->tsc = res.tsc;                                    /* :1797 */
+	if (res.rc > 0) {
+		t.last_burst = burst.begin();
+		t.last_size = n;
+		t.last_sps = sps;
+		t.last_rc = res.rc;
+		t.last_ebp = *ebp;
+	}
+	return res.rc;
+}
+
+SoftVector *demodAnyBurst(const signalVector &burst, CorrType type, int sps, struct estim_burst_params *ebp)
+{
+	Scratch &t = tls;
+	if (!g_ctx || !ebp || ((sps != 1) && (sps != 4)))
+		return NULL;
+	if (type == EDGE)
+		return NULL;                  /* 8-PSK demodulation: not built yet */
+	const size_t n = burst.size();
+	const size_t ns = soft_len(sps, n);
+	SoftVector *bits = new SoftVector(ns);
+
+	/* the fused kernel already demodulated this burst during detectAnyBurst() with these very parameters */
+	if (t.last_burst == burst.begin() && t.last_size == n && t.last_sps == sps && t.last_rc == (int)type &&
+	    t.last_ebp.toa == ebp->toa && t.last_ebp.amp == ebp->amp && t.last_soft.size() >= ns) {
+		memcpy(bits->begin(), t.last_soft.data(), ns * sizeof(float));
+		return bits;
+	}
+
+	const size_t stride = ns < 156 ? 156 : ns;
+	trxhip_burst_params prm;
+	memset(&prm, 0, sizeof(prm));
+	prm.type = (uint8_t)type;
+	prm.tsc = ebp->tsc;
+	const float e[4] = { ebp->toa, ebp->amp.real(), ebp->amp.imag(), 0.0f };
+	if (!t.ensure(1, burst.bytes(), stride) || !h2d(t.d_iq, burst.begin(), burst.bytes(), t.stream) ||
+	    !h2d(t.d_prm, &prm, sizeof(prm), t.stream) || !h2d(t.d_ebp, e, sizeof(e), t.stream) ||
+	    trxhip_demod_batch_cf32(g_ctx, static_cast<const float *>(t.d_iq), t.d_prm, t.d_ebp, t.d_res, t.d_soft, 1, (int)n,
+				    sps, (int)stride, 0, t.stream) != TRXHIP_OK ||
+	    !d2h(bits->begin(), t.d_soft, ns * sizeof(float), t.stream) || hipStreamSynchronize(t.stream) != hipSuccess) {
+		delete bits;
+		return NULL;
+	}
+	return bits;
+}
+
+int pullRadioVectorBatch(const BurstRequest *req, size_t n, int sps, size_t burst_len, double rxFullScale,
+			 double rssi_offset, BurstIndication *out)
+{
+	Scratch &t = tls;
+	if (!n)
+		return 0;
+	if (!g_ctx || !req || !out)
+		return -EIO;
+	const size_t burst_bytes = burst_len * 2 * sizeof(int16_t);
+	if (!t.ensure(n, n * burst_bytes, NORMAL_BURST_NBITS))
+		return -EIO;
+
+	std::vector<int16_t> iq(n * burst_len * 2);
+	std::vector<trxhip_burst_params> prm(n);
+	for (size_t i = 0; i < n; i++) {
+		memcpy(&iq[i * burst_len * 2], req[i].iq, burst_bytes);
+		memset(&prm[i], 0, sizeof(prm[i]));
+		prm[i].type = (uint8_t)req[i].type;
+		prm[i].tsc = (uint8_t)req[i].tsc;
+		prm[i].max_toa = (uint16_t)req[i].max_toa;
+	}
+	std::vector<trxhip_burst_result> res(n);
+	std::vector<float> soft(n * NORMAL_BURST_NBITS);
+	if (!h2d(t.d_iq, iq.data(), n * burst_bytes, t.stream) || !h2d(t.d_prm, prm.data(), n * sizeof(prm[0]), t.stream))
+		return -EIO;
+	int rc = trxhip_detect_demod_batch(g_ctx, static_cast<const int16_t *>(t.d_iq), t.d_prm, t.d_res, t.d_soft, n,
+					   (int)burst_len, sps, BURST_THRESH, (float)rxFullScale, NORMAL_BURST_NBITS,
+					   1 /* vectorSlicer applied */, t.stream);
+	if (rc != TRXHIP_OK || !d2h(res.data(), t.d_res, n * sizeof(res[0]), t.stream) ||
+	    !d2h(soft.data(), t.d_soft, soft.size() * sizeof(float), t.stream) || hipStreamSynchronize(t.stream) != hipSuccess)
+		return -EIO;
+
+	for (size_t i = 0; i < n; i++) {
+		BurstIndication &bi = out[i];
+		memset(&bi, 0, sizeof(bi));
+		bi.rc = res[i].rc;
+		bi.idle = res[i].idle != 0;
+		bi.energy = res[i].energy;
+		bi.rssi = req[i].type == OFF ? 0.0 : (double)res[i].rssi + rssi_offset;     /* Transceiver.cpp:751 */
+		if (!bi.idle) {
+			bi.toa = res[i].toa;
+			bi.tsc = res[i].tsc;
+			bi.ci = res[i].ci;
+			bi.nbits = 4u * res[i].nbits_div4;
+			memcpy(bi.rx_burst, &soft[i * NORMAL_BURST_NBITS], sizeof(bi.rx_burst));
+		}
+	}
+	return 0;
+}

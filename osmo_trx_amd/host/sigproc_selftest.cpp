@@ -1,0 +1,92 @@
+// sigproc_selftest.cpp -- exercises the sigProcLib-compatible host shim the way the reference's callers do
+// (burst-gen.cpp:274-290 for the captured burst; Transceiver.cpp:768-803 for the detect -> demod -> slice
+// sequence).  Reads inputs prepared by tests/test_gpu_host_shim.py, writes results as plain text/binary.
+//   sigproc_selftest capture <cfile> <out.txt>
+//   sigproc_selftest batch <iq.s16> <params.bin> <n> <sps> <burst_len> <out_results.bin> <out_soft.bin>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "sigProcLib.h"
+
+static std::vector<char> slurp(const char *path)
+{
+	std::vector<char> v;
+	FILE *f = fopen(path, "rb");
+	if (!f) { perror(path); exit(2); }
+	fseek(f, 0, SEEK_END);
+	long n = ftell(f);
+	fseek(f, 0, SEEK_SET);
+	v.resize(n);
+	if (fread(v.data(), 1, n, f) != (size_t)n) { perror("read"); exit(2); }
+	fclose(f);
+	return v;
+}
+
+int main(int argc, char **argv)
+{
+	if (argc < 2) return 2;
+	if (!sigProcLibSetup()) { fprintf(stderr, "no GPU\n"); return 3; }
+
+	if (!strcmp(argv[1], "capture") && argc == 4) {
+		std::vector<char> raw = slurp(argv[2]);
+		size_t n = raw.size() / sizeof(complex);
+		signalVector sv(reinterpret_cast<complex *>(raw.data()), 0, n);
+		struct estim_burst_params ebp;
+		int rc = detectAnyBurst(sv, 7, BURST_THRESH, 4, TSC, 40, &ebp);
+		FILE *o = fopen(argv[3], "w");
+		fprintf(o, "rc %d\ntoa %.9g\namp %.9g %.9g\nci %.9g\ntsc %u\n", rc, ebp.toa, ebp.amp.real(), ebp.amp.imag(), ebp.ci, ebp.tsc);
+		if (rc > 0) {
+			std::unique_ptr<SoftVector> soft(demodAnyBurst(sv, (CorrType)rc, 4, &ebp));
+			fprintf(o, "nsoft %zu\nbits ", soft->size());
+			for (size_t i = 0; i < 148; i++) fputc(soft->bit(i) ? '1' : '0', o);
+			fputc('\n', o);
+			/* second path: demod alone with caller-held parameters on a copy of the burst */
+			signalVector copy(n);
+			memcpy(copy.begin(), sv.begin(), sv.bytes());
+			std::unique_ptr<SoftVector> soft2(demodAnyBurst(copy, (CorrType)rc, 4, &ebp));
+			int same = soft2 && soft2->size() == soft->size() && !memcmp(soft2->begin(), soft->begin(), soft->bytes());
+			fprintf(o, "demod_alone_identical %d\n", same);
+			float sliced[148];
+			vectorSlicer(sliced, soft->begin(), 148);
+			fprintf(o, "sliced0 %.9g %.9g %.9g\n", sliced[0], sliced[73], sliced[147]);
+		}
+		fprintf(o, "energy %.9g\n", energyDetect(sv, 80));
+		fclose(o);
+		sigProcLibDestroy();
+		return 0;
+	}
+
+	if (!strcmp(argv[1], "batch") && argc == 9) {
+		std::vector<char> iq = slurp(argv[2]), pr = slurp(argv[3]);
+		size_t n = atol(argv[4]);
+		int sps = atoi(argv[5]);
+		size_t burst_len = atol(argv[6]);
+		std::vector<BurstRequest> req(n);
+		const int16_t *s = reinterpret_cast<const int16_t *>(iq.data());
+		for (size_t i = 0; i < n; i++) {
+			const unsigned char *p = reinterpret_cast<const unsigned char *>(pr.data()) + 8 * i;
+			req[i].iq = s + i * burst_len * 2;
+			req[i].type = (CorrType)p[0];
+			req[i].tsc = p[1];
+			req[i].max_toa = p[2] | (p[3] << 8);
+		}
+		std::vector<BurstIndication> out(n);
+		int rc = pullRadioVectorBatch(req.data(), n, sps, burst_len, 32767.0, 0.0, out.data());
+		if (rc) { fprintf(stderr, "pullRadioVectorBatch rc=%d\n", rc); return 4; }
+		FILE *fr = fopen(argv[7], "wb"), *fs = fopen(argv[8], "wb");
+		for (size_t i = 0; i < n; i++) {
+			float rec[6] = { (float)out[i].rc, (float)out[i].toa, out[i].ci, (float)out[i].rssi, (float)out[i].idle,
+					 (float)out[i].tsc };
+			fwrite(rec, sizeof(rec), 1, fr);
+			fwrite(out[i].rx_burst, sizeof(float), 148, fs);
+		}
+		fclose(fr);
+		fclose(fs);
+		sigProcLibDestroy();
+		return 0;
+	}
+	return 2;
+}

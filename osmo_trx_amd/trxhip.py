@@ -50,6 +50,9 @@ SYMBOLS = {
     "trxhip_tables_checksum": (C.c_uint64, [_VP, _SZ]),
     "trxhip_detect_demod_batch": (_I, [_VP, _VP, _VP, _VP, _VP, _SZ, _I, _I, _F, _F, _I, _I, _VP]),
     "trxhip_detect_demod_batch_cf32": (_I, [_VP, _VP, _VP, _VP, _VP, _SZ, _I, _I, _F, _F, _I, _I, _VP]),
+    "trxhip_demod_batch_cf32": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _SZ, _I, _I, _I, _I, _VP]),
+    "trxhip_energy_detect_batch_cf32": (_I, [_VP, _VP, _SZ, _I, C.c_uint, _VP, _VP]),
+    "trxhip_vector_slicer": (_I, [_VP, _VP, _VP, _SZ, _VP]),
     "trxhip_pack_trxd_batch": (_I, [_VP, _VP, _VP, _I, _VP, _SZ, _F, _VP]),
     "trxhip_convolve_real_batch": (_I, [_VP, _VP, _I, _VP, _I, _VP, _I, _I, _I, _SZ, _VP]),
     "trxhip_convolve_complex_batch": (_I, [_VP, _VP, _I, _VP, _I, _VP, _I, _I, _I, _SZ, _VP]),
@@ -184,6 +187,18 @@ class TrxHip:
         _check(rc, "trxhip_detect_demod_batch")
         return results, soft
 
+    def demod_only(self, iq_cf32, params, ebp, sps=4, soft_stride=156, slice_bits=False, stream=None):
+        """demodAnyBurst() alone: iq complex64[n, L], params uint8[n, 8], ebp float32[n, 4] = {toa, amp_re, amp_im, 0}."""
+        torch = self.torch
+        n, burst_len = iq_cf32.shape
+        results = torch.empty((n, 32), dtype=torch.uint8, device=iq_cf32.device)
+        soft = torch.empty((n, soft_stride), dtype=torch.float32, device=iq_cf32.device)
+        rc = self.L.trxhip_demod_batch_cf32(self.h, self._dev(iq_cf32), self._dev(params), self._dev(ebp, torch.float32),
+                                            self._dev(results), self._dev(soft), n, burst_len, sps, soft_stride,
+                                            1 if slice_bits else 0, self._stream(stream))
+        _check(rc, "trxhip_demod_batch_cf32")
+        return results, soft
+
     @staticmethod
     def results_to_numpy(results):
         return results.cpu().numpy().view(RESULT_DTYPE).reshape(-1)
@@ -208,6 +223,21 @@ class TrxHip:
                 self._stream(stream))
         _check(rc, "trxhip_convolve_batch")
         return y
+
+    def energy_detect(self, iq_cf32, window, stream=None):
+        torch = self.torch
+        n, burst_len = iq_cf32.shape
+        out = torch.empty(n, dtype=torch.float32, device=iq_cf32.device)
+        _check(self.L.trxhip_energy_detect_batch_cf32(self.h, self._dev(iq_cf32), n, burst_len, window, self._dev(out),
+                                                      self._stream(stream)), "trxhip_energy_detect_batch_cf32")
+        return out
+
+    def vector_slicer(self, src, stream=None):
+        torch = self.torch
+        out = torch.empty_like(src)
+        _check(self.L.trxhip_vector_slicer(self.h, self._dev(out), self._dev(src, torch.float32), src.numel(),
+                                           self._stream(stream)), "trxhip_vector_slicer")
+        return out
 
     def convert_short_float(self, s, stream=None):
         torch = self.torch

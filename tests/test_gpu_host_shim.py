@@ -1,0 +1,75 @@
+"""GPU tests of the C++ host shim (osmo_trx_amd/host): the reference's sigProcLib.h signatures
+(detectAnyBurst / demodAnyBurst / energyDetect / vectorSlicer) and the batched pullRadioVector core,
+driven from C++ exactly as the reference's callers drive them, checked against the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "osmo_trx_amd", "lib", "sigproc_selftest")
+
+
+@pytest.fixture(scope="module")
+def exe():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from osmo_trx_amd import build as trx_build
+    trx_build.build_all()
+    assert os.path.exists(EXE)
+    return EXE
+
+
+def test_captured_burst_through_sigproclib_api(exe, golden_dir, tmp_path):
+    """burst-gen.cpp:274-290 with the shim's detectAnyBurst()/demodAnyBurst()."""
+    out = tmp_path / "cap.txt"
+    subprocess.check_call([exe, "capture", os.path.join(golden_dir, "nb_chunk_tsc7.cfile"), str(out)])
+    kv = dict(line.split(" ", 1) for line in out.read_text().strip().splitlines())
+    assert int(kv["rc"]) == O.TSC
+    assert np.float32(float(kv["toa"])) == np.float32(12.535156)
+    ar, ai = (float(v) for v in kv["amp"].split())
+    assert abs(ar + 0.00112989) < 1e-8 and abs(ai - 0.00166411) < 1e-8
+    assert abs(float(kv["ci"]) - 6.460016) < 2e-5
+    assert int(kv["nsoft"]) == 156
+    bits = np.fromfile(os.path.join(golden_dir, "demodbits_tsc7.s8"), dtype=np.int8)
+    assert kv["bits"] == "".join("1" if b > 0 else "0" for b in bits)
+    assert int(kv["demod_alone_identical"]) == 1          # demodAnyBurst() on its own == fused result
+    x = np.fromfile(os.path.join(golden_dir, "nb_chunk_tsc7.cfile"), dtype=np.complex64)
+    e = O.lib().orc_energy_detect(x.ctypes.data, len(x), 80)
+    assert abs(float(kv["energy"]) - e) <= 1e-6 * e
+    rc, ebp = O.detect_any_burst(x, 7, 4.0, 4, O.TSC, 40)
+    soft = O.demod_any_burst(x, rc, 4, ebp)
+    sl = np.zeros(148, dtype=np.float32)
+    O.lib().orc_vector_slicer(sl.ctypes.data, soft.ctypes.data, 148)
+    got = [np.float32(float(v)) for v in kv["sliced0"].split()]
+    assert got == [sl[0], sl[73], sl[147]]
+
+
+def test_pull_radio_vector_batch(exe, tmp_path):
+    from osmo_trx_amd import synth
+    n = 512
+    iq, params = synth.make_mixed_bursts(n, "cpu")
+    params = synth.make_idle_off_mix(params)
+    (tmp_path / "iq.s16").write_bytes(iq.numpy().tobytes())
+    (tmp_path / "p.bin").write_bytes(params.tobytes())
+    subprocess.check_call([exe, "batch", str(tmp_path / "iq.s16"), str(tmp_path / "p.bin"), str(n), "4", "625",
+                           str(tmp_path / "r.bin"), str(tmp_path / "s.bin")])
+    rec = np.fromfile(tmp_path / "r.bin", dtype=np.float32).reshape(n, 6)
+    soft = np.fromfile(tmp_path / "s.bin", dtype=np.float32).reshape(n, 148)
+    o_res, o_soft = O.pull_batch(iq.numpy(), 4, params)
+    assert np.array_equal(rec[:, 0].astype(np.int32), o_res["rc"])
+    assert np.array_equal(rec[:, 4].astype(np.uint8), o_res["idle"])
+    det = o_res["idle"] == 0
+    assert np.array_equal(rec[det, 1], o_res["toa"][det])
+    assert np.array_equal(rec[det, 5].astype(np.uint8), o_res["tsc"][det])
+    np.testing.assert_allclose(rec[det, 2], o_res["ci"][det], atol=2e-5)
+    on = params["type"] != O.OFF
+    fin = np.isfinite(o_res["rssi"]) & on
+    np.testing.assert_allclose(rec[fin, 3], o_res["rssi"][fin], rtol=1e-5, atol=1e-4)
+    assert np.array_equal(soft[det], o_soft[det])
