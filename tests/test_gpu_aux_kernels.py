@@ -161,10 +161,10 @@ def test_trxd_packing(trx):
     L = O.lib()
     for i in range(256):
         toa = L.orc_trxd_toa256(float(r["toa"][i])) & 0xFFFF
-        assert (pkt[i, 0] << 8 | pkt[i, 1]) == toa
+        assert (int(pkt[i, 0]) << 8 | int(pkt[i, 1])) == toa
         assert pkt[i, 2] == min(255, max(0, int(float(r["rssi"][i]) + 3.0)))
         ci = L.orc_trxd_ci_cb(float(r["ci"][i])) & 0xFFFF
-        assert (pkt[i, 3] << 8 | pkt[i, 4]) == ci
+        assert (int(pkt[i, 3]) << 8 | int(pkt[i, 4])) == ci
         assert pkt[i, 5] == r["tsc"][i] and pkt[i, 6] == r["idle"][i] and pkt[i, 7] == r["nbits_div4"][i]
         u8 = np.zeros(148, dtype=np.uint8)
         if not r["idle"][i]:
