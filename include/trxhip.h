@@ -59,6 +59,14 @@ enum trxhip_signal_error {
 #define TRXHIP_MAX_BURST_LEN 1536   /* samples per burst the kernels accept (625 @4 SPS, 156/157 @1 SPS) */
 #define TRXHIP_BURST_THRESH   4.0f  /* BURST_THRESH, sigProcLib.h:54 */
 
+/* `flags` of the detect/demod entry points */
+#define TRXHIP_FLAG_SLICE        1  /* soft bits through vectorSlicer(): 0..1, 148 per burst (else raw -1..+1) */
+#define TRXHIP_FLAG_EXACT_DEMOD  2  /* demodulate with the reference's two FIR stages in its operand order: soft bits
+                                     * bit-identical to the generic-C reference.  Default (flag clear) is the fused
+                                     * 35-tap delay-o-decimate filter with FMA: same result to <= 2e-6 of full scale,
+                                     * ~3x fewer multiply-adds.  Detection (rc, TOA, amp, C/I) is bit-exact either way.
+                                     * Only the 4-SPS / 625-sample kernel has a fused path; others are always exact. */
+
 /* Per-burst input: what pullRadioVector() knows before calling detectAnyBurst()
  * (expectedCorrType() Transceiver.cpp:513-601, mTSC, mMaxExpectedDelayAB/NB :757-758). 8 bytes. */
 typedef struct trxhip_burst_params {
@@ -110,10 +118,10 @@ uint64_t trxhip_tables_checksum(const void *h_blob, size_t size);     /* FNV-1a 
  *   d_params : n_bursts trxhip_burst_params
  *   d_results: n_bursts trxhip_burst_result
  *   d_soft   : n_bursts * soft_stride float32 (may be NULL to skip soft output).
- *              slice != 0: rx_burst[] after vectorSlicer(), 0..1, first nbits valid (148) -- what
- *              pullRadioVector() hands to TRXD; slice == 0: raw demodAnyBurst() SoftVector
- *              (-1..+1; 156 values @4 SPS, burst_len @1 SPS, 444 for 8-PSK).  Unused tail and
- *              undetected bursts are zero-filled.
+ *              TRXHIP_FLAG_SLICE set: rx_burst[] after vectorSlicer(), 0..1, first nbits valid (148) -- what
+ *              pullRadioVector() hands to TRXD; clear: raw demodAnyBurst() SoftVector
+ *              (-1..+1; 156 values @4 SPS, burst_len @1 SPS).  Unused tail and undetected bursts are zero-filled.
+ *   flags    : TRXHIP_FLAG_* bits
  *   sps      : 1 or 4; burst_len: 625 @4 SPS (>= 624), 156/157 @1 SPS
  */
 int trxhip_detect_demod_batch(trxhip_ctx *ctx,
@@ -121,7 +129,7 @@ int trxhip_detect_demod_batch(trxhip_ctx *ctx,
 			      trxhip_burst_result *d_results, float *d_soft,
 			      size_t n_bursts, int burst_len, int sps,
 			      float threshold, float full_scale,
-			      int soft_stride, int slice, void *stream);
+			      int soft_stride, int flags, void *stream);
 
 /* Same, from complex64 device samples (the form sigProcLib's detectAnyBurst()/demodAnyBurst() take). */
 int trxhip_detect_demod_batch_cf32(trxhip_ctx *ctx,
@@ -129,7 +137,7 @@ int trxhip_detect_demod_batch_cf32(trxhip_ctx *ctx,
 				   trxhip_burst_result *d_results, float *d_soft,
 				   size_t n_bursts, int burst_len, int sps,
 				   float threshold, float full_scale,
-				   int soft_stride, int slice, void *stream);
+				   int soft_stride, int flags, void *stream);
 
 /* demodAnyBurst() on its own (sigProcLib.h:151-152): the caller supplies, per burst, the CorrType
  * (d_params[b].type; EDGE is reported as detected-only, 8-PSK demodulation is not built yet) and the
@@ -137,7 +145,7 @@ int trxhip_detect_demod_batch_cf32(trxhip_ctx *ctx,
  * Detection is skipped; d_soft receives the soft bits, d_results echoes the parameters. */
 int trxhip_demod_batch_cf32(trxhip_ctx *ctx, const float *d_iq_cf32, const trxhip_burst_params *d_params,
 			    const float *d_ebp, trxhip_burst_result *d_results, float *d_soft,
-			    size_t n_bursts, int burst_len, int sps, int soft_stride, int slice, void *stream);
+			    size_t n_bursts, int burst_len, int sps, int soft_stride, int flags, void *stream);
 
 /* energyDetect() on its own (sigProcLib.h:105, sigProcLib.cpp:1573-1585): mean |x|^2 of `window` samples at
  * stride 4 from sample 0 of each burst (complex64); d_energy: n_bursts floats. */

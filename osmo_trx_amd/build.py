@@ -21,7 +21,7 @@ LIB = os.path.join(LIBDIR, "libtrxhip.so")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-result"]
 
-LIB_SOURCES = ["trx_kernels.hip", "trx_aux_kernels.hip", "trx_capi.cpp", "trx_tables.cpp"]
+LIB_SOURCES = ["trx_kernel4.hip", "trx_kernels.hip", "trx_aux_kernels.hip", "trx_capi.cpp", "trx_tables.cpp"]
 
 
 def _stale(target, sources):
@@ -42,7 +42,8 @@ def _run(cmd):
 def build_lib(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = [os.path.join(CSRC, s) for s in LIB_SOURCES]
-    deps = srcs + [os.path.join(CSRC, "trx_tables.h"), os.path.join(ROOT, "include", "trxhip.h")]
+    deps = srcs + [os.path.join(CSRC, "trx_tables.h"), os.path.join(CSRC, "trx_device.h"),
+                   os.path.join(ROOT, "include", "trxhip.h")]
     if force or _stale(LIB, deps):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared"] + COMMON + ["-o", LIB] + srcs
         if verbose:

@@ -154,7 +154,7 @@ int trxhip_tables_device_ptr(trxhip_ctx *ctx, void **d_blob)
 
 static int pull_common(trxhip_ctx *ctx, const void *d_iq, int cf32, const trxhip_burst_params *d_params,
 		       const float *d_ebp_in, trxhip_burst_result *d_results, float *d_soft, size_t n_bursts, int burst_len, int sps,
-		       float threshold, float full_scale, int soft_stride, int slice, void *stream)
+		       float threshold, float full_scale, int soft_stride, int flags, void *stream)
 {
 	if (!ctx)
 		return TRXHIP_EINVAL;
@@ -174,33 +174,33 @@ static int pull_common(trxhip_ctx *ctx, const void *d_iq, int cf32, const trxhip
 	if (with_device(ctx))
 		return TRXHIP_EIO;
 	return trx_launch_pull(d_iq, cf32, d_params, d_results, d_soft, ctx->d_tables, d_ebp_in, n_bursts, burst_len, sps,
-			       threshold, full_scale, soft_stride, slice, ctx->n_cu, static_cast<hipStream_t>(stream));
+			       threshold, full_scale, soft_stride, flags, ctx->n_cu, static_cast<hipStream_t>(stream));
 }
 
 int trxhip_detect_demod_batch(trxhip_ctx *ctx, const int16_t *d_iq, const trxhip_burst_params *d_params,
 			      trxhip_burst_result *d_results, float *d_soft, size_t n_bursts, int burst_len, int sps,
-			      float threshold, float full_scale, int soft_stride, int slice, void *stream)
+			      float threshold, float full_scale, int soft_stride, int flags, void *stream)
 {
 	return pull_common(ctx, d_iq, 0, d_params, nullptr, d_results, d_soft, n_bursts, burst_len, sps, threshold, full_scale,
-			   soft_stride, slice, stream);
+			   soft_stride, flags, stream);
 }
 
 int trxhip_detect_demod_batch_cf32(trxhip_ctx *ctx, const float *d_iq, const trxhip_burst_params *d_params,
 				   trxhip_burst_result *d_results, float *d_soft, size_t n_bursts, int burst_len,
-				   int sps, float threshold, float full_scale, int soft_stride, int slice, void *stream)
+				   int sps, float threshold, float full_scale, int soft_stride, int flags, void *stream)
 {
 	return pull_common(ctx, d_iq, 1, d_params, nullptr, d_results, d_soft, n_bursts, burst_len, sps, threshold, full_scale,
-			   soft_stride, slice, stream);
+			   soft_stride, flags, stream);
 }
 
 int trxhip_demod_batch_cf32(trxhip_ctx *ctx, const float *d_iq, const trxhip_burst_params *d_params,
 			    const float *d_ebp, trxhip_burst_result *d_results, float *d_soft, size_t n_bursts,
-			    int burst_len, int sps, int soft_stride, int slice, void *stream)
+			    int burst_len, int sps, int soft_stride, int flags, void *stream)
 {
 	if (n_bursts > 0 && (!d_ebp || (reinterpret_cast<uintptr_t>(d_ebp) & 15) != 0))
 		return TRXHIP_EINVAL;
 	return pull_common(ctx, d_iq, 1, d_params, d_ebp, d_results, d_soft, n_bursts, burst_len, sps,
-			   TRXHIP_BURST_THRESH, 1.0f, soft_stride, slice, stream);
+			   TRXHIP_BURST_THRESH, 1.0f, soft_stride, flags, stream);
 }
 
 int trxhip_pack_trxd_batch(trxhip_ctx *ctx, const trxhip_burst_result *d_results, const float *d_soft_sliced,

@@ -1,0 +1,527 @@
+// trx_kernel4.hip -- the production kernel for 4-SPS bursts of 624..628 samples (the only burst size the
+// transceiver produces at 4 SPS: 625, radioInterface.cpp:254-260).  Same algorithm and boundary as the generic
+// burst_pull_kernel (trx_kernels.hip); what differs is how the two resources that bound it are spent:
+//
+//   * LDS: the burst is kept in a POLYPHASE layout -- four arrays P_r[m] = x[4m + r].  Every FIR of the path
+//     advances in steps of 4 samples per lane (the /4 decimator) or a multiple of 4 (12 outputs per lane in
+//     the fractional-delay filter), so consecutive lanes read consecutive LDS words of one phase array:
+//     bank-conflict-free ds_read_b64, where the linear layout was 2- and 4-way conflicted (42 % of all
+//     LDS cycles).  The phase of a tap is wave-uniform, so addresses are lane base + compile-time offset.
+//   * VALU: two demodulators.
+//       EXACT (TRXHIP_FLAG_EXACT_DEMOD): delayVector -> scaleVector -> downsampleBurst as the reference
+//         does it, two FIR stages in the reference's operand order: soft bits bit-identical to generic C.
+//       FUSED (default): delay(20 taps) o decimate(16 taps) is ONE 35-tap filter evaluated only at the 148/156
+//         symbol instants (5.5 k MACs instead of 15 k), with FMA.  The reference truncates the intermediate
+//         signal (zero outside [0, L) after the delay, zero history in front of the decimator): the <= 8
+//         outputs whose decimator window straddles those edges are recomputed with the exact masked two-stage
+//         sum, so the result differs from the reference only by rounding (<= 2e-6 of full scale; bar 1e-4).
+//     Detection (rc, TOA, amp, C/I) is shared and bit-exact in both modes.
+#include "trx_device.h"
+
+#define PH_A   180                 // entries per phase array (= 4 mod 16: conflict-free loader writes)
+#define PH_M0  12                  // position of m = 0 inside a phase array (48 samples of zero pad in front)
+#define K4_XS  (4 * PH_A)
+#define K4_EDGE 8
+#define K4_SLICE (K4_XS + TRX_DEC_LEN + TRX_CZ_LEN + K4_EDGE)
+#define K4_DROWS (TRX_DELAY_FILTS + 1)                         // + identity row (no fractional filter)
+#define K4_TABLES_FLOATS (TRX_SINCV_LDS + K4_DROWS * TRX_DELAY_HLEN + 2 * 160 + 16 + 2 * LSEQ_TAPS + 8 * LSEQ_NHDR + K4_DROWS * 36)
+#define K4_TABLES_BYTES (K4_TABLES_FLOATS * 4)
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int fdiv(int a, int b) { const int q = a / b; return (a % b != 0 && a < 0) ? q - 1 : q; }   // b > 0
+__device__ __forceinline__ int cdiv(int a, int b) { return -fdiv(-a, b); }
+
+// four per-lane base pointers for a run of consecutive samples s0, s0+1, ... : sample s0+t lives at
+// pb[t & 3][t >> 2].  ph0 = s0 & 3, m0 = s0 >> 2 (arithmetic).
+struct PhBase { const c32 *p[4]; };
+__device__ __forceinline__ PhBase ph_bases(const c32 *P, int ph0, int m0)
+{
+	PhBase b;
+#pragma unroll
+	for (int k = 0; k < 4; k++)
+		b.p[k] = P + ((ph0 + k) & 3) * PH_A + PH_M0 + m0 + ((ph0 + k) >> 2);
+	return b;
+}
+
+// 16-lane (one DPP row) sum, result in every lane of the row
+__device__ __forceinline__ float row_sum(float v)
+{
+	v += dpp<DPP_QUAD_XOR1, 0xf>(v);
+	v += dpp<DPP_QUAD_XOR2, 0xf>(v);
+	v += dpp<DPP_HALF_MIRROR, 0xf>(v);
+	v += dpp<DPP_ROW_MIRROR, 0xf>(v);
+	return v;
+}
+
+template <bool CF32>
+__global__ void __launch_bounds__(TRX_WPB * WAVE, 3)
+burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__restrict__ params,
+		   trxhip_burst_result *__restrict__ results, float *__restrict__ soft,
+		   const trx_tables *__restrict__ tab, const float4 *__restrict__ ebp_in,
+		   unsigned n_bursts, int L, float thresh, float full_scale, int soft_stride, int slice)
+{
+	constexpr int NLD = 10;
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	const int lane = threadIdx.x & (WAVE - 1);
+	const int wave = threadIdx.x >> 6;
+	const int waves_per_block = blockDim.x >> 6;
+
+	// ---- LDS carve: [tables][per-wave slices]
+	float *sincv = reinterpret_cast<float *>(smem);                 // [4128] swizzled sinc LUT
+	float *dfilt = sincv + TRX_SINCV_LDS;                          // [65][20] fractional-delay filters + identity
+	c32 *rrot = reinterpret_cast<c32 *>(dfilt + K4_DROWS * TRX_DELAY_HLEN);   // [160] reverse rotation
+	float *gdec = reinterpret_cast<float *>(rrot + 160);           // [16] decimator taps
+	c32 *lseq = reinterpret_cast<c32 *>(gdec + 16);                // [376] training sequences
+	float *lhdr = reinterpret_cast<float *>(lseq + LSEQ_TAPS);     // [19][8] sequence headers
+	float *comp = lhdr + 8 * LSEQ_NHDR;                            // [65][36] composite delay-o-decimate filters
+	c32 *wbase = reinterpret_cast<c32 *>(smem + K4_TABLES_BYTES) + (size_t)wave * K4_SLICE;
+	c32 *const P = wbase;                                          // polyphase burst: P[r*PH_A + PH_M0 + m] = x[4m + r]
+	c32 *const dec = wbase + K4_XS;                                // 1-SPS (decimated) burst, zero tail
+	c32 *const cz = dec + TRX_DEC_LEN + TRX_CZ_PAD;                // zero-padded correlation
+	c32 *const edge = dec + TRX_DEC_LEN + TRX_CZ_LEN;              // [8] exactly recomputed edge outputs (fused demod)
+
+	// ---- one-time staging (workgroup-wide) of every table; zero this wave's slice (pads stay zero)
+	for (int i = threadIdx.x; i < TRX_SINCV_LDS; i += blockDim.x)
+		sincv[i] = (i < TRX_SINCV_LEN) ? tab->sincv[i] : 0.0f;
+	for (int i = threadIdx.x; i < K4_DROWS * TRX_DELAY_HLEN; i += blockDim.x)
+		dfilt[i] = (i < TRX_DELAY_FILTS * TRX_DELAY_HLEN) ? (&tab->delay_filt[0][0])[i]
+								  : ((i - TRX_DELAY_FILTS * TRX_DELAY_HLEN) == 9 ? 1.0f : 0.0f);
+	for (int i = threadIdx.x; i < K4_DROWS * 36; i += blockDim.x)
+		comp[i] = (&tab->comp_filt[0][0])[i];
+	for (int i = threadIdx.x; i < 160; i += blockDim.x)
+		rrot[i] = make_float2(tab->rrot1[i].re, tab->rrot1[i].im);
+	if (threadIdx.x < 16)
+		gdec[threadIdx.x] = tab->dec_taps[threadIdx.x];
+	for (int i = threadIdx.x; i < LSEQ_TAPS; i += blockDim.x) {
+		int s, k;
+		if (i < 128)      { s = TRX_SEQ_TSC0 + i / 16;          k = i % 16; }
+		else if (i < 248) { s = TRX_SEQ_RACH0 + (i - 128) / 40; k = (i - 128) % 40; }
+		else              { s = TRX_SEQ_EDGE0 + (i - 248) / 16; k = (i - 248) % 16; }
+		lseq[i] = make_float2(tab->seq[s].taps[k].re, tab->seq[s].taps[k].im);
+	}
+	for (int i = threadIdx.x; i < 8 * LSEQ_NHDR; i += blockDim.x) {
+		const int slot = i / 8;
+		const int s = (slot < 8) ? TRX_SEQ_TSC0 + slot : (slot < 11) ? TRX_SEQ_RACH0 + (slot - 8) : TRX_SEQ_EDGE0 + (slot - 11);
+		lhdr[i] = reinterpret_cast<const float *>(&tab->seq[s].gain)[i % 8];
+	}
+	for (int i = lane; i < K4_SLICE; i += WAVE)
+		wbase[i] = make_float2(0.0f, 0.0f);
+	__syncthreads();
+
+	const unsigned total_waves = gridDim.x * waves_per_block;
+	const unsigned first = blockIdx.x * waves_per_block + wave;
+
+	// Software prefetch of the next burst (see burst_pull_kernel)
+	uint32_t pre_i[NLD];
+	c32 pre_c[CF32 ? NLD : 1];
+	uint32_t pre_prm = 0u;
+	auto prefetch = [&](unsigned bb) {
+		pre_prm = reinterpret_cast<const uint32_t *>(params)[2 * (size_t)bb];
+		if (CF32) {
+			const c32 *src = reinterpret_cast<const c32 *>(iq_) + (size_t)bb * L;
+#pragma unroll
+			for (int r = 0; r < NLD; r++) {
+				const int i = r * WAVE + lane;
+				pre_c[r] = (r < NLD - 1 || i < L) ? src[i] : make_float2(0.0f, 0.0f);
+			}
+		} else {
+			const uint32_t *src = reinterpret_cast<const uint32_t *>(iq_) + (size_t)bb * L;
+#pragma unroll
+			for (int r = 0; r < NLD; r++) {
+				const int i = r * WAVE + lane;
+				pre_i[r] = (r < NLD - 1 || i < L) ? src[i] : 0u;
+			}
+		}
+	};
+	if (first < n_bursts)
+		prefetch(first);
+
+	// loader address: sample r*64 + lane -> phase lane&3, m = 16r + lane>>2
+	c32 *const pload = P + (lane & 3) * PH_A + PH_M0 + (lane >> 2);
+
+	for (unsigned b = first; b < n_bursts; b += total_waves) {
+		// Re-materialise the lane id per burst (2 VALU ops): otherwise every lane-derived address, tree-node
+		// offset and LUT base of every phase is hoisted out of this loop and kept live across it, which
+		// costs ~50 VGPRs and spills.
+		int lane;
+		asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+		const unsigned prm0 = (unsigned)uni((int)pre_prm);
+		const int type = prm0 & 0xff;
+		const int tsc = (prm0 >> 8) & 0xff;
+		const int max_toa = prm0 >> 16;
+
+		int rc = 0;
+		float toa = 0.0f, ci = 0.0f, energy = 0.0f, rssi = 0.0f;
+		c32 amp = make_float2(0.0f, 0.0f);
+		int out_tsc = 0, clip = 0, idle = 1, nbits = 0;
+		float *so = soft ? soft + (size_t)b * soft_stride : nullptr;
+
+		// ---- phase 0: registers -> fp32 polyphase LDS; clip scan and energyDetect partial sums on the fly
+		float amax = 0.0f, epart = 0.0f;
+#pragma unroll
+		for (int r = 0; r < NLD; r++) {
+			const int i = r * WAVE + lane;
+			if (r < NLD - 1 || i < L) {
+				c32 v;
+				if (CF32) v = pre_c[r];
+				else v = make_float2((float)(int16_t)(pre_i[r] & 0xffffu), (float)(int16_t)(pre_i[r] >> 16));
+				pload[16 * r] = v;
+				amax = fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y)));
+				if (r < 5)                                          // samples 4i, i < 80 (:1576-1584)
+					if ((lane & 3) == 0)
+						epart += norm2(v);
+			}
+		}
+		if (b + total_waves < n_bursts)
+			prefetch(b + total_waves);
+
+		if (type != TRXHIP_OFF) {                                   // Transceiver.cpp:704-707
+			amax = wave_max(amax);                                  // maxAmplitude(), :1711-1722
+			clip = amax > TRX_CLIP_THRESH;
+			energy = wave_sum(epart) / 80.0f;                       // energyDetect(burst, 20*sps)
+			if (!ABL(2))
+				rssi = 6.02059991f * __log2f(full_scale / sqrtf(energy));   // 20*log10(fs/avg), Transceiver.cpp:741,751
+			wave_sync();
+
+			if (ebp_in) {
+				const float4 e = ebp_in[b];
+				rc = (type == TRXHIP_OFF || type == TRXHIP_IDLE) ? 0 : type;
+				toa = unif(e.x);
+				amp = make_float2(unif(e.y), unif(e.z));
+				out_tsc = tsc;
+			} else if (type != TRXHIP_IDLE && !ABL(3)) {            // Transceiver.cpp:754-755
+				// ---- detectAnyBurst (:1926-1957): up to 3 candidate windows, first hit wins
+				int ncand = 0;
+				rc = 0;
+				if (max_toa > TRXHIP_MAX_TOA) {
+					rc = -TRXHIP_SIGERR_UNSUPPORTED;
+				} else if (type == TRXHIP_TSC || type == TRXHIP_EDGE) {
+					if (tsc > 7) rc = -TRXHIP_SIGERR_UNSUPPORTED;           // :1893, :1912
+					else ncand = (type == TRXHIP_EDGE) ? 2 : 1;                // EDGE falls through to TSC (:1933-1941)
+				} else if (type == TRXHIP_RACH || type == TRXHIP_EXT_RACH) {
+					ncand = (type == TRXHIP_EXT_RACH) ? 3 : 1;                 // :1791
+				}
+
+				int dec_lo = 1 << 30, dec_hi = 0;
+				int det_type = 0;
+				for (int c = 0; c < ncand; c++) {
+					int slot, target, head, tail, N;
+					if (type == TRXHIP_RACH || type == TRXHIP_EXT_RACH) {
+						slot = 8 + c; target = 48; head = 8; tail = 8 + max_toa; N = 40;       // :1788-1790
+					} else if (type == TRXHIP_EDGE && c == 0) {
+						slot = 11 + tsc; target = 82; head = 6; tail = 6 + max_toa; N = 16;    // :1915-1918
+					} else {
+						slot = tsc; target = 82; head = 10; tail = 6 + max_toa; N = 16;        // :1896-1899
+					}
+					const c32 *taps = lseq + ((slot < 8) ? LSEQ_TSC(slot) : (slot < 11) ? LSEQ_RACH(slot - 8) : LSEQ_EDGE(slot - 11));
+					const float *hdr = lhdr + 8 * slot;
+					const int start = target - head - 1;                   // :1752
+					const int len = head + tail;                           // :1753
+
+					// downsampleBurst (:1587-1601) restricted to what correlate/computeCI read:
+					// dec[i] = sum_k x[4i-15+k] * g[k];  x[4(i-4) + k'] with k' = k+1 -> phase k'&3, m = i-4 + k'>>2
+					int lo = start - (N - 1); if (lo < 0) lo = 0;
+					int hi = start + len;     if (hi > 156) hi = 156;
+					if (lo < dec_lo || hi > dec_hi) {
+						for (int i = lo + lane; i < hi; i += WAVE) {
+							const c32 *pd = P + PH_M0 + i - 4;
+							float yr = 0.0f, yi = 0.0f;
+#pragma unroll
+							for (int k = 0; k < 16; k++) {
+								const c32 x = pd[((k + 1) & 3) * PH_A + ((k + 1) >> 2)];
+								const float g = gdec[k];
+								yr += x.x * g;
+								yi += x.y * g;
+							}
+							dec[i] = make_float2(yr, yi);
+						}
+						dec_lo = lo; dec_hi = hi;
+						wave_sync();
+					}
+					float t; c32 a; float cc;
+					const int hit = detect_burst<true>(dec, 156, cz, taps, hdr, N, thresh, start, len, sincv, lane, &t, &a, &cc, slice);
+					wave_sync();
+					if (hit) {
+						rc = 1;
+						toa = t - (float)head;                             // :1768
+						amp = a;
+						ci = cc;
+						if (slot >= 8 && slot < 11) { out_tsc = slot - 8; det_type = type; }
+						else if (slot >= 11) { out_tsc = tsc; det_type = TRXHIP_EDGE; }
+						else { out_tsc = tsc; det_type = TRXHIP_TSC; }
+						break;
+					}
+				}
+				if (rc > 0) rc = det_type;                                  // :1953-1954
+				else if (rc == 0 && ncand > 0 && clip) rc = -TRXHIP_SIGERR_CLIP;   // :1764
+			}
+		}
+
+		// ---- demodAnyBurst -> demodGmskBurst (:2055-2072) ----
+		if (rc > 0 && rc != TRXHIP_EDGE && !ABL(0)) {
+			// demodCommon (:2030-2048): delayVector(burst, -toa*sps) -> scaleVector(1/amp) -> downsampleBurst
+			const float delay = -toa * 4.0f;
+			const int w = (int)floorf(delay);                              // integer shift: y[n] = fshift[n - w]
+			const float frac = delay - (float)w;
+			const bool use_filt = ((double)fabsf(frac) > 1e-2) && !ABL(4);  // :1056
+			const int fidx = uni(use_filt ? (int)floorf(frac * (float)TRX_DELAY_FILTS) : TRX_DELAY_FILTS);   // :1057; row 64 = identity
+			// (complex) 1.0 / amp = (1,0) * amp.inv()   (Complex.h:75,144-150)
+			const float an = norm2(amp);
+			const c32 ainv = make_float2(amp.x / an, -amp.y / an);
+			const c32 scale = cmul(make_float2(1.0f, 0.0f), ainv);
+			nbits = 148;
+			idle = 0;
+			const int nwrite = (slice & 1) ? 148 : 156;
+
+			// delayed samples n exist for n in [n_lo, n_hi]: n >= 0 (zero history in front of the decimator, :1590),
+			// 0 <= n - w < L (delayVector zero-fills what it shifts in, :1071-1090), n <= 623 (:78)
+			const int n_lo = w > 0 ? w : 0;
+			const int n_hi = (L - 1 + w < 623) ? L - 1 + w : 623;
+
+			float hh[TRX_DELAY_HLEN];                                      // delay filter taps (LDS broadcast reads)
+			{
+				const float4 *hf4 = reinterpret_cast<const float4 *>(dfilt + fidx * TRX_DELAY_HLEN);
+#pragma unroll
+				for (int q = 0; q < TRX_DELAY_HLEN / 4; q++) {
+					const float4 h4 = hf4[q];
+					hh[4 * q + 0] = h4.x; hh[4 * q + 1] = h4.y; hh[4 * q + 2] = h4.z; hh[4 * q + 3] = h4.w;
+				}
+			}
+
+			if (slice & TRXHIP_FLAG_EXACT_DEMOD) {
+				// ================= EXACT: two FIR stages in the reference's operand order =================
+				constexpr int R = 12;                                       // outputs per lane: 12*l .. 12*l+11 (52 lanes)
+				const int c0 = -w - 9;                                      // sample of tap 0 of output n: n + c0
+				int lc = lane;
+				const int lc_min = cdiv(-36 - c0, 12), lc_max = fdiv(L + 6 - c0, 12);
+				if (lc < lc_min) lc = lc_min;
+				if (lc > lc_max) lc = lc_max;
+				const PhBase pb = ph_bases(P, c0 & 3, 3 * lc + (c0 >> 2));
+				c32 yv[R];
+				{
+					// fshift[m] = sum_k X(m - 9 + k) * h[k]  (convolve NO_DELAY, 20 real taps; :1060): tap-outer /
+					// output-inner with a sliding window; each output still accumulates k = 0..19 in order
+					constexpr int D = 3;
+					c32 xr[R + 19];
+#pragma unroll
+					for (int j = 0; j < R; j++)
+						yv[j] = make_float2(0.0f, 0.0f);
+#pragma unroll
+					for (int j = 0; j < R - 1 + D; j++)
+						xr[j] = pb.p[j & 3][j >> 2];
+#pragma unroll
+					for (int k = 0; k < 20; k++) {
+						const float h = hh[k];
+						if (R - 1 + D + k < R + 19)
+							xr[R - 1 + D + k] = pb.p[(R - 1 + D + k) & 3][(R - 1 + D + k) >> 2];
+#pragma unroll
+						for (int j = 0; j < R; j++) {
+							yv[j].x += xr[j + k].x * h;
+							yv[j].y += xr[j + k].y * h;
+						}
+						__builtin_amdgcn_sched_barrier(0);
+					}
+				}
+#pragma unroll
+				for (int j = 0; j < R; j++) {
+					const int m = 12 * lane - w + j;
+					const bool ok = (lc == lane) && ((unsigned)m < (unsigned)L);
+					const c32 v = ok ? yv[j] : make_float2(0.0f, 0.0f);
+					yv[j] = cmul(v, scale);                                 // scaleVector (:1198-1205)
+				}
+				wave_sync();                 // every lane has read its inputs: safe to overwrite in place
+				if (lane < 52) {
+#pragma unroll
+					for (int j = 0; j < R; j++)                             // y[12l + j] -> phase j&3, m = 3l + j>>2
+						P[(j & 3) * PH_A + PH_M0 + 3 * lane + (j >> 2)] = yv[j];
+				}
+				wave_sync();
+
+				if (so) {
+					for (int i = lane; i < soft_stride; i += WAVE) {
+						float sv = 0.0f;
+						if (i < nwrite && !ABL(5)) {
+							const c32 *pd = P + PH_M0 + i - 4;
+							float yr = 0.0f, yi = 0.0f;
+#pragma unroll
+							for (int k = 0; k < 16; k++) {
+								const c32 x = pd[((k + 1) & 3) * PH_A + ((k + 1) >> 2)];
+								const float g = gdec[k];
+								yr += x.x * g;
+								yi += x.y * g;
+							}
+							const c32 r = rrot[i];
+							sv = r.x * yr - r.y * yi;                       // real(rot * x)  (:2066-2068)
+							if (slice & 1)
+								sv = __builtin_amdgcn_fmed3f(0.5f * (sv + 1.0f), 0.0f, 1.0f);
+						}
+						so[i] = sv;
+					}
+				}
+				wave_sync();
+			} else {
+				// ================= FUSED: one 35-tap composite filter at the symbol instants =================
+				// dec[i] = scale * sum_u comp[u] * X(4i - 24 - w + u) for outputs whose 16 decimator inputs all exist
+				const int i_full_lo = cdiv(n_lo + 15, 4), i_full_hi = fdiv(n_hi, 4);
+				const int i0l = cdiv(n_lo, 4);                              // low-side partial outputs: [i0l, i_full_lo)
+				const int i0h = i_full_hi + 1;                              // high-side partial outputs: [i0h, fdiv(n_hi+15,4)]
+				const bool need_lo = (n_hi >= n_lo) && (i0l < i_full_lo) && (i0l < nwrite);
+				const bool need_hi = (n_hi >= n_lo) && (i0h <= fdiv(n_hi + 15, 4)) && (i0h < nwrite);
+
+				// exact masked two-stage sum for 4 consecutive outputs i0..i0+3: lane = 16*e + t computes
+				// g[t] * fshift[n - w] for n = 4(i0+e) - 15 + t if that sample exists, one DPP row sums over t
+				auto edge_round = [&](int i0, int slot) {
+					const int e = lane >> 4, t = lane & 15;
+					const int n = 4 * (i0 + e) - 15 + t;
+					const bool ok = (n >= n_lo) && (n <= n_hi);
+					const int s0 = n - w - 9;
+					int m0 = s0 >> 2;
+					if (m0 < -9) m0 = -9;
+					if (m0 > 158) m0 = 158;
+					const PhBase pb = ph_bases(P, s0 & 3, m0);
+					v2f acc0 = { 0.0f, 0.0f }, acc1 = { 0.0f, 0.0f };     // two chains: even / odd taps
+#pragma unroll
+					for (int k0 = 0; k0 < TRX_DELAY_HLEN; k0 += 10) {
+						c32 x[10];
+#pragma unroll
+						for (int q = 0; q < 10; q++)
+							x[q] = pb.p[(k0 + q) & 3][(k0 + q) >> 2];
+#pragma unroll
+						for (int q = 0; q < 10; q += 2) {
+							acc0 = __builtin_elementwise_fma((v2f){ x[q].x, x[q].y }, (v2f){ hh[k0 + q], hh[k0 + q] }, acc0);
+							acc1 = __builtin_elementwise_fma((v2f){ x[q + 1].x, x[q + 1].y }, (v2f){ hh[k0 + q + 1], hh[k0 + q + 1] }, acc1);
+						}
+						__builtin_amdgcn_sched_barrier(0);
+					}
+					const v2f acc = acc0 + acc1;
+					const float g = ok ? gdec[t] : 0.0f;
+					const float sr = row_sum(acc.x * g), si = row_sum(acc.y * g);
+					if (t == 0)
+						edge[slot + e] = cmul(make_float2(sr, si), scale);
+				};
+				if (need_lo) edge_round(i0l, 0);
+				if (need_hi) edge_round(i0h, 4);
+
+				const float4 *c4 = reinterpret_cast<const float4 *>(comp + fidx * 36);   // 35 taps, LDS broadcast reads
+				const int c = -24 - w;
+				const int i_min = cdiv(-36 - c, 4), i_max = fdiv(L + 1 - c, 4);
+				wave_sync();
+				if (so) {
+					// three output rounds (i = lane, lane+64, lane+128) advance together: three independent FMA
+					// chains per lane hide the LDS and FMA latency, and the 35 taps are fetched once
+					constexpr int NR = 3;
+					PhBase pbr[NR];
+					v2f acc[NR];
+#pragma unroll
+					for (int r = 0; r < NR; r++) {
+						int ic = lane + r * WAVE;
+						if (ic < i_min) ic = i_min;
+						if (ic > i_max) ic = i_max;
+						pbr[r] = ph_bases(P, c & 3, ic + (c >> 2));
+						acc[r] = (v2f){ 0.0f, 0.0f };
+					}
+					if (!ABL(5)) {
+#pragma unroll
+						for (int u0 = 0; u0 < 36; u0 += 4) {                    // chunks of 4 taps (tap 35 is a zero pad)
+							const float4 ca = c4[u0 / 4];
+							const float cf[4] = { ca.x, ca.y, ca.z, ca.w };
+							c32 x[NR][4];
+#pragma unroll
+							for (int q = 0; q < 4; q++)
+#pragma unroll
+								for (int r = 0; r < NR; r++)
+									x[r][q] = pbr[r].p[(u0 + q) & 3][(u0 + q) >> 2];   // tap 35: coefficient 0, sample in range
+#pragma unroll
+							for (int q = 0; q < 4; q++) {
+								const v2f hv = { cf[q], cf[q] };
+#pragma unroll
+								for (int r = 0; r < NR; r++) {
+									const v2f xv = { x[r][q].x, x[r][q].y };
+									acc[r] = __builtin_elementwise_fma(xv, hv, acc[r]);
+								}
+							}
+							__builtin_amdgcn_sched_barrier(0);
+						}
+					}
+					// pin the three sums here: without it LLVM sinks all 105 FMAs below the per-output predicates
+					// and keeps every LDS operand alive (170 spilled VGPRs)
+#pragma unroll
+					for (int r = 0; r < NR; r++)
+						asm volatile("" : "+v"(acc[r]));
+#pragma unroll
+					for (int r = 0; r < NR; r++) {
+						const int i = lane + r * WAVE;
+						if (i < soft_stride) {
+							float sv = 0.0f;
+							if (i < nwrite) {
+								const bool full = (i >= i_full_lo) && (i <= i_full_hi);
+								c32 d = full ? cmul(make_float2(acc[r].x, acc[r].y), scale) : make_float2(0.0f, 0.0f);
+								if (need_lo && (unsigned)(i - i0l) < 4u) d = edge[i - i0l];
+								if (need_hi && (unsigned)(i - i0h) < 4u) d = edge[4 + i - i0h];
+								const c32 rr = rrot[i];
+								sv = rr.x * d.x - rr.y * d.y;                   // real(rot * x)  (:2066-2068)
+								if (slice & 1)
+									sv = __builtin_amdgcn_fmed3f(0.5f * (sv + 1.0f), 0.0f, 1.0f);
+							}
+							so[i] = sv;
+						}
+					}
+					for (int i = lane + NR * WAVE; i < soft_stride; i += WAVE)     // soft_stride > 192: zero tail
+						so[i] = 0.0f;
+				}
+				wave_sync();
+			}
+		} else {
+			if (rc == TRXHIP_EDGE) {
+				// 8-PSK demodulation is not built yet: report detection only
+				nbits = 0;
+				idle = 0;
+			}
+			if (so)
+				for (int i = lane; i < soft_stride; i += WAVE)
+					so[i] = 0.0f;
+		}
+
+		// ---- result record: 32 bytes, one dword per lane 0..7
+		if (lane < 8) {
+			const bool det = rc > 0;
+			uint32_t word = (uint32_t)rc;
+			word = (lane == 1) ? __float_as_uint(det ? toa : 0.0f) : word;
+			word = (lane == 2) ? __float_as_uint(det ? amp.x : 0.0f) : word;
+			word = (lane == 3) ? __float_as_uint(det ? amp.y : 0.0f) : word;
+			word = (lane == 4) ? __float_as_uint(det ? ci : 0.0f) : word;
+			word = (lane == 5) ? __float_as_uint(energy) : word;
+			word = (lane == 6) ? __float_as_uint(rssi) : word;
+			word = (lane == 7) ? ((uint32_t)(det ? out_tsc : 0) | ((uint32_t)clip << 8) | ((uint32_t)idle << 16) |
+					      ((uint32_t)(nbits / 4) << 24)) : word;
+			reinterpret_cast<uint32_t *>(results + b)[lane] = word;
+		}
+	}
+}
+
+extern "C" int trx_launch_pull4(const void *d_iq, int cf32, const trxhip_burst_params *d_params,
+				trxhip_burst_result *d_results, float *d_soft, const trx_tables *d_tab, const float *d_ebp_in,
+				size_t n_bursts, int L, float thresh, float full_scale, int soft_stride, int flags, int n_cu,
+				hipStream_t stream)
+{
+	if (n_bursts == 0)
+		return 0;
+	const int wpb = TRX_WPB;
+	const size_t lds = K4_TABLES_BYTES + (size_t)wpb * K4_SLICE * sizeof(c32);
+	size_t need = (n_bursts + wpb - 1) / wpb;
+	size_t grid = (size_t)n_cu;
+	if (grid > need) grid = need;
+#define LAUNCH4(CF_)                                                                                            \
+	do {                                                                                                    \
+		auto k = burst_pull4_kernel<CF_>;                                                               \
+		if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+			return TRXHIP_EIO;                                                                      \
+		hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(wpb * WAVE), lds, stream, d_iq, d_params, d_results, \
+				   d_soft, d_tab, reinterpret_cast<const float4 *>(d_ebp_in), (unsigned)n_bursts, L, thresh, \
+				   full_scale, soft_stride, flags);                                             \
+	} while (0)
+	if (cf32) LAUNCH4(true); else LAUNCH4(false);
+#undef LAUNCH4
+	return hipGetLastError() == hipSuccess ? 0 : TRXHIP_EIO;
+}

@@ -29,336 +29,7 @@
 // the file is compiled with -ffp-contract=off, so rc / TOA / amp / soft bits are bit-identical to the
 // generic-C reference.  Only energyDetect (tree-summed), log2f (C/I) and log10f (RSSI) differ at the
 // 1e-6 level.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <stdlib.h>
-
-#include "trx_tables.h"
-#include "../../include/trxhip.h"
-
-#define WAVE 64
-#define TRX_PAD 20                 // zero samples kept on both sides of a burst in LDS
-#define TRX_DEC_LEN 208            // decimated burst: 156 samples + zero tail up to start+len (<= 199)
-#define TRX_CORR_MAX 128           // head + tail <= 16 + TRXHIP_MAX_TOA
-#define TRX_CZ_PAD 12              // zero samples either side of the correlation (interpolatePoint reach)
-#define TRX_CZ_LEN (TRX_CZ_PAD + TRX_CORR_MAX + TRX_CZ_PAD)
-#define TRX_SINCV_LDS (TRX_SINCV_LEN + 32)   // + zero tail: q = 4096 is addressed when the fraction is 0
-#define TRX_CLIP_THRESH 30000.0f   // sigProcLib.cpp:49
-#define TRX_WPB 12                 // waves (= bursts in flight) per workgroup; one workgroup per CU
-
-// LDS-resident sequence table: [8 TSC x 16][3 RACH x 40][8 EDGE x 16] taps, then 19 headers of 8 floats
-#define LSEQ_TSC(s)   ((s) * 16)
-#define LSEQ_RACH(i)  (128 + (i) * 40)
-#define LSEQ_EDGE(s)  (248 + (s) * 16)
-#define LSEQ_TAPS     376
-#define LSEQ_NHDR     19
-#define TRX_TABLES_LDS_FLOATS (TRX_SINCV_LDS + TRX_DELAY_FILTS * TRX_DELAY_HLEN + 2 * 160 + 16 + 2 * LSEQ_TAPS + 8 * LSEQ_NHDR)
-#define TRX_TABLES_LDS_BYTES (TRX_TABLES_LDS_FLOATS * 4)
-
-typedef float2 c32;
-
-// Diagnostic build only (-DTRX_DIAG, libtrxhip_diag.so): the upper bits of `slice` carry a phase-ablation
-// mask so that per-phase cost can be measured on the GPU.  The product library is built without it.
-#ifdef TRX_DIAG
-#define ABL(bit) ((slice >> (8 + (bit))) & 1)
-#else
-#define ABL(bit) 0
-#endif
-
-// ------------------------------------------------------------------------------------------------
-// wave-level helpers
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wave_sync()
-{
-	// all 64 lanes of a wave execute LDS instructions in order: a compiler-level fence is enough to
-	// make this wave's earlier LDS writes visible to its later reads from other lanes.
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-	__builtin_amdgcn_wave_barrier();
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ float unif(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
-// value held by lane `l` (l wave-uniform): v_readlane_b32
-__device__ __forceinline__ float lane_val(float v, int l)
-{
-	return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), __builtin_amdgcn_readfirstlane(l)));
-}
-
-// DPP move: lanes without a valid source keep their own value
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp(float v)
-{
-	return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
-}
-#define DPP_QUAD_XOR1   0xB1   // quad_perm:[1,0,3,2]
-#define DPP_QUAD_XOR2   0x4E   // quad_perm:[2,3,0,1]
-#define DPP_HALF_MIRROR 0x141
-#define DPP_ROW_MIRROR  0x140
-#define DPP_BCAST15     0x142
-#define DPP_BCAST31     0x143
-
-// wave-wide max / sum in 6 DPP-fed VALU ops; result taken from lane 63
-__device__ __forceinline__ float wave_max(float v)
-{
-	v = fmaxf(v, dpp<DPP_QUAD_XOR1, 0xf>(v));
-	v = fmaxf(v, dpp<DPP_QUAD_XOR2, 0xf>(v));
-	v = fmaxf(v, dpp<DPP_HALF_MIRROR, 0xf>(v));
-	v = fmaxf(v, dpp<DPP_ROW_MIRROR, 0xf>(v));
-	v = fmaxf(v, dpp<DPP_BCAST15, 0xa>(v));
-	v = fmaxf(v, dpp<DPP_BCAST31, 0xc>(v));
-	return lane_val(v, 63);
-}
-
-__device__ __forceinline__ float wave_sum(float v)
-{
-	v += dpp<DPP_QUAD_XOR1, 0xf>(v);
-	v += dpp<DPP_QUAD_XOR2, 0xf>(v);
-	v += dpp<DPP_HALF_MIRROR, 0xf>(v);
-	v += dpp<DPP_ROW_MIRROR, 0xf>(v);
-	{
-		// rows 1,3 += row 0,2 totals; rows 2,3 += (rows 0+1) total.  Masked-out rows must add 0.
-		const float t = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_BCAST15, 0xa, 0xf, false));
-		v += t;
-		const float u = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_BCAST31, 0xc, 0xf, false));
-		v += u;
-	}
-	return lane_val(v, 63);
-}
-
-// Complex.h:113 norm2(): i*i + r*r
-__device__ __forceinline__ float norm2(c32 v) { return v.y * v.y + v.x * v.x; }
-// Complex.h:74 operator*(Complex)
-__device__ __forceinline__ c32 cmul(c32 a, c32 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-
-// ------------------------------------------------------------------------------------------------
-// interpolatePoint() for one candidate position per lane (sigProcLib.cpp:1100-1118)
-//   cz    = zero-padded correlation in LDS: cz[i] = corr[i] for 0 <= i < size-1, 0 elsewhere in
-//           [-TRX_CZ_PAD, size + TRX_CZ_PAD).  The reference sums i in [max(0,fl-10), min(size-1,fl+11)):
-//           note the last sample (size-1) is never used (":1105 end = size-1; i < end"), hence zeroed.
-//   ix512 = position in 1/512 symbol units (multiples of 1/512 are all peakDetect() ever asks for)
-//   sincv = swizzled LDS table, sincv[swz(q)] = sinc(M_PI_F * q/512), 0 for q >= 4096
-// Of the 21 taps only i = fl-7 .. fl+8 can be non-zero (|i - ix| < 8, the LUT is 0 beyond 8*pi);
-// dropping the others only drops additions of +-0.  q = |i*512 - ix512| is affine in the tap index on
-// either side of the peak, so the LUT address is one per-lane base plus a compile-time offset.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ c32 interp_point(const c32 *cz, int ix512, const float *sincv)
-{
-	const int fl = ix512 >> 9;                       // floor(ix)
-	const int f = ix512 & 511;                       // fractional part * 512
-	const int fs = trx_sincv_swz(f);                 // taps i <= fl : q = 512*(fl-i) + f
-	const int g = 512 - f;                           // taps i >  fl : q = 512*(i-fl-1) + (512 - f)
-	const int gs = (f == 0) ? 512 : trx_sincv_swz(g);
-	const c32 *c = cz + (fl - 7);
-	const float *sa = sincv + fs;
-	const float *sb = sincv + gs;
-	c32 p = make_float2(0.0f, 0.0f);
-#pragma unroll
-	for (int u = 0; u < 8; u++) {                    // i = fl-7 .. fl   (k = 7 .. 0)
-		const c32 v = c[u];
-		const float w = sa[512 * (7 - u)];
-		p.x += v.x * w;
-		p.y += v.y * w;
-	}
-#pragma unroll
-	for (int u = 0; u < 8; u++) {                    // i = fl+1 .. fl+8 (k = 0 .. 7)
-		const c32 v = c[8 + u];
-		const float w = sb[512 * u];
-		p.x += v.x * w;
-		p.y += v.y * w;
-	}
-	return p;
-}
-
-// earlyIndex offset (1/512 units) of heap node n of a bisection subtree whose first step is `inc0`:
-// node n = (1<<L) + p - 1 at level L with path bits p (MSB first, 1 = "+incr"):
-//   off = sum_{j<L} (+-)(inc0 >> j) = ((4*p*inc0) >> L) - (2*inc0 - ((2*inc0) >> L))
-__device__ __forceinline__ int node_offset(int n, int inc0)
-{
-	const int L = 31 - __clz(n + 1);
-	const int p = n + 1 - (1 << L);
-	return ((4 * p * inc0) >> L) - (2 * inc0 - ((2 * inc0) >> L));
-}
-
-// One round of the speculative bisection: lanes 2n / 2n+1 hold |interp(early)|^2 / |interp(late)|^2 of
-// heap node n.  Each even lane compares with its odd neighbour (one DPP move); the two v_cmp results are
-// ballots the scalar unit walks: no further vector work.  Returns the accumulated step; sets `tie` at
-// ":1170 else break".
-template <int LEVELS>
-__device__ __forceinline__ int walk_tree(float nv, int inc0, bool &tie)
-{
-	const float other = dpp<DPP_QUAD_XOR1, 0xf>(nv);               // even lane <- late, odd lane <- early
-	const unsigned long long lt = __ballot(nv < other);            // even bits: early < late
-	const unsigned long long gt = __ballot(nv > other);            // even bits: early > late
-	int node = 0, off = 0;
-#pragma unroll
-	for (int Lw = 0; Lw < LEVELS; Lw++) {
-		if (!tie) {
-			const int bit = 2 * node;
-			if ((lt >> bit) & 1ull)      { off += (inc0 >> Lw); node = 2 * node + 2; }
-			else if ((gt >> bit) & 1ull) { off -= (inc0 >> Lw); node = 2 * node + 1; }
-			else tie = true;
-		}
-	}
-	return off;
-}
-
-// ------------------------------------------------------------------------------------------------
-// peakDetect() (sigProcLib.cpp:1141-1186) with the early/late bisection expanded across lanes.
-// All lanes return the same (toa512, value).
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void peak_detect_spec(const c32 *cz, int max_idx, const float *sincv,
-						  int lane, int *toa512_out, c32 *val_out)
-{
-	int E = (max_idx - 1) * 512;                     // earlyIndex * 512
-	bool tie = false;
-
-	// ---- round A: levels 0..4 (incr = 1/2 .. 1/32): heap node n on lanes 2n (early) and 2n+1 (late)
-	{
-		const int ix = E + node_offset(lane >> 1, 256) + ((lane & 1) ? 1024 : 0);
-		const float nv = norm2(interp_point(cz, ix, sincv));     // lanes 62,63 evaluate a harmless extra node
-		E += walk_tree<5>(nv, 256, tie);
-	}
-	int final_ix;
-	c32 val;
-	if (!tie) {
-		// ---- round B: levels 5..8 (incr = 1/64 .. 1/512) on lanes 0..29, the 16 possible final
-		// positions (earlyIndex + 1) on lanes 32..47
-		int ix;
-		if (lane < 32)
-			ix = E + node_offset(lane >> 1, 8) + ((lane & 1) ? 1024 : 0);
-		else
-			ix = E + (2 * (lane & 15) - 15) + 512;
-		const c32 pv = interp_point(cz, ix, sincv);
-		const float nv = norm2(pv);
-		const int offB = walk_tree<4>(nv, 8, tie);
-		E += offB;
-		final_ix = E + 512;
-		const int src = 32 + ((offB + 15) >> 1);     // lane that evaluated this final position
-		val.x = lane_val(pv.x, src);
-		val.y = lane_val(pv.y, src);
-	}
-	if (tie) {                                        // rare: equal early/late power -> loop left early
-		final_ix = E + 512;
-		val = interp_point(cz, final_ix, sincv);
-	}
-	*toa512_out = final_ix;
-	*val_out = val;
-}
-
-// ------------------------------------------------------------------------------------------------
-// detectBurst() on the 1-SPS signal `sig` (sigProcLib.cpp:1649-1709); correlation kept in LDS (cz).
-//   PADDED: sig is readable (zero) over the whole correlation window, no range checks (4 SPS: dec[])
-//   taps  : LDS, wave-uniform -> broadcast reads; hdr: {gain.re, gain.im, ginv.re, ginv.im, ci_den, toa}
-// Returns rc (1 / 0); on 1 fills toa (symbols, before "- head"), amp, ci.  Wave-uniform.
-// ------------------------------------------------------------------------------------------------
-template <bool PADDED>
-__device__ __forceinline__ int detect_burst(const c32 *sig, int sig_len, c32 *cz, const c32 *taps, const float *hdr,
-					     int N, float thresh, int start, int len, const float *sincv, int lane,
-					     float *toa_out, c32 *amp_out, float *ci_out, int slice)
-{
-	// ---- correlate: corr[i] = sum_k SIG(i + start - (N-1) + k) * seq[k]   (:1674, convolve_base.c:72-85)
-	// N is 16 (TSC/EDGE) or 40 (RACH): tap loop unrolled by 8 so the LDS reads pipeline
-	float best = 0.0f;                               // fastPeakDetect state, fused into the same pass
-	int bidx = -1;
-	for (int i = lane; i < len; i += WAVE) {
-		float yr = 0.0f, yi = 0.0f;
-		const int base = i + start - (N - 1);
-		for (int k0 = 0; k0 < N; k0 += 8) {
-			c32 x[8];
-#pragma unroll
-			for (int u = 0; u < 8; u++) {
-				const int j = base + k0 + u;
-				if (PADDED) x[u] = sig[j];
-				else x[u] = (j >= 0 && j < sig_len) ? sig[j] : make_float2(0.0f, 0.0f);
-			}
-#pragma unroll
-			for (int u = 0; u < 8; u++) {
-				const c32 h = taps[k0 + u];
-				yr += x[u].x * h.x - x[u].y * h.y;
-				yi += x[u].x * h.y + x[u].y * h.x;
-			}
-		}
-		const c32 y = make_float2(yr, yi);
-		cz[i] = y;
-		// fastPeakDetect (:1120-1139): first strict maximum of |corr|^2 (per lane: i ascending)
-		const float v = norm2(y);
-		if (v > best) { best = v; bidx = i; }
-	}
-	if (lane < TRX_CZ_PAD)
-		cz[len + lane] = make_float2(0.0f, 0.0f);    // right zero pad (len varies per burst)
-
-	// arg-max across lanes: wave max (DPP), then the lowest index holding it (ballot + scalar ff1)
-	const float m = wave_max(best);
-	if (!(m > 0.0f))
-		return 0;                                    // toa = -1 < 3
-	{
-		const unsigned long long hit = __ballot(best == m);
-		const unsigned long long hit_lo = __ballot(best == m && bidx == lane);
-		bidx = hit_lo ? (__ffsll((unsigned long long)hit_lo) - 1) : (64 + __ffsll((unsigned long long)hit) - 1);
-	}
-	if ((bidx < 3) || (bidx > len - 3))               // :1683
-		return 0;
-	wave_sync();
-	const c32 amp0 = cz[bidx];
-
-	// ---- computePeakRatio (:1541-1571): terms in the reference's order; out-of-range terms read the
-	// zero pads (adding +0 is exact), their count is arithmetic
-	{
-		float avg = 0.0f;
-		int num = 0;
-#pragma unroll
-		for (int i = 2; i <= 5; i++) {
-			avg += norm2(cz[bidx - i]);
-			avg += norm2(cz[bidx + i]);              // bidx + i >= len reads zeros (pad = 12 > 5)
-			num += (bidx - i >= 0) + (bidx + i < len);
-		}
-		if (num < 5)
-			return 0;
-		const float rms = (float)((double)sqrtf(avg / (float)num) + 0.00001);
-		const float ratio = sqrtf(norm2(amp0)) / rms;
-		if (ratio < thresh)
-			return 0;
-	}
-
-	// ---- peakDetect (:1695): refined TOA (multiple of 1/512) and interpolated correlation value
-	int toa512;
-	c32 xcorr;
-	// interpolatePoint() never reads the last correlation sample (:1105, :1109): zero it in the padded copy
-	if (lane == 0)
-		cz[len - 1] = make_float2(0.0f, 0.0f);
-	wave_sync();
-	if (ABL(1)) { toa512 = bidx * 512; xcorr = amp0; }
-	else
-		peak_detect_spec(cz, bidx, sincv, lane, &toa512, &xcorr);
-	toa512 = uni(toa512);
-	xcorr.x = unif(xcorr.x);
-	xcorr.y = unif(xcorr.y);
-	const float toa = (float)toa512 * (1.0f / 512.0f);   // exact
-
-	// ---- computeCI (:1608-1639)
-	float ci = 0.0f;
-	{
-		// roundf(toa): toa is k/512 -> round half away from zero on integers
-		const int rt = (toa512 >= 0) ? ((toa512 + 256) >> 9) : -((-toa512 + 256) >> 9);
-		const int ps = start + 1 - N + rt;
-		if (ps >= 0 && ps + N <= sig_len) {
-			// S = sum_i |sig[ps+i]|^2 in index order: lane i squares one sample, the sum walks the lanes
-			const float pw = norm2(sig[ps + (lane < N ? lane : 0)]);
-			float S = 0.0f;
-			for (int i = 0; i < N; i++)
-				S += lane_val(pw, i);
-			S /= (float)N;
-			const float C = norm2(xcorr) / hdr[4];
-			ci = 3.0103f * log2f(C / (S - C));
-		}
-	}
-
-	*amp_out = cmul(xcorr, make_float2(hdr[2], hdr[3]));   // xcorr / sync->gain  (:1701)
-	*toa_out = toa - hdr[5];                                 // :1704
-	*ci_out = ci;
-	return 1;
-}
+#include "trx_device.h"
 
 // ------------------------------------------------------------------------------------------------
 // the hot kernel
@@ -738,6 +409,11 @@ extern "C" size_t trx_pull_lds_bytes(int L, int waves_per_block)
 	return TRX_TABLES_LDS_BYTES + (size_t)waves_per_block * slice_c32 * sizeof(c32);
 }
 
+extern "C" int trx_launch_pull4(const void *d_iq, int cf32, const trxhip_burst_params *d_params,
+				trxhip_burst_result *d_results, float *d_soft, const trx_tables *d_tab, const float *d_ebp_in,
+				size_t n_bursts, int L, float thresh, float full_scale, int soft_stride, int flags, int n_cu,
+				hipStream_t stream);
+
 extern "C" int trx_launch_pull(const void *d_iq, int cf32, const trxhip_burst_params *d_params,
 			       trxhip_burst_result *d_results, float *d_soft, const trx_tables *d_tab, const float *d_ebp_in,
 			       size_t n_bursts, int L, int sps, float thresh, float full_scale,
@@ -745,6 +421,10 @@ extern "C" int trx_launch_pull(const void *d_iq, int cf32, const trxhip_burst_pa
 {
 	if (n_bursts == 0)
 		return 0;
+	// the transceiver's 4-SPS burst size gets the production kernel (polyphase LDS layout, fused or exact demod)
+	if (sps == 4 && L >= 624 && L <= 628)
+		return trx_launch_pull4(d_iq, cf32, d_params, d_results, d_soft, d_tab, d_ebp_in, n_bursts, L, thresh, full_scale,
+					soft_stride, slice, n_cu, stream);
 	// as many waves per workgroup as the 160 KB of LDS admit (12 at L = 625), one workgroup per CU
 	int wpb = TRX_WPB;
 	while (wpb > 1 && trx_pull_lds_bytes(L, wpb) > 160 * 1024)

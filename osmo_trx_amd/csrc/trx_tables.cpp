@@ -85,6 +85,7 @@ public:
 		static const double inv[5] = { 0.15884, -0.43176, 1.00000, -0.42608, 0.14882 };   // :414-419
 		for (int i = 0; i < 5; i++) t_->c0_inv[i] = (float)inv[i];
 		sincv_table();
+		composite_filters();
 	}
 
 private:
@@ -365,6 +366,25 @@ private:
 		for (size_t i = 0; i < h_len; i++)
 			for (size_t n = 0; n < m; n++)
 				t_->chan_taps[n][h_len - 1 - i] = proto[i * m + n] * scale;
+	}
+
+	// Derived table for the fused demodulator: delayVector's 20-tap filter followed by the 16-tap /4 decimator
+	// (sigProcLib.cpp:1060 then :1587-1601) is one 35-tap filter per delay index.  Products in double, rounded once.
+	void composite_filters()
+	{
+		for (int f = 0; f <= TRX_DELAY_FILTS; f++) {
+			for (int u = 0; u < 36; u++) {
+				double acc = 0.0;
+				for (int t = 0; t < 16; t++) {
+					const int k = u - t;
+					if (k < 0 || k >= TRX_DELAY_HLEN)
+						continue;
+					const double h = (f < TRX_DELAY_FILTS) ? (double)t_->delay_filt[f][k] : (k == 9 ? 1.0 : 0.0);
+					acc += (double)t_->dec_taps[t] * h;
+				}
+				t_->comp_filt[f][u] = (u < 35) ? (float)acc : 0.0f;
+			}
+		}
 	}
 
 	// Every sinc() value interpolatePoint() can ask for: positions are multiples of 1/512, so

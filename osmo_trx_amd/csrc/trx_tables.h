@@ -48,10 +48,13 @@ struct trx_tables {
 	float    sincv[TRX_SINCV_LEN];                      // index q ^ ((q >> 4) & 31)
 	float    chan_taps[4][16];                          // Channelizer(4,*,16) sub-filters (reversed)
 	float    rs6548_taps[65][16];                       // Resampler(65,48) partitions (reversed)
+	// composite of fractional-delay filter f and the /4 decimator (fused demod): comp[f][u] = sum_{t+k=u} g[t]*h_f[k],
+	// u < 35; row 64 = no fractional filter (|frac| <= 0.01, sigProcLib.cpp:1056): g shifted by 9
+	float    comp_filt[TRX_DELAY_FILTS + 1][36];
 };
 
 #define TRX_TABLES_MAGIC   0x54585254u
-#define TRX_TABLES_VERSION 1u
+#define TRX_TABLES_VERSION 2u
 
 // XOR swizzle of the sincv index: conflict-free LDS gathers both for lanes whose positions differ
 // by multiples of 16/512 (coarse bisection levels) and by 1/512 steps (fine levels).

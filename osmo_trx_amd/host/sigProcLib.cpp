@@ -154,7 +154,8 @@ int detectAnyBurst(const signalVector &burst, unsigned tsc, float threshold, int
 	if (!h2d(t.d_iq, burst.begin(), burst.bytes(), t.stream) || !h2d(t.d_prm, &prm, sizeof(prm), t.stream))
 		return -SIGERR_INTERNAL;
 	int rc = trxhip_detect_demod_batch_cf32(g_ctx, static_cast<const float *>(t.d_iq), t.d_prm, t.d_res, t.d_soft, 1,
-						(int)n, sps, threshold, 1.0f, (int)stride, 0 /* raw soft bits */, t.stream);
+						(int)n, sps, threshold, 1.0f, (int)stride,
+						TRXHIP_FLAG_EXACT_DEMOD /* raw soft bits, reference operand order */, t.stream);
 	if (rc != TRXHIP_OK || !d2h(&res, t.d_res, sizeof(res), t.stream) ||
 	    !d2h(t.last_soft.data(), t.d_soft, stride * sizeof(float), t.stream) ||
 	    hipStreamSynchronize(t.stream) != hipSuccess)
@@ -204,7 +205,7 @@ SoftVector *demodAnyBurst(const signalVector &burst, CorrType type, int sps, str
 	if (!t.ensure(1, burst.bytes(), stride) || !h2d(t.d_iq, burst.begin(), burst.bytes(), t.stream) ||
 	    !h2d(t.d_prm, &prm, sizeof(prm), t.stream) || !h2d(t.d_ebp, e, sizeof(e), t.stream) ||
 	    trxhip_demod_batch_cf32(g_ctx, static_cast<const float *>(t.d_iq), t.d_prm, t.d_ebp, t.d_res, t.d_soft, 1, (int)n,
-				    sps, (int)stride, 0, t.stream) != TRXHIP_OK ||
+				    sps, (int)stride, TRXHIP_FLAG_EXACT_DEMOD, t.stream) != TRXHIP_OK ||
 	    !d2h(bits->begin(), t.d_soft, ns * sizeof(float), t.stream) || hipStreamSynchronize(t.stream) != hipSuccess) {
 		delete bits;
 		return NULL;
@@ -239,7 +240,7 @@ int pullRadioVectorBatch(const BurstRequest *req, size_t n, int sps, size_t burs
 		return -EIO;
 	int rc = trxhip_detect_demod_batch(g_ctx, static_cast<const int16_t *>(t.d_iq), t.d_prm, t.d_res, t.d_soft, n,
 					   (int)burst_len, sps, BURST_THRESH, (float)rxFullScale, NORMAL_BURST_NBITS,
-					   1 /* vectorSlicer applied */, t.stream);
+					   TRXHIP_FLAG_SLICE /* vectorSlicer applied; fused demodulator */, t.stream);
 	if (rc != TRXHIP_OK || !d2h(res.data(), t.d_res, n * sizeof(res[0]), t.stream) ||
 	    !d2h(soft.data(), t.d_soft, soft.size() * sizeof(float), t.stream) || hipStreamSynchronize(t.stream) != hipSuccess)
 		return -EIO;

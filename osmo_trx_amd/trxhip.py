@@ -22,6 +22,8 @@ RESULT_DTYPE = np.dtype([
 assert PARAMS_DTYPE.itemsize == 8 and RESULT_DTYPE.itemsize == 32
 
 TRXD_RECORD_BYTES = 156
+FLAG_SLICE = 1          # TRXHIP_FLAG_SLICE
+FLAG_EXACT_DEMOD = 2    # TRXHIP_FLAG_EXACT_DEMOD
 
 
 class TrxHipError(RuntimeError):
@@ -160,7 +162,7 @@ class TrxHip:
 
     # ---- hot path ------------------------------------------------------------------------------
     def detect_demod(self, iq, params, sps=4, threshold=4.0, full_scale=32767.0, soft_stride=148, slice_bits=True,
-                     results=None, soft=None, stream=None, want_soft=True, _diag_mask=0):
+                     results=None, soft=None, stream=None, want_soft=True, exact=False, _diag_mask=0):
         """iq: int16[n, burst_len, 2] or complex64[n, burst_len] (device).  params: uint8[n, 8] (device).
         Returns (results uint8[n, 32], soft float32[n, soft_stride]) device tensors."""
         torch = self.torch
@@ -183,11 +185,13 @@ class TrxHip:
         else:
             raise TrxHipError(f"unsupported IQ dtype {iq.dtype}")
         rc = fn(self.h, ip, self._dev(params), self._dev(results), sp, n, burst_len, sps,
-                threshold, full_scale, soft_stride, (1 if slice_bits else 0) | (int(_diag_mask) << 8), self._stream(stream))
+                threshold, full_scale, soft_stride,
+                (FLAG_SLICE if slice_bits else 0) | (FLAG_EXACT_DEMOD if exact else 0) | (int(_diag_mask) << 8),
+                self._stream(stream))
         _check(rc, "trxhip_detect_demod_batch")
         return results, soft
 
-    def demod_only(self, iq_cf32, params, ebp, sps=4, soft_stride=156, slice_bits=False, stream=None):
+    def demod_only(self, iq_cf32, params, ebp, sps=4, soft_stride=156, slice_bits=False, exact=False, stream=None):
         """demodAnyBurst() alone: iq complex64[n, L], params uint8[n, 8], ebp float32[n, 4] = {toa, amp_re, amp_im, 0}."""
         torch = self.torch
         n, burst_len = iq_cf32.shape
@@ -195,7 +199,8 @@ class TrxHip:
         soft = torch.empty((n, soft_stride), dtype=torch.float32, device=iq_cf32.device)
         rc = self.L.trxhip_demod_batch_cf32(self.h, self._dev(iq_cf32), self._dev(params), self._dev(ebp, torch.float32),
                                             self._dev(results), self._dev(soft), n, burst_len, sps, soft_stride,
-                                            1 if slice_bits else 0, self._stream(stream))
+                                            (FLAG_SLICE if slice_bits else 0) | (FLAG_EXACT_DEMOD if exact else 0),
+                                            self._stream(stream))
         _check(rc, "trxhip_demod_batch_cf32")
         return results, soft
 

@@ -41,7 +41,8 @@ SEQ = np.dtype([("taps", "<c8", 64), ("gain", "<c8"), ("gain_inv", "<c8"), ("ci_
                 ("n", "<i4"), ("pad", "<i4")])
 BLOB = np.dtype([("magic", "<u4"), ("version", "<u4"), ("dec_taps", "<f4", 16), ("delay_filt", "<f4", (64, 20)),
                  ("rrot1", "<c8", 160), ("c0_inv", "<f4", 8), ("seq", SEQ, 21), ("sincv", "<f4", 4096),
-                 ("chan_taps", "<f4", (4, 16)), ("rs6548_taps", "<f4", (65, 16))])
+                 ("chan_taps", "<f4", (4, 16)), ("rs6548_taps", "<f4", (65, 16)),
+                 ("comp_filt", "<f4", (65, 36))])
 
 
 def test_tables_bit_identical_to_oracle(lib):
@@ -76,6 +77,12 @@ def test_tables_bit_identical_to_oracle(lib):
         v = np.float64(abs(x)) / (8 * np.pi) * 1024
         ref = 0.0 if np.float64(abs(x)) >= 8 * np.pi else st[int(np.floor(np.float32(v)))]
         assert t["sincv"][q ^ ((q >> 4) & 31)] == np.float32(ref), q
+    # composite (delay o decimate) filters of the fused demodulator: 35 taps, sum = 1, row 64 = shifted decimator
+    for f in (0, 1, 32, 63):
+        ref = np.convolve(o["dec_taps"].astype(np.float64), o["delay_filt"][f].astype(np.float64))
+        np.testing.assert_allclose(t["comp_filt"][f][:35], ref, rtol=0, atol=1e-8)
+        assert t["comp_filt"][f][35] == 0
+    assert np.array_equal(t["comp_filt"][64][9:25], o["dec_taps"]) and not t["comp_filt"][64][:9].any()
     # resampler / channelizer partitions against the oracle's restatements
     L = O.lib()
     r = L.orc_resampler_new(65, 48, 16, 1.0)

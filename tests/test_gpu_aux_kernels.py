@@ -124,13 +124,13 @@ def test_demod_only_matches_fused(trx):
     iq, params, _ = synth.make_normal_bursts(512, "cpu", 4, seed=77)
     cf = torch.view_as_complex(iq.to(torch.float32)).contiguous().to("cuda:0")
     d_p = trx.params_tensor(params)
-    res, soft = trx.detect_demod(cf, d_p, sps=4, soft_stride=156, slice_bits=False)
+    res, soft = trx.detect_demod(cf, d_p, sps=4, soft_stride=156, slice_bits=False, exact=True)
     r = trx.results_to_numpy(res)
     ebp = np.stack([r["toa"], r["amp_re"], r["amp_im"], np.zeros(len(r), np.float32)], axis=1).astype(np.float32)
     det = r["rc"] > 0
     p2 = params.copy()
     p2["type"][~det] = O.OFF
-    res2, soft2 = trx.demod_only(cf, trx.params_tensor(p2), dev(ebp))
+    res2, soft2 = trx.demod_only(cf, trx.params_tensor(p2), dev(ebp), exact=True)
     torch.cuda.synchronize()
     assert det.sum() > 450
     assert torch.equal(soft[torch.from_numpy(det).to("cuda:0")], soft2[torch.from_numpy(det).to("cuda:0")])

@@ -27,20 +27,29 @@ def trx():
     return TrxHip(0)
 
 
-def run_gpu(trx, iq, params, sps, soft_stride=148, slice_bits=True, **kw):
+def run_gpu(trx, iq, params, sps, soft_stride=148, slice_bits=True, exact=True, **kw):
     d_iq = iq.to("cuda:0") if not iq.is_cuda else iq
     d_p = trx.params_tensor(params)
-    res, soft = trx.detect_demod(d_iq, d_p, sps=sps, soft_stride=soft_stride, slice_bits=slice_bits, **kw)
+    res, soft = trx.detect_demod(d_iq, d_p, sps=sps, soft_stride=soft_stride, slice_bits=slice_bits, exact=exact, **kw)
     torch.cuda.synchronize()
     return trx.results_to_numpy(res), soft.cpu().numpy()
 
 
-def check_parity(g_res, g_soft, o_res, o_soft):
+FUSED_SOFT_ATOL = 1e-5      # fused demodulator vs reference soft bits (full scale ~1); north-star bar: 1e-4
+
+
+def check_parity(g_res, g_soft, o_res, o_soft, soft_atol=0.0):
     for f in ("rc", "tsc", "clip", "idle", "nbits_div4"):
         assert np.array_equal(g_res[f], o_res[f]), f
     for f in ("toa", "amp_re", "amp_im"):
         assert np.array_equal(g_res[f], o_res[f]), f
-    assert np.array_equal(g_soft, o_soft)
+    if soft_atol == 0.0:
+        assert np.array_equal(g_soft, o_soft)
+    else:
+        np.testing.assert_allclose(g_soft, o_soft, rtol=0, atol=soft_atol)
+        sure = np.abs(o_soft - (0.5 if o_soft.min() >= 0 else 0.0)) > 10 * soft_atol
+        ref_mid = 0.5 if o_soft.min() >= 0 else 0.0
+        assert np.array_equal((g_soft > ref_mid)[sure], (o_soft > ref_mid)[sure])      # same hard decisions
     np.testing.assert_allclose(g_res["energy"], o_res["energy"], rtol=1e-6, atol=0)
     fin = np.isfinite(o_res["rssi"])
     np.testing.assert_allclose(g_res["rssi"][fin], o_res["rssi"][fin], rtol=0, atol=1e-5)
@@ -56,6 +65,9 @@ def test_normal_bursts_4sps_all_tsc(trx):
     g_res, g_soft = run_gpu(trx, iq, params, 4)
     assert (o_res["rc"] > 0).sum() > 3500 and (o_res["rc"] == 0).sum() > 100
     check_parity(g_res, g_soft, o_res, o_soft)
+    # default (fused) demodulator: detection bit-exact, soft bits within 1e-5 of full scale
+    f_res, f_soft = run_gpu(trx, iq, params, 4, exact=False)
+    check_parity(f_res, f_soft, o_res, o_soft, soft_atol=FUSED_SOFT_ATOL)
 
 
 def test_normal_bursts_wide_window_raw_soft(trx):
@@ -65,6 +77,9 @@ def test_normal_bursts_wide_window_raw_soft(trx):
     g_res, g_soft = run_gpu(trx, iq, params, 4, soft_stride=156, slice_bits=False)
     assert (o_res["rc"] > 0).sum() > 800
     check_parity(g_res, g_soft, o_res, o_soft)
+    # fused demodulator with large and negative TOAs: exercises both truncation edges of delayVector/downsampleBurst
+    f_res, f_soft = run_gpu(trx, iq, params, 4, soft_stride=156, slice_bits=False, exact=False)
+    check_parity(f_res, f_soft, o_res, o_soft, soft_atol=FUSED_SOFT_ATOL)
 
 
 @pytest.mark.parametrize("ext", [False, True])
@@ -76,6 +91,8 @@ def test_access_bursts(trx, ext):
     g_res, g_soft = run_gpu(trx, iq, params, 4)
     assert (o_res["rc"] > 0).sum() > 1800
     check_parity(g_res, g_soft, o_res, o_soft)
+    f_res, f_soft = run_gpu(trx, iq, params, 4, exact=False)          # TOA up to 63 symbols: high-side edge outputs
+    check_parity(f_res, f_soft, o_res, o_soft, soft_atol=FUSED_SOFT_ATOL)
 
 
 def test_mixed_types_idle_off_edge_fallthrough(trx):
@@ -88,6 +105,8 @@ def test_mixed_types_idle_off_edge_fallthrough(trx):
     g_res, g_soft = run_gpu(trx, iq, params, 4)
     assert set(np.unique(o_res["rc"])) >= {-3, 0, 1, 3}
     check_parity(g_res, g_soft, o_res, o_soft)
+    f_res, f_soft = run_gpu(trx, iq, params, 4, exact=False)
+    check_parity(f_res, f_soft, o_res, o_soft, soft_atol=FUSED_SOFT_ATOL)
 
 
 @pytest.mark.parametrize("burst_len", [156, 157])
@@ -134,9 +153,10 @@ def test_full_size_properties(trx):
     n = 1 << 20
     iq, params, truth = synth.make_normal_bursts(n, "cuda:0", 4)
     d_p = trx.params_tensor(params)
-    res, soft = trx.detect_demod(iq, d_p, sps=4)
+    res, soft = trx.detect_demod(iq, d_p, sps=4)                         # default = fused demodulator
     perm = torch.randperm(n, device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(3))
     res2, soft2 = trx.detect_demod(iq[perm].contiguous(), d_p[perm].contiguous(), sps=4)
+    res_x, soft_x = trx.detect_demod(iq, d_p, sps=4, exact=True)
     torch.cuda.synchronize()
     assert torch.equal(res[perm], res2) and torch.equal(soft[perm], soft2)
     r = trx.results_to_numpy(res)
@@ -147,7 +167,11 @@ def test_full_size_properties(trx):
     assert abs(np.mean(r["toa"][ok] - truth["delay_sym"][ok])) < 0.05
     sel = np.random.default_rng(5).choice(n, 2048, replace=False)
     o_res, o_soft = O.pull_batch(iq[torch.from_numpy(sel).to("cuda:0")].cpu().numpy(), 4, params[sel])
-    check_parity(r[sel], soft[torch.from_numpy(sel).to("cuda:0")].cpu().numpy(), o_res, o_soft)
+    tsel = torch.from_numpy(sel).to("cuda:0")
+    check_parity(r[sel], soft[tsel].cpu().numpy(), o_res, o_soft, soft_atol=FUSED_SOFT_ATOL)
+    check_parity(trx.results_to_numpy(res_x)[sel], soft_x[tsel].cpu().numpy(), o_res, o_soft)
+    assert torch.equal(res, res_x)                                       # detection identical in both modes
+    assert float((soft - soft_x).abs().max()) <= FUSED_SOFT_ATOL
 
 
 def test_argument_errors(trx):
