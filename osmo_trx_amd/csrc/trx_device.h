@@ -115,16 +115,8 @@ __device__ __forceinline__ c32 cmul(c32 a, c32 b) { return make_float2(a.x * b.x
 // dropping the others only drops additions of +-0.  q = |i*512 - ix512| is affine in the tap index on
 // either side of the peak, so the LUT address is one per-lane base plus a compile-time offset.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ c32 interp_point(const c32 *cz, int ix512, const float *sincv)
+__device__ __forceinline__ c32 interp_taps(const c32 *c, const float *sa, const float *sb)
 {
-	const int fl = ix512 >> 9;                       // floor(ix)
-	const int f = ix512 & 511;                       // fractional part * 512
-	const int fs = trx_sincv_swz(f);                 // taps i <= fl : q = 512*(fl-i) + f
-	const int g = 512 - f;                           // taps i >  fl : q = 512*(i-fl-1) + (512 - f)
-	const int gs = (f == 0) ? 512 : trx_sincv_swz(g);
-	const c32 *c = cz + (fl - 7);
-	const float *sa = sincv + fs;
-	const float *sb = sincv + gs;
 	c32 p = make_float2(0.0f, 0.0f);
 #pragma unroll
 	for (int u = 0; u < 8; u++) {                    // i = fl-7 .. fl   (k = 7 .. 0)
@@ -141,6 +133,39 @@ __device__ __forceinline__ c32 interp_point(const c32 *cz, int ix512, const floa
 		p.y += v.y * w;
 	}
 	return p;
+}
+
+// LUT bases of a fractional position f (= ix512 & 511): taps i <= fl use q = 512*(fl-i) + f,
+// taps i > fl use q = 512*(i-fl-1) + (512 - f)
+__device__ __forceinline__ int sinc_base_lo(int f) { return trx_sincv_swz(f); }
+__device__ __forceinline__ int sinc_base_hi(int f) { return (f == 0) ? 512 : trx_sincv_swz(512 - f); }
+
+__device__ __forceinline__ c32 interp_point(const c32 *cz, int ix512, const float *sincv)
+{
+	const int fl = ix512 >> 9;                       // floor(ix)
+	const int f = ix512 & 511;                       // fractional part * 512
+	return interp_taps(cz + (fl - 7), sincv + sinc_base_lo(f), sincv + sinc_base_hi(f));
+}
+
+// Lane constants of the speculative bisection (functions of the lane id only): computed once per kernel,
+// they cost 5 VGPRs instead of ~40 VALU instructions per burst.
+struct PeakConst {
+	int flA;        // round A: floor((offset of this lane's position) / 512)
+	int loA, hiA;   // round A: sinc LUT bases (the fraction depends on the lane only: E is a multiple of 512)
+	int offB;       // round B: position offset of this lane (node early/late, or one of the 16 final positions)
+	int pad;
+};
+__device__ __forceinline__ int node_offset(int n, int inc0);
+__device__ __forceinline__ PeakConst peak_const(int lane)
+{
+	PeakConst pc;
+	const int offA = node_offset(lane >> 1, 256) + ((lane & 1) ? 1024 : 0);
+	pc.flA = offA >> 9;
+	pc.loA = sinc_base_lo(offA & 511);
+	pc.hiA = sinc_base_hi(offA & 511);
+	pc.offB = (lane < 32) ? node_offset(lane >> 1, 8) + ((lane & 1) ? 1024 : 0) : (2 * (lane & 15) - 15) + 512;
+	pc.pad = 0;
+	return pc;
 }
 
 // earlyIndex offset (1/512 units) of heap node n of a bisection subtree whose first step is `inc0`:
@@ -180,7 +205,7 @@ __device__ __forceinline__ int walk_tree(float nv, int inc0, bool &tie)
 // peakDetect() (sigProcLib.cpp:1141-1186) with the early/late bisection expanded across lanes.
 // All lanes return the same (toa512, value).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void peak_detect_spec(const c32 *cz, int max_idx, const float *sincv,
+__device__ __forceinline__ void peak_detect_spec(const c32 *cz, int max_idx, const float *sincv, const PeakConst &pc,
 						  int lane, int *toa512_out, c32 *val_out)
 {
 	int E = (max_idx - 1) * 512;                     // earlyIndex * 512
@@ -188,8 +213,9 @@ __device__ __forceinline__ void peak_detect_spec(const c32 *cz, int max_idx, con
 
 	// ---- round A: levels 0..4 (incr = 1/2 .. 1/32): heap node n on lanes 2n (early) and 2n+1 (late)
 	{
-		const int ix = E + node_offset(lane >> 1, 256) + ((lane & 1) ? 1024 : 0);
-		const float nv = norm2(interp_point(cz, ix, sincv));     // lanes 62,63 evaluate a harmless extra node
+		// ix = E + offA with E a multiple of 512: floor and fraction come from the lane constants
+		const float nv = norm2(interp_taps(cz + ((max_idx - 1) + pc.flA - 7), sincv + pc.loA, sincv + pc.hiA));
+		// (lanes 62,63 evaluate a harmless extra node)
 		E += walk_tree<5>(nv, 256, tie);
 	}
 	int final_ix;
@@ -197,12 +223,7 @@ __device__ __forceinline__ void peak_detect_spec(const c32 *cz, int max_idx, con
 	if (!tie) {
 		// ---- round B: levels 5..8 (incr = 1/64 .. 1/512) on lanes 0..29, the 16 possible final
 		// positions (earlyIndex + 1) on lanes 32..47
-		int ix;
-		if (lane < 32)
-			ix = E + node_offset(lane >> 1, 8) + ((lane & 1) ? 1024 : 0);
-		else
-			ix = E + (2 * (lane & 15) - 15) + 512;
-		const c32 pv = interp_point(cz, ix, sincv);
+		const c32 pv = interp_point(cz, E + pc.offB, sincv);
 		const float nv = norm2(pv);
 		const int offB = walk_tree<4>(nv, 8, tie);
 		E += offB;
@@ -227,7 +248,7 @@ __device__ __forceinline__ void peak_detect_spec(const c32 *cz, int max_idx, con
 // ------------------------------------------------------------------------------------------------
 template <bool PADDED>
 __device__ __forceinline__ int detect_burst(const c32 *sig, int sig_len, c32 *cz, const c32 *taps, const float *hdr,
-					     int N, float thresh, int start, int len, const float *sincv, int lane,
+					     int N, float thresh, int start, int len, const float *sincv, const PeakConst &pc, int lane,
 					     float *toa_out, c32 *amp_out, float *ci_out, int slice)
 {
 	// ---- correlate: corr[i] = sum_k SIG(i + start - (N-1) + k) * seq[k]   (:1674, convolve_base.c:72-85)
@@ -275,6 +296,7 @@ __device__ __forceinline__ int detect_burst(const c32 *sig, int sig_len, c32 *cz
 	wave_sync();
 	const c32 amp0 = cz[bidx];
 
+	if (ABL(9)) { *toa_out = (float)bidx; *amp_out = amp0; *ci_out = 0.0f; return 1; }
 	// ---- computePeakRatio (:1541-1571): terms in the reference's order; out-of-range terms read the
 	// zero pads (adding +0 is exact), their count is arithmetic
 	{
@@ -303,7 +325,7 @@ __device__ __forceinline__ int detect_burst(const c32 *sig, int sig_len, c32 *cz
 	wave_sync();
 	if (ABL(1)) { toa512 = bidx * 512; xcorr = amp0; }
 	else
-		peak_detect_spec(cz, bidx, sincv, lane, &toa512, &xcorr);
+		peak_detect_spec(cz, bidx, sincv, pc, lane, &toa512, &xcorr);
 	toa512 = uni(toa512);
 	xcorr.x = unif(xcorr.x);
 	xcorr.y = unif(xcorr.y);
@@ -315,20 +337,22 @@ __device__ __forceinline__ int detect_burst(const c32 *sig, int sig_len, c32 *cz
 		// roundf(toa): toa is k/512 -> round half away from zero on integers
 		const int rt = (toa512 >= 0) ? ((toa512 + 256) >> 9) : -((-toa512 + 256) >> 9);
 		const int ps = start + 1 - N + rt;
-		if (ps >= 0 && ps + N <= sig_len) {
+		if (ps >= 0 && ps + N <= sig_len && !ABL(7)) {
 			// S = sum_i |sig[ps+i]|^2 in index order: lane i squares one sample, the sum walks the lanes
 			const float pw = norm2(sig[ps + (lane < N ? lane : 0)]);
 			float S = 0.0f;
 			for (int i = 0; i < N; i++)
 				S += lane_val(pw, i);
-			S /= (float)N;
-			const float C = norm2(xcorr) / hdr[4];
-			ci = 3.0103f * log2f(C / (S - C));
+			// C/I is an analogue report (tolerance 2e-5 dB in the tests): reciprocal-multiplies and the
+			// hardware log2 instead of three IEEE divisions and a software log
+			S *= (N == 16) ? 0.0625f : 0.025f;               // S /= N  (N is 16 or 40)
+			const float C = norm2(xcorr) * hdr[7];           // / ((N-1)*|gain|), reciprocal from the table
+			ci = 3.0103f * __log2f(C * __builtin_amdgcn_rcpf(S - C));
 		}
 	}
 
 	*amp_out = cmul(xcorr, make_float2(hdr[2], hdr[3]));   // xcorr / sync->gain  (:1701)
-	*toa_out = toa - hdr[5];                                 // :1704
+	*toa_out = unif(toa - hdr[5]);                           // :1704
 	*ci_out = ci;
 	return 1;
 }

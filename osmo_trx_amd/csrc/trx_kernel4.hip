@@ -109,6 +109,8 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 		wbase[i] = make_float2(0.0f, 0.0f);
 	__syncthreads();
 
+	const float fs_db = 6.02059991f * __log2f(full_scale);          // 20*log10(full_scale)
+	const PeakConst pkc = peak_const(threadIdx.x & (WAVE - 1));      // lane constants of the TOA bisection
 	const unsigned total_waves = gridDim.x * waves_per_block;
 	const unsigned first = blockIdx.x * waves_per_block + wave;
 
@@ -179,9 +181,9 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 		if (type != TRXHIP_OFF) {                                   // Transceiver.cpp:704-707
 			amax = wave_max(amax);                                  // maxAmplitude(), :1711-1722
 			clip = amax > TRX_CLIP_THRESH;
-			energy = wave_sum(epart) / 80.0f;                       // energyDetect(burst, 20*sps)
+			energy = wave_sum(epart) * 0.0125f;                     // energyDetect(burst, 20*sps): / 80
 			if (!ABL(2))
-				rssi = 6.02059991f * __log2f(full_scale / sqrtf(energy));   // 20*log10(fs/avg), Transceiver.cpp:741,751
+				rssi = fs_db - 3.01029996f * __log2f(energy);       // 20*log10(fs/sqrt(e)), Transceiver.cpp:741,751
 			wave_sync();
 
 			if (ebp_in) {
@@ -240,7 +242,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 						wave_sync();
 					}
 					float t; c32 a; float cc;
-					const int hit = detect_burst<true>(dec, 156, cz, taps, hdr, N, thresh, start, len, sincv, lane, &t, &a, &cc, slice);
+					const int hit = detect_burst<true>(dec, 156, cz, taps, hdr, N, thresh, start, len, sincv, pkc, lane, &t, &a, &cc, slice);
 					wave_sync();
 					if (hit) {
 						rc = 1;
@@ -262,7 +264,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 		if (rc > 0 && rc != TRXHIP_EDGE && !ABL(0)) {
 			// demodCommon (:2030-2048): delayVector(burst, -toa*sps) -> scaleVector(1/amp) -> downsampleBurst
 			const float delay = -toa * 4.0f;
-			const int w = (int)floorf(delay);                              // integer shift: y[n] = fshift[n - w]
+			const int w = uni((int)floorf(delay));                         // integer shift: y[n] = fshift[n - w]; wave-uniform -> SALU
 			const float frac = delay - (float)w;
 			const bool use_filt = ((double)fabsf(frac) > 1e-2) && !ABL(4);  // :1056
 			const int fidx = uni(use_filt ? (int)floorf(frac * (float)TRX_DELAY_FILTS) : TRX_DELAY_FILTS);   // :1057; row 64 = identity
@@ -400,8 +402,8 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 					if (t == 0)
 						edge[slot + e] = cmul(make_float2(sr, si), scale);
 				};
-				if (need_lo) edge_round(i0l, 0);
-				if (need_hi) edge_round(i0h, 4);
+				if (need_lo && !ABL(6)) edge_round(i0l, 0);
+				if (need_hi && !ABL(6)) edge_round(i0h, 4);
 
 				const float4 *c4 = reinterpret_cast<const float4 *>(comp + fidx * 36);   // 35 taps, LDS broadcast reads
 				const int c = -24 - w;

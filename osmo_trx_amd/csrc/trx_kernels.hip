@@ -87,6 +87,8 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 		wbase[i] = make_float2(0.0f, 0.0f);
 	__syncthreads();
 
+	const float fs_db = 6.02059991f * __log2f(full_scale);          // 20*log10(full_scale)
+	const PeakConst pkc = peak_const(threadIdx.x & (WAVE - 1));      // lane constants of the TOA bisection
 	const unsigned total_waves = gridDim.x * waves_per_block;
 	const unsigned first = blockIdx.x * waves_per_block + wave;
 
@@ -175,7 +177,7 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 			// energyDetect(burst, 20*sps) (:1573-1585), tree-summed; RSSI (Transceiver.cpp:741,751) in fp32
 			energy = wave_sum(epart) / (float)win;
 			if (!ABL(2))
-				rssi = 6.02059991f * __log2f(full_scale / sqrtf(energy));  // 20*log10(x) = 20*log10(2)*log2(x), v_log_f32
+				rssi = fs_db - 3.01029996f * __log2f(energy);       // 20*log10(fs/sqrt(e)), Transceiver.cpp:741,751
 			wave_sync();
 
 			if (ebp_in) {
@@ -238,9 +240,9 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 							dec_lo = lo; dec_hi = hi;
 							wave_sync();
 						}
-						hit = detect_burst<true>(dec, 156, cz, taps, hdr, N, thresh, start, len, sincv, lane, &t, &a, &cc, slice);
+						hit = detect_burst<true>(dec, 156, cz, taps, hdr, N, thresh, start, len, sincv, pkc, lane, &t, &a, &cc, slice);
 					} else {
-						hit = detect_burst<false>(xs, L, cz, taps, hdr, N, thresh, start, len, sincv, lane, &t, &a, &cc, slice);
+						hit = detect_burst<false>(xs, L, cz, taps, hdr, N, thresh, start, len, sincv, pkc, lane, &t, &a, &cc, slice);
 					}
 					wave_sync();
 					if (hit) {

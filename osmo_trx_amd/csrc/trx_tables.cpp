@@ -254,6 +254,7 @@ private:
 		dst->gain_inv.re = gi.r;
 		dst->gain_inv.im = gi.i;
 		dst->ci_den = (dst->n - 1) * gain.abs();          // sigProcLib.cpp:1629
+		dst->ci_den_inv = 1.0f / dst->ci_den;
 	}
 
 	// generateMidamble / generateDummyMidamble (sps = 1), sigProcLib.cpp:1227-1299, :1301-1370

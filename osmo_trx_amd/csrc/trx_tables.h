@@ -34,7 +34,7 @@ struct trx_seq {
 	float   ci_den;                // (N-1) * gain.abs()
 	float   toa;                   // CorrelationSequence::toa
 	int32_t n;                     // sequence length: 16 / 40 / 64
-	int32_t pad;
+	float   ci_den_inv;            // 1 / ci_den
 };
 
 struct trx_tables {

@@ -38,7 +38,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 # device blob layout (osmo_trx_amd/csrc/trx_tables.h)
 SEQ = np.dtype([("taps", "<c8", 64), ("gain", "<c8"), ("gain_inv", "<c8"), ("ci_den", "<f4"), ("toa", "<f4"),
-                ("n", "<i4"), ("pad", "<i4")])
+                ("n", "<i4"), ("ci_den_inv", "<f4")])
 BLOB = np.dtype([("magic", "<u4"), ("version", "<u4"), ("dec_taps", "<f4", 16), ("delay_filt", "<f4", (64, 20)),
                  ("rrot1", "<c8", 160), ("c0_inv", "<f4", 8), ("seq", SEQ, 21), ("sincv", "<f4", 4096),
                  ("chan_taps", "<f4", (4, 16)), ("rs6548_taps", "<f4", (65, 16)),
@@ -80,7 +80,7 @@ def test_tables_bit_identical_to_oracle(lib):
     # composite (delay o decimate) filters of the fused demodulator: 35 taps, sum = 1, row 64 = shifted decimator
     for f in (0, 1, 32, 63):
         ref = np.convolve(o["dec_taps"].astype(np.float64), o["delay_filt"][f].astype(np.float64))
-        np.testing.assert_allclose(t["comp_filt"][f][:35], ref, rtol=0, atol=1e-8)
+        np.testing.assert_allclose(t["comp_filt"][f][:35], ref, rtol=1e-7, atol=1e-12)   # products in double, one float rounding
         assert t["comp_filt"][f][35] == 0
     assert np.array_equal(t["comp_filt"][64][9:25], o["dec_taps"]) and not t["comp_filt"][64][:9].any()
     # resampler / channelizer partitions against the oracle's restatements

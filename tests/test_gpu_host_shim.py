@@ -72,4 +72,7 @@ def test_pull_radio_vector_batch(exe, tmp_path):
     on = params["type"] != O.OFF
     fin = np.isfinite(o_res["rssi"]) & on
     np.testing.assert_allclose(rec[fin, 3], o_res["rssi"][fin], rtol=1e-5, atol=1e-4)
-    assert np.array_equal(soft[det], o_soft[det])
+    # the batched core uses the fused demodulator: soft bits within 1e-5 of full scale, same hard decisions
+    np.testing.assert_allclose(soft[det], o_soft[det], rtol=0, atol=1e-5)
+    sure = np.abs(o_soft[det] - 0.5) > 1e-4
+    assert np.array_equal((soft[det] > 0.5)[sure], (o_soft[det] > 0.5)[sure])
