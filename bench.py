@@ -23,43 +23,60 @@ BYTES_PER_BURST = 3132          # 2500 B int16 IQ + 8 B params +
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def cpu_baseline(iq_host, params, target_seconds=4.0):
+def usable_cores():
+    """Host threads this process can actually run: the affinity mask, capped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(-(-int(quota) // int(period)))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(iq_host, params, target_seconds=6.0):
     """Time the CPU oracle (oracle/trx_oracle.c, a port of the reference's generic-C path, gcc -O2) on a
-    bounded sample of the same workload: one thread per host core, each thread looping over its own
-    contiguous slice of the sample until ~target_seconds of work is done (bursts are independent, so a
-    static split is the fair CPU ceiling; ctypes releases the GIL)."""
+    bounded sample of the same workload: one thread per usable host core, each thread looping over its own
+    contiguous slice of the sample (bursts are independent, so a static split is the fair CPU ceiling;
+    ctypes releases the GIL).  A one-pass calibration sizes the repeat count to ~target_seconds."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     from concurrent.futures import ThreadPoolExecutor
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
+    cores = usable_cores()
     O.lib()
     n_sample = len(iq_host)
     per = max(256, n_sample // cores)
-    # single thread first: rate on one slice, also sizes the repeat count
     n1 = min(n_sample, 8192)
     t0 = time.perf_counter()
     O.pull_batch(iq_host[:n1], 4, params[:n1])
     t1 = time.perf_counter() - t0
-    reps = max(1, int(target_seconds / max(t1 * per / n1, 1e-6)))
     slices = [(min(i * per, n_sample - per), min(i * per, n_sample - per) + per) for i in range(cores)]
 
-    def work(b):
-        for _ in range(reps):
-            O.pull_batch(iq_host[b[0]:b[1]], 4, params[b[0]:b[1]])
+    def run(reps):
+        def work(b):
+            for _ in range(reps):
+                O.pull_batch(iq_host[b[0]:b[1]], 4, params[b[0]:b[1]])
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:
+            list(ex.map(work, slices))
+        return time.perf_counter() - t0
 
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(cores) as ex:
-        list(ex.map(work, slices))
-    tn = time.perf_counter() - t0
+    tcal = run(1)                                                    # calibration pass, all threads
+    reps = max(1, min(200, int(target_seconds / max(tcal, 1e-3))))
+    tn = run(reps)
     done = per * reps * cores
     return {
         "value": round(done / tn / 1e6, 6), "unit": "Mbursts/s", "cores": cores, "kind": "port",
         "sample": f"first {n_sample} bursts of the same batch split over {cores} threads ({per} bursts each, "
-                  f"repeated {reps}x, {done} bursts in {tn:.1f} s); oracle/trx_oracle.c, generic-C order, gcc -O2",
+                  f"repeated {reps}x: {done} bursts in {tn:.1f} s); oracle/trx_oracle.c, generic-C order, gcc -O2",
         "single_thread_kbursts_s": round(n1 / t1 / 1e3, 2),
+        "host": {"affinity_cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+                 "cgroup_cpu_max": (open("/sys/fs/cgroup/cpu.max").read().strip()
+                                    if os.path.exists("/sys/fs/cgroup/cpu.max") else None)},
     }
 
 
@@ -95,8 +112,9 @@ def main():
     results = torch.empty((n, 32), dtype=torch.uint8, device=dev)
     soft = torch.empty((n, 148), dtype=torch.float32, device=dev)
 
-    def step():
-        trx.detect_demod(iq, d_params, sps=4, soft_stride=148, slice_bits=True, results=results, soft=soft)
+    def step(exact=False):
+        # default flags = what a deployment runs: vectorSlicer applied, fused demodulator
+        trx.detect_demod(iq, d_params, sps=4, soft_stride=148, slice_bits=True, results=results, soft=soft, exact=exact)
 
     for _ in range(args.warmup):
         step()
@@ -120,6 +138,16 @@ def main():
 
     r = trx.results_to_numpy(results)
     detected = int((r["rc"] > 0).sum())
+
+    # side measurement (not `value`): the bit-exact two-stage demodulator on the same batch
+    xs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+    step(exact=True)
+    for a, b in xs:
+        a.record()
+        step(exact=True)
+        b.record()
+    torch.cuda.synchronize()
+    exact_ms = sum(a.elapsed_time(b) for a, b in xs) / len(xs)
 
     if rank == 0:
         total_bursts = n * world * args.steps
@@ -146,20 +174,19 @@ def main():
                 "bursts_per_gpu": n, "global_bursts": n * world, "sps": 4, "burst_len": 625,
                 "parallelism": f"batch-sharded x{world} (no data-path collective; tables RCCL-broadcast once)",
                 "detected_fraction": round(detected / n, 4),
+                "demodulator": "fused 35-tap delay-o-decimate (default); detection bit-exact, soft bits <= 1e-5",
+                "exact_demod_mbursts_per_gpu": round(n / exact_ms / 1e3, 2),
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                "kernel": "burst_pull_kernel<4,false>", "kernel_ms": round(kernel_ms, 4),
+                "kernel": "burst_pull4_kernel<false, false>", "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_bytes_per_burst": BYTES_PER_BURST, "bursts_per_launch": n,
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            try:
-                cores = len(os.sched_getaffinity(0))
-            except AttributeError:
-                cores = os.cpu_count() or 1
-            ns = args.cpu_sample or min(n, max(8192, 2048 * cores))
+            cores = usable_cores()
+            ns = args.cpu_sample or min(n, max(8192, 4096 * cores))
             out["cpu_baseline"] = cpu_baseline(iq[:ns].cpu().numpy(), params[:ns])
         print(json.dumps(out), flush=True)
 

@@ -54,8 +54,13 @@ __device__ __forceinline__ float row_sum(float v)
 	return v;
 }
 
-template <bool CF32>
-__global__ void __launch_bounds__(TRX_WPB * WAVE, 3)
+// waves per workgroup (one workgroup per CU).  The fused kernel would fit 14 (124 VGPRs, 36 KB of tables + 8.7 KB
+// of LDS per wave) but measures no faster than 12: the kernel is VALU-throughput bound (~85 % busy), not latency bound.
+#define K4_WPB_FUSED 12
+#define K4_WPB_EXACT 12
+
+template <bool CF32, bool EXACT>
+__global__ void __launch_bounds__((EXACT ? K4_WPB_EXACT : K4_WPB_FUSED) * WAVE, 3)
 burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__restrict__ params,
 		   trxhip_burst_result *__restrict__ results, float *__restrict__ soft,
 		   const trx_tables *__restrict__ tab, const float4 *__restrict__ ebp_in,
@@ -291,7 +296,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 				}
 			}
 
-			if (slice & TRXHIP_FLAG_EXACT_DEMOD) {
+			if (EXACT) {
 				// ================= EXACT: two FIR stages in the reference's operand order =================
 				constexpr int R = 12;                                       // outputs per lane: 12*l .. 12*l+11 (52 lanes)
 				const int c0 = -w - 9;                                      // sample of tap 0 of output n: n + c0
@@ -509,21 +514,23 @@ extern "C" int trx_launch_pull4(const void *d_iq, int cf32, const trxhip_burst_p
 {
 	if (n_bursts == 0)
 		return 0;
-	const int wpb = TRX_WPB;
+	const bool exact = (flags & TRXHIP_FLAG_EXACT_DEMOD) != 0;      // two kernels: the demodulator is a compile-time choice
+	const int wpb = exact ? K4_WPB_EXACT : K4_WPB_FUSED;
 	const size_t lds = K4_TABLES_BYTES + (size_t)wpb * K4_SLICE * sizeof(c32);
 	size_t need = (n_bursts + wpb - 1) / wpb;
 	size_t grid = (size_t)n_cu;
 	if (grid > need) grid = need;
-#define LAUNCH4(CF_)                                                                                            \
+#define LAUNCH4(CF_, EX_)                                                                                       \
 	do {                                                                                                    \
-		auto k = burst_pull4_kernel<CF_>;                                                               \
+		auto k = burst_pull4_kernel<CF_, EX_>;                                                          \
 		if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
 			return TRXHIP_EIO;                                                                      \
 		hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(wpb * WAVE), lds, stream, d_iq, d_params, d_results, \
 				   d_soft, d_tab, reinterpret_cast<const float4 *>(d_ebp_in), (unsigned)n_bursts, L, thresh, \
 				   full_scale, soft_stride, flags);                                             \
 	} while (0)
-	if (cf32) LAUNCH4(true); else LAUNCH4(false);
+	if (cf32) { if (exact) LAUNCH4(true, true); else LAUNCH4(true, false); }
+	else      { if (exact) LAUNCH4(false, true); else LAUNCH4(false, false); }
 #undef LAUNCH4
 	return hipGetLastError() == hipSuccess ? 0 : TRXHIP_EIO;
 }
