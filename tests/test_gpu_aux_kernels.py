@@ -170,3 +170,44 @@ def test_trxd_packing(trx):
         if not r["idle"][i]:
             L.orc_trxd_soft_u8(u8.ctypes.data, np.ascontiguousarray(s[i]).ctypes.data, 148)
         assert np.array_equal(pkt[i, 8:], u8)
+
+
+def test_multi_arfcn_front_end_full_size(trx):
+    """BASELINE.json configs[3]: 4-path channelizer over 256k blocks (one continuous stream) + 65/48 resampler
+    + per-channel burst detection.  Size-independent properties: (a) overlap-save -- a segment processed alone
+    with 16 samples of history per path reproduces the full run bit-for-bit; (b) the first blocks match the
+    oracle's block-by-block Channelizer::rotate; (c) the resampled channel keeps feeding the detector."""
+    from osmo_trx_amd import synth
+    n_blocks = 1 << 18
+    wide = synth.make_wideband_stream(n_blocks, "cuda:0")
+    full = trx.channelize(wide, n_blocks)
+    torch.cuda.synchronize()
+    assert full.shape == (4, n_blocks * 192)
+    # (a) segment starting at block s with 16 path-samples (= 64 wideband samples) of history
+    s, nb = 100_003, 64
+    seg = wide[(s * 192 - 16) * 4:((s + nb) * 192) * 4].contiguous()
+    # pad the segment to whole blocks: (16 + nb*192) path samples -> use block_len = 16 + nb*192, one "block"
+    part = trx.channelize(seg, 1, block_len=16 + nb * 192)
+    torch.cuda.synchronize()
+    assert torch.equal(part[:, 16 + 15:], full[:, s * 192 + 15:(s + nb) * 192])      # FIR memory is 15 samples
+    # (b) oracle on the first 32 blocks
+    L = O.lib()
+    c = L.orc_channelizer_new(4, 192, 16)
+    x = wide[:32 * 768].cpu().numpy().astype(np.float32).view(np.complex64).reshape(32, 768)
+    for b in range(32):
+        out = np.zeros((4, 192), dtype=np.complex64)
+        blk = np.ascontiguousarray(x[b])
+        L.orc_channelizer_rotate(c, blk.ctypes.data, 768, out.ctypes.data)
+        assert np.array_equal(full[:, b * 192:(b + 1) * 192].cpu().numpy().view(np.float32), out.view(np.float32))
+    L.orc_channelizer_free(c)
+    # (c) 65/48 resampler on the three active paths: 192 -> 260 per block, continuous
+    n_in = 48 * 4096
+    rs = trx.resample(full[:, :n_in].contiguous(), 65, 48)
+    torch.cuda.synchronize()
+    assert rs.shape == (4, n_in // 48 * 65)
+    r = L.orc_resampler_new(65, 48, 16, 1.0)
+    xin = np.concatenate([np.zeros(16, dtype=np.complex64), full[1, :n_in].cpu().numpy()])
+    ref = np.zeros(n_in // 48 * 65, dtype=np.complex64)
+    L.orc_resampler_rotate(r, xin[16:].ctypes.data, n_in, ref.ctypes.data, len(ref))
+    L.orc_resampler_free(r)
+    assert np.array_equal(rs[1].cpu().numpy().view(np.float32), ref.view(np.float32))

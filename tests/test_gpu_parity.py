@@ -184,3 +184,28 @@ def test_argument_errors(trx):
         trx.detect_demod(iq[:, :600].contiguous(), p, sps=4)
     # empty batch is a no-op
     trx.detect_demod(iq[:0], p[:0], sps=4)
+
+
+def test_full_size_access_bursts(trx):
+    """BASELINE.json configs[2] at full size: 1M access bursts, max_toa 63 (79-lag, 40-tap correlation sweep)."""
+    from osmo_trx_amd import synth
+    n = 1 << 20
+    iq, params, truth = synth.make_access_bursts(n, "cuda:0")
+    d_p = trx.params_tensor(params)
+    res, soft = trx.detect_demod(iq, d_p, sps=4)
+    torch.cuda.synchronize()
+    r = trx.results_to_numpy(res)
+    sig = ~truth["noise_only"]
+    assert (r["rc"][sig] == O.RACH).mean() > 0.9995
+    assert (r["rc"][~sig] > 0).mean() < 0.02
+    ok = (r["rc"] > 0) & sig
+    assert abs(np.mean(r["toa"][ok] - truth["delay_sym"][ok])) < 0.05
+    assert np.std(r["toa"][ok] - truth["delay_sym"][ok]) < 0.1
+    # idempotence / batch-position independence on a slice processed alone
+    sl = slice(777_000, 777_000 + 4096)
+    res2, soft2 = trx.detect_demod(iq[sl].contiguous(), d_p[sl].contiguous(), sps=4)
+    assert torch.equal(res[sl], res2) and torch.equal(soft[sl], soft2)
+    sel = np.random.default_rng(9).choice(n, 1024, replace=False)
+    tsel = torch.from_numpy(sel).to("cuda:0")
+    o_res, o_soft = O.pull_batch(iq[tsel].cpu().numpy(), 4, params[sel])
+    check_parity(r[sel], soft[tsel].cpu().numpy(), o_res, o_soft, soft_atol=FUSED_SOFT_ATOL)
