@@ -120,7 +120,9 @@ uint64_t trxhip_tables_checksum(const void *h_blob, size_t size);     /* FNV-1a 
  *   d_soft   : n_bursts * soft_stride float32 (may be NULL to skip soft output).
  *              TRXHIP_FLAG_SLICE set: rx_burst[] after vectorSlicer(), 0..1, first nbits valid (148) -- what
  *              pullRadioVector() hands to TRXD; clear: raw demodAnyBurst() SoftVector
- *              (-1..+1; 156 values @4 SPS, burst_len @1 SPS).  Unused tail and undetected bursts are zero-filled.
+ *              (-1..+1; 156 values @4 SPS, burst_len @1 SPS).  A burst detected as EDGE (8-PSK) yields 444 soft
+ *              bits (nbits_div4 = 111): give soft_stride >= 444 when EDGE slots are possible, otherwise the row is
+ *              truncated to soft_stride.  Unused tail and undetected bursts are zero-filled.
  *   flags    : TRXHIP_FLAG_* bits
  *   sps      : 1 or 4; burst_len: 625 @4 SPS (>= 624), 156/157 @1 SPS
  */
@@ -140,7 +142,7 @@ int trxhip_detect_demod_batch_cf32(trxhip_ctx *ctx,
 				   int soft_stride, int flags, void *stream);
 
 /* demodAnyBurst() on its own (sigProcLib.h:151-152): the caller supplies, per burst, the CorrType
- * (d_params[b].type; EDGE is reported as detected-only, 8-PSK demodulation is not built yet) and the
+ * (d_params[b].type; EDGE selects the 8-PSK demodulator, 444 soft bits, C/I replaced by the EVM estimate) and the
  * estim_burst_params it got from detection as d_ebp[b] = {toa, amp_re, amp_im, unused} (16-byte aligned).
  * Detection is skipped; d_soft receives the soft bits, d_results echoes the parameters. */
 int trxhip_demod_batch_cf32(trxhip_ctx *ctx, const float *d_iq_cf32, const trxhip_burst_params *d_params,

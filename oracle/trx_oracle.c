@@ -1006,10 +1006,10 @@ static float compute_edge_ci(const orc_cf *rot, int n)
 /* sigProcLib.cpp:2105-2128 (+ derotateEdgeBurst :691-711, softSliceEdgeBurst :1962-2006) */
 static int demod_edge_burst(const orc_cf *burst, int n, int sps, orc_ebp *ebp, float *soft)
 {
-	orc_cf dec[640], eq[640], rot[640];
-	if (n > 640) return -1;
+	const int cap = n > 160 ? n : 160;
+	orc_cf *dec = malloc(3 * (size_t)cap * sizeof(orc_cf)), *eq = dec + cap, *rot = eq + cap;
 	int olen = demod_common(burst, n, sps, ebp, dec);
-	if (olen < 0) return -1;
+	if (olen < 0) { free(dec); return -1; }
 
 	/* eq = convolve(dec, c0_inv, NULL, NO_DELAY): 5 real taps, start = 2 */
 	conv_span_rtaps(dec, olen, T.c0_inv, 5, eq, 2, olen);
@@ -1021,7 +1021,7 @@ static int demod_edge_burst(const orc_cf *burst, int n, int sps, orc_ebp *ebp, f
 	ebp->ci = compute_edge_ci(rot, olen);
 
 	const int nsyms = 148;
-	if (olen < nsyms) return -1;
+	if (olen < nsyms) { free(dec); return -1; }
 	rotate_burst2(rot, olen, -M_PI / 8.0);
 	for (int i = 0; i < nsyms; i++) {
 		soft[3 * i + 0] = -rot[i].im;
@@ -1032,6 +1032,7 @@ static int demod_edge_burst(const orc_cf *burst, int n, int sps, orc_ebp *ebp, f
 	rotate_burst2(rot, olen, -M_PI / 4.0);
 	for (int i = 0; i < nsyms; i++)
 		soft[3 * i + 2] = -rot[i].im;
+	free(dec);
 	return nsyms * 3;
 }
 

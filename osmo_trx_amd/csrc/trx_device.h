@@ -357,3 +357,60 @@ __device__ __forceinline__ int detect_burst(const c32 *sig, int sig_len, c32 *cz
 	return 1;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// 8-PSK tail of demodEdgeBurst() (sigProcLib.cpp:2105-2128) on the 1-SPS burst dec[0..n_dec) (LDS):
+//   eq  = convolve(dec, c0_inv, NO_DELAY)            5 real taps, zero outside            (:2116, :405-422)
+//   rot = derotateEdgeBurst(eq, 1)                   x (cosf(p), -sinf(p)), p = (i%16)*3pi/8  (:691-711)
+//   ci  = computeEdgeCI(rot)                         EVM against the nearest 8-PSK point   (:2074-2093)
+//   soft= softSliceEdgeBurst(rot)                    444 Manhattan soft bits               (:1962-2006)
+// Element-wise work in the reference's operand order (bit-exact); the C/I sum is a wave tree sum.
+// Writes so[0 .. min(444, soft_stride)) and zero-fills the rest; returns C/I in dB.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float edge_post(const c32 *dec, int n_dec, const trx_tables *__restrict__ tab,
+					    float *so, int soft_stride, int slice, int lane)
+{
+	const c32 r_pi8 = make_float2(tab->edge_rot2[0].re, tab->edge_rot2[0].im);
+	const c32 r_pi4 = make_float2(tab->edge_rot2[1].re, tab->edge_rot2[1].im);
+	const float step = tab->edge_step;
+	float err = 0.0f;
+	for (int i = lane; i < n_dec; i += WAVE) {
+		float er = 0.0f, ei = 0.0f;
+#pragma unroll
+		for (int k = 0; k < 5; k++) {
+			const int j = i - 2 + k;
+			c32 x = make_float2(0.0f, 0.0f);
+			if (j >= 0 && j < n_dec) x = dec[j];
+			const float h = tab->c0_inv[k];
+			er += x.x * h;
+			ei += x.y * h;
+		}
+		const trx_c32 d = tab->edge_derot[i & 15];
+		const c32 rot = cmul(make_float2(er, ei), make_float2(d.re, d.im));
+		if (i >= 8 && i < n_dec - 8) {
+			const int k = (int)roundf(atan2f(rot.y, rot.x) / step);
+			const trx_c32 id = tab->edge_ideal[k + 4];
+			const c32 e = make_float2(id.re - rot.x, id.im - rot.y);
+			err += norm2(e);
+		}
+		if (i < 148 && so) {
+			const c32 a = cmul(rot, r_pi8);                       // rotateBurst2(burst, -M_PI/8)
+			float b0 = -a.y, b1 = a.x;
+			const c32 q = cmul(make_float2(fabsf(a.x), fabsf(a.y)), r_pi4);   // fold into quadrant 0, rotate by -M_PI/4
+			float b2 = -q.y;
+			if (slice & 1) {
+				b0 = __builtin_amdgcn_fmed3f(0.5f * (b0 + 1.0f), 0.0f, 1.0f);
+				b1 = __builtin_amdgcn_fmed3f(0.5f * (b1 + 1.0f), 0.0f, 1.0f);
+				b2 = __builtin_amdgcn_fmed3f(0.5f * (b2 + 1.0f), 0.0f, 1.0f);
+			}
+			if (3 * i + 0 < soft_stride) so[3 * i + 0] = b0;
+			if (3 * i + 1 < soft_stride) so[3 * i + 1] = b1;
+			if (3 * i + 2 < soft_stride) so[3 * i + 2] = b2;
+		}
+	}
+	if (so)
+		for (int i = 444 + lane; i < soft_stride; i += WAVE)
+			so[i] = 0.0f;
+	err = wave_sum(err);
+	return 3.0103f * log2f(1.0f * (float)(n_dec - 16) / err);
+}

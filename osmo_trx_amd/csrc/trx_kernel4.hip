@@ -266,7 +266,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 		}
 
 		// ---- demodAnyBurst -> demodGmskBurst (:2055-2072) ----
-		if (rc > 0 && rc != TRXHIP_EDGE && !ABL(0)) {
+		if (rc > 0 && !ABL(0)) {
 			// demodCommon (:2030-2048): delayVector(burst, -toa*sps) -> scaleVector(1/amp) -> downsampleBurst
 			const float delay = -toa * 4.0f;
 			const int w = uni((int)floorf(delay));                         // integer shift: y[n] = fshift[n - w]; wave-uniform -> SALU
@@ -277,9 +277,10 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 			const float an = norm2(amp);
 			const c32 ainv = make_float2(amp.x / an, -amp.y / an);
 			const c32 scale = cmul(make_float2(1.0f, 0.0f), ainv);
-			nbits = 148;
+			const bool is_edge = (rc == TRXHIP_EDGE);                     // 8-PSK: all 156 symbols go through LDS to edge_post()
+			nbits = is_edge ? 444 : 148;
 			idle = 0;
-			const int nwrite = (slice & 1) ? 148 : 156;
+			const int nwrite = (is_edge || !(slice & 1)) ? 156 : 148;
 
 			// delayed samples n exist for n in [n_lo, n_hi]: n >= 0 (zero history in front of the decimator, :1590),
 			// 0 <= n - w < L (delayVector zero-fills what it shifts in, :1071-1090), n <= 623 (:78)
@@ -345,8 +346,9 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 				}
 				wave_sync();
 
-				if (so) {
-					for (int i = lane; i < soft_stride; i += WAVE) {
+				if (so || is_edge) {
+					const int nloop = is_edge ? 156 : soft_stride;
+					for (int i = lane; i < nloop; i += WAVE) {
 						float sv = 0.0f;
 						if (i < nwrite && !ABL(5)) {
 							const c32 *pd = P + PH_M0 + i - 4;
@@ -358,6 +360,10 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 								yr += x.x * g;
 								yi += x.y * g;
 							}
+							if (is_edge) {
+								dec[i] = make_float2(yr, yi);
+								continue;
+							}
 							const c32 r = rrot[i];
 							sv = r.x * yr - r.y * yi;                       // real(rot * x)  (:2066-2068)
 							if (slice & 1)
@@ -367,6 +373,8 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 					}
 				}
 				wave_sync();
+				if (is_edge)
+					ci = edge_post(dec, 156, tab, so, soft_stride, slice, lane);
 			} else {
 				// ================= FUSED: one 35-tap composite filter at the symbol instants =================
 				// dec[i] = scale * sum_u comp[u] * X(4i - 24 - w + u) for outputs whose 16 decimator inputs all exist
@@ -414,7 +422,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 				const int c = -24 - w;
 				const int i_min = cdiv(-36 - c, 4), i_max = fdiv(L + 1 - c, 4);
 				wave_sync();
-				if (so) {
+				if (so || is_edge) {
 					// three output rounds (i = lane, lane+64, lane+128) advance together: three independent FMA
 					// chains per lane hide the LDS and FMA latency, and the 35 taps are fetched once
 					constexpr int NR = 3;
@@ -459,13 +467,17 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 #pragma unroll
 					for (int r = 0; r < NR; r++) {
 						const int i = lane + r * WAVE;
-						if (i < soft_stride) {
+						if (i < (is_edge ? 156 : soft_stride)) {
 							float sv = 0.0f;
 							if (i < nwrite) {
 								const bool full = (i >= i_full_lo) && (i <= i_full_hi);
 								c32 d = full ? cmul(make_float2(acc[r].x, acc[r].y), scale) : make_float2(0.0f, 0.0f);
 								if (need_lo && (unsigned)(i - i0l) < 4u) d = edge[i - i0l];
 								if (need_hi && (unsigned)(i - i0h) < 4u) d = edge[4 + i - i0h];
+								if (is_edge) {
+									dec[i] = d;
+									continue;
+								}
 								const c32 rr = rrot[i];
 								sv = rr.x * d.x - rr.y * d.y;                   // real(rot * x)  (:2066-2068)
 								if (slice & 1)
@@ -474,17 +486,17 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 							so[i] = sv;
 						}
 					}
-					for (int i = lane + NR * WAVE; i < soft_stride; i += WAVE)     // soft_stride > 192: zero tail
-						so[i] = 0.0f;
+					if (!is_edge)
+						for (int i = lane + NR * WAVE; i < soft_stride; i += WAVE) // soft_stride > 192: zero tail
+							so[i] = 0.0f;
+				}
+				if (is_edge) {
+					wave_sync();
+					ci = edge_post(dec, 156, tab, so, soft_stride, slice, lane);
 				}
 				wave_sync();
 			}
 		} else {
-			if (rc == TRXHIP_EDGE) {
-				// 8-PSK demodulation is not built yet: report detection only
-				nbits = 0;
-				idle = 0;
-			}
 			if (so)
 				for (int i = lane; i < soft_stride; i += WAVE)
 					so[i] = 0.0f;

@@ -262,7 +262,7 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 		}
 
 		// ---- demodAnyBurst -> demodGmskBurst (:2055-2072) ----
-		if (rc > 0 && rc != TRXHIP_EDGE && !ABL(0)) {
+		if (rc > 0 && !ABL(0)) {
 			// demodCommon (:2030-2048): delayVector(burst, -toa*sps), scaleVector(1/amp)
 			const float delay = -toa * (float)SPS;
 			const int whole = (int)floorf(delay);
@@ -340,8 +340,30 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 
 			// downsampleBurst (4 SPS) + GMSKReverseRotate + real part + vectorSlicer
 			const int nsoft = (SPS == 4) ? 156 : L;
-			nbits = 148;
 			idle = 0;
+			if (rc == TRXHIP_EDGE) {
+				// demodEdgeBurst (:2105-2128): decimate everything into LDS, then equalise / derotate / slice
+				if (SPS == 4) {
+					for (int i = lane; i < 156; i += WAVE) {
+						const c32 *xp = xs + 4 * i - 15;
+						float yr = 0.0f, yi = 0.0f;
+#pragma unroll
+						for (int k = 0; k < 16; k++) {
+							const c32 x = xp[k];
+							const float g = gdec[k];
+							yr += x.x * g;
+							yi += x.y * g;
+						}
+						dec[i] = make_float2(yr, yi);
+					}
+					wave_sync();
+					ci = edge_post(dec, 156, tab, so, soft_stride, slice, lane);
+				} else {
+					ci = edge_post(xs, L, tab, so, soft_stride, slice, lane);
+				}
+				nbits = 444;
+			} else {
+			nbits = 148;
 			if (so) {
 				const int nwrite = (slice & 1) ? nbits : nsoft;
 				for (int i = lane; i < soft_stride; i += WAVE) {
@@ -370,15 +392,11 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 					so[i] = sv;
 				}
 			}
+			}
 			wave_sync();
 			// the in-place delayed burst leaves sample L-1 (and nothing else) stale: harmless, the next
 			// burst overwrites [0, L) completely
 		} else {
-			if (rc == TRXHIP_EDGE) {
-				// 8-PSK demodulation is not built yet: report detection only
-				nbits = 0;
-				idle = 0;
-			}
 			if (so)
 				for (int i = lane; i < soft_stride; i += WAVE)
 					so[i] = 0.0f;

@@ -86,6 +86,7 @@ public:
 		for (int i = 0; i < 5; i++) t_->c0_inv[i] = (float)inv[i];
 		sincv_table();
 		composite_filters();
+		edge_constants();
 	}
 
 private:
@@ -385,6 +386,28 @@ private:
 				}
 				t_->comp_filt[f][u] = (u < 35) ? (float)acc : 0.0f;
 			}
+		}
+	}
+
+	// EDGE 8-PSK demodulator constants, with the float/double steps of the reference
+	void edge_constants()
+	{
+		for (int i = 0; i < 16; i++) {                        // derotateEdgeBurst, sigProcLib.cpp:702-706
+			float phase = (float)(i % 16) * 3.0f * M_PI / 8.0f;
+			t_->edge_derot[i].re = cosf(phase);
+			t_->edge_derot[i].im = -sinf(phase);
+		}
+		const float step = 2.0f * kPiF / 8.0f;                // computeEdgeCI, :2077
+		t_->edge_step = step;
+		for (int k = -4; k <= 4; k++) {                       // :2082-2083  complex(cos(phase), sin(phase)), float phase
+			float phase = step * (float)k;
+			t_->edge_ideal[k + 4].re = std::cos(phase);
+			t_->edge_ideal[k + 4].im = std::sin(phase);
+		}
+		const double ph[2] = { -M_PI / 8.0, -M_PI / 4.0 };    // rotateBurst2, :582-588 (double phase)
+		for (int j = 0; j < 2; j++) {
+			t_->edge_rot2[j].re = std::cos(ph[j]);
+			t_->edge_rot2[j].im = std::sin(ph[j]);
 		}
 	}
 

@@ -51,10 +51,16 @@ struct trx_tables {
 	// composite of fractional-delay filter f and the /4 decimator (fused demod): comp[f][u] = sum_{t+k=u} g[t]*h_f[k],
 	// u < 35; row 64 = no fractional filter (|frac| <= 0.01, sigProcLib.cpp:1056): g shifted by 9
 	float    comp_filt[TRX_DELAY_FILTS + 1][36];
+	// EDGE 8-PSK demodulator constants (sigProcLib.cpp:691-711, :1962-2006, :2074-2093), evaluated with the host libm
+	trx_c32  edge_derot[16];                            // (cosf(p), -sinf(p)), p = (float)(i%16)*3.0f*M_PI/8.0f
+	trx_c32  edge_ideal[9];                             // (cos(ph), sin(ph)), ph = step*k, k = -4..4, step = 2*M_PI_F/8
+	trx_c32  edge_rot2[2];                              // rotateBurst2 phasors for -M_PI/8 and -M_PI/4
+	float    edge_step;                                 // 2.0f * M_PI_F / 8.0f
+	float    edge_pad;
 };
 
 #define TRX_TABLES_MAGIC   0x54585254u
-#define TRX_TABLES_VERSION 2u
+#define TRX_TABLES_VERSION 3u
 
 // XOR swizzle of the sincv index: conflict-free LDS gathers both for lanes whose positions differ
 // by multiples of 16/512 (coarse bisection levels) and by 1/512 steps (fine levels).

@@ -37,6 +37,7 @@ struct Scratch {
 	int last_sps = 0, last_rc = 0;
 	estim_burst_params last_ebp;
 	std::vector<float> last_soft;
+	trxhip_burst_result last_res;
 
 	bool ensure(size_t n, size_t iq_b, size_t stride)
 	{
@@ -79,6 +80,7 @@ bool h2d(void *d, const void *h, size_t n, hipStream_t s) { return hipMemcpyAsyn
 bool d2h(void *h, const void *d, size_t n, hipStream_t s) { return hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s) == hipSuccess; }
 
 size_t soft_len(int sps, size_t burst_size) { return sps == 4 ? 156 : burst_size; }
+size_t soft_cap(int sps, size_t burst_size) { size_t n = soft_len(sps, burst_size); return n < EDGE_BURST_NBITS ? EDGE_BURST_NBITS : n; }
 
 }  // namespace
 
@@ -140,7 +142,7 @@ int detectAnyBurst(const signalVector &burst, unsigned tsc, float threshold, int
 	if (!g_ctx || !ebp)
 		return -SIGERR_INTERNAL;
 	const size_t n = burst.size();
-	const size_t stride = soft_len(sps, n) < 156 ? 156 : soft_len(sps, n);
+	const size_t stride = soft_cap(sps, n);                /* room for 444 8-PSK soft bits */
 	if (!t.ensure(1, burst.bytes(), stride))
 		return -SIGERR_INTERNAL;
 
@@ -183,20 +185,18 @@ SoftVector *demodAnyBurst(const signalVector &burst, CorrType type, int sps, str
 	Scratch &t = tls;
 	if (!g_ctx || !ebp || ((sps != 1) && (sps != 4)))
 		return NULL;
-	if (type == EDGE)
-		return NULL;                  /* 8-PSK demodulation: not built yet */
 	const size_t n = burst.size();
-	const size_t ns = soft_len(sps, n);
+	const size_t ns = (type == EDGE) ? EDGE_BURST_NBITS : soft_len(sps, n);   /* sigProcLib.cpp:1970, :2013 */
 	SoftVector *bits = new SoftVector(ns);
 
 	/* the fused kernel already demodulated this burst during detectAnyBurst() with these very parameters */
 	if (t.last_burst == burst.begin() && t.last_size == n && t.last_sps == sps && t.last_rc == (int)type &&
 	    t.last_ebp.toa == ebp->toa && t.last_ebp.amp == ebp->amp && t.last_soft.size() >= ns) {
 		memcpy(bits->begin(), t.last_soft.data(), ns * sizeof(float));
-		return bits;
+		return bits;                  /* (8-PSK: ebp->ci already holds the EVM estimate of sigProcLib.cpp:2118) */
 	}
 
-	const size_t stride = ns < 156 ? 156 : ns;
+	const size_t stride = soft_cap(sps, n);
 	trxhip_burst_params prm;
 	memset(&prm, 0, sizeof(prm));
 	prm.type = (uint8_t)type;
@@ -206,23 +206,27 @@ SoftVector *demodAnyBurst(const signalVector &burst, CorrType type, int sps, str
 	    !h2d(t.d_prm, &prm, sizeof(prm), t.stream) || !h2d(t.d_ebp, e, sizeof(e), t.stream) ||
 	    trxhip_demod_batch_cf32(g_ctx, static_cast<const float *>(t.d_iq), t.d_prm, t.d_ebp, t.d_res, t.d_soft, 1, (int)n,
 				    sps, (int)stride, TRXHIP_FLAG_EXACT_DEMOD, t.stream) != TRXHIP_OK ||
-	    !d2h(bits->begin(), t.d_soft, ns * sizeof(float), t.stream) || hipStreamSynchronize(t.stream) != hipSuccess) {
+	    !d2h(bits->begin(), t.d_soft, ns * sizeof(float), t.stream) || !d2h(&t.last_res, t.d_res, sizeof(t.last_res), t.stream) ||
+	    hipStreamSynchronize(t.stream) != hipSuccess) {
 		delete bits;
 		return NULL;
 	}
+	if (type == EDGE)
+		ebp->ci = t.last_res.ci;      /* demodEdgeBurst() replaces C/I by the EVM estimate (sigProcLib.cpp:2118) */
 	return bits;
 }
 
 int pullRadioVectorBatch(const BurstRequest *req, size_t n, int sps, size_t burst_len, double rxFullScale,
-			 double rssi_offset, BurstIndication *out)
+			 double rssi_offset, BurstIndication *out, bool egprs)
 {
+	const size_t stride = egprs ? EDGE_BURST_NBITS : NORMAL_BURST_NBITS;
 	Scratch &t = tls;
 	if (!n)
 		return 0;
 	if (!g_ctx || !req || !out)
 		return -EIO;
 	const size_t burst_bytes = burst_len * 2 * sizeof(int16_t);
-	if (!t.ensure(n, n * burst_bytes, NORMAL_BURST_NBITS))
+	if (!t.ensure(n, n * burst_bytes, stride))
 		return -EIO;
 
 	std::vector<int16_t> iq(n * burst_len * 2);
@@ -235,11 +239,11 @@ int pullRadioVectorBatch(const BurstRequest *req, size_t n, int sps, size_t burs
 		prm[i].max_toa = (uint16_t)req[i].max_toa;
 	}
 	std::vector<trxhip_burst_result> res(n);
-	std::vector<float> soft(n * NORMAL_BURST_NBITS);
+	std::vector<float> soft(n * stride);
 	if (!h2d(t.d_iq, iq.data(), n * burst_bytes, t.stream) || !h2d(t.d_prm, prm.data(), n * sizeof(prm[0]), t.stream))
 		return -EIO;
 	int rc = trxhip_detect_demod_batch(g_ctx, static_cast<const int16_t *>(t.d_iq), t.d_prm, t.d_res, t.d_soft, n,
-					   (int)burst_len, sps, BURST_THRESH, (float)rxFullScale, NORMAL_BURST_NBITS,
+					   (int)burst_len, sps, BURST_THRESH, (float)rxFullScale, (int)stride,
 					   TRXHIP_FLAG_SLICE /* vectorSlicer applied; fused demodulator */, t.stream);
 	if (rc != TRXHIP_OK || !d2h(res.data(), t.d_res, n * sizeof(res[0]), t.stream) ||
 	    !d2h(soft.data(), t.d_soft, soft.size() * sizeof(float), t.stream) || hipStreamSynchronize(t.stream) != hipSuccess)
@@ -257,7 +261,7 @@ int pullRadioVectorBatch(const BurstRequest *req, size_t n, int sps, size_t burs
 			bi.tsc = res[i].tsc;
 			bi.ci = res[i].ci;
 			bi.nbits = 4u * res[i].nbits_div4;
-			memcpy(bi.rx_burst, &soft[i * NORMAL_BURST_NBITS], sizeof(bi.rx_burst));
+			memcpy(bi.rx_burst, &soft[i * stride], (bi.nbits < stride ? bi.nbits : stride) * sizeof(float));
 		}
 	}
 	return 0;

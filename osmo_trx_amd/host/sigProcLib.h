@@ -60,7 +60,7 @@ struct BurstRequest {
 	unsigned max_toa;
 };
 struct BurstIndication {          /* the DSP-derived fields of struct trx_ul_burst_ind (proto_trxd.h:24-37) */
-	float rx_burst[NORMAL_BURST_NBITS];   /* soft bits 0..1 */
+	float rx_burst[EDGE_BURST_NBITS];     /* soft bits 0..1; nbits of them valid (148 GMSK, 444 8-PSK) */
 	unsigned nbits;
 	double rssi;           /* dBFS incl. rssi_offset */
 	double toa;
@@ -70,7 +70,8 @@ struct BurstIndication {          /* the DSP-derived fields of struct trx_ul_bur
 	int rc;                /* detectAnyBurst() result, for the rate counters (Transceiver.cpp:769-781) */
 	float energy;
 };
-/** Process n bursts in one GPU launch.  Returns 0, or a negative errno-style code (-EIO on a GPU error). */
+/** Process n bursts in one GPU launch.  egprs: some slots may carry 8-PSK (cfg->egprs): soft output is 444 wide.
+ *  Returns 0, or a negative errno-style code (-EIO on a GPU error). */
 int pullRadioVectorBatch(const BurstRequest *req, size_t n, int sps, size_t burst_len, double rxFullScale,
-			 double rssi_offset, BurstIndication *out);
+			 double rssi_offset, BurstIndication *out, bool egprs = false);
 #endif

@@ -74,14 +74,16 @@ int main(int argc, char **argv)
 			req[i].max_toa = p[2] | (p[3] << 8);
 		}
 		std::vector<BurstIndication> out(n);
-		int rc = pullRadioVectorBatch(req.data(), n, sps, burst_len, 32767.0, 0.0, out.data());
+		bool egprs = false;
+		for (size_t i = 0; i < n; i++) egprs |= (req[i].type == EDGE);
+		int rc = pullRadioVectorBatch(req.data(), n, sps, burst_len, 32767.0, 0.0, out.data(), egprs);
 		if (rc) { fprintf(stderr, "pullRadioVectorBatch rc=%d\n", rc); return 4; }
 		FILE *fr = fopen(argv[7], "wb"), *fs = fopen(argv[8], "wb");
 		for (size_t i = 0; i < n; i++) {
 			float rec[6] = { (float)out[i].rc, (float)out[i].toa, out[i].ci, (float)out[i].rssi, (float)out[i].idle,
 					 (float)out[i].tsc };
 			fwrite(rec, sizeof(rec), 1, fr);
-			fwrite(out[i].rx_burst, sizeof(float), 148, fs);
+			fwrite(out[i].rx_burst, sizeof(float), egprs ? 444 : 148, fs);
 		}
 		fclose(fr);
 		fclose(fs);

@@ -14,7 +14,8 @@ import math
 import numpy as np
 import torch
 
-from .trxhip import PARAMS_DTYPE, TSC as T_TSC, RACH as T_RACH, EXT_RACH as T_EXT_RACH, IDLE as T_IDLE, OFF as T_OFF
+from .trxhip import (PARAMS_DTYPE, TSC as T_TSC, RACH as T_RACH, EXT_RACH as T_EXT_RACH, IDLE as T_IDLE, OFF as T_OFF,
+                     EDGE as T_EDGE)
 
 # 3GPP TS 45.002 training sequences / access-burst bits
 TSC_BITS = [
@@ -28,6 +29,19 @@ RACH_SYNC = [
     "11101111001001110101011000001101101110111",
 ]
 RACH_HEAD = "00111010"          # 8 extended tail bits
+EDGE_TSC_BITS = [
+    "111111001111111001111001001001111111111111001111111111001111111001111001001001",
+    "111111001111001001111001001001111001001001001111111111001111001001111001001001",
+    "111001111111111111001001001111001001001111001111111001111111111111001001001111",
+    "111001111111111001001001001111001001111001111111111001111111111001001001001111",
+    "111111111001001111001111001001001111111001111111111111111001001111001111001001",
+    "111001111111001001001111001111001001111111111111111001111111001001001111001111",
+    "001111001111111001001001001001111001001111111111001111001111111001001001001001",
+    "001001001111001001001001111111111001111111001111001001001111001001001001111111",
+]
+# 8-PSK constellation indexed by b0 | b1<<1 | b2<<2 (3GPP TS 45.004)
+PSK8 = [(-0.70710678, 0.70710678), (0.0, -1.0), (0.0, 1.0), (0.70710678, -0.70710678),
+        (-1.0, 0.0), (-0.70710678, -0.70710678), (0.70710678, 0.70710678), (1.0, 0.0)]
 
 # Laurent pulses at 4 SPS (BT = 0.3): C0 (16 taps), C1 (8 taps)
 C0_4 = [0.0, 4.46348606e-03, 2.84385729e-02, 1.03184855e-01, 2.56065552e-01, 4.76375085e-01, 7.05961177e-01,
@@ -97,6 +111,57 @@ def modulate_basic_1sps(bits, length):
     x = torch.zeros((N, length), dtype=torch.complex64, device=dev)
     x[:, :nb] = (bits.to(torch.float32) * 2.0 - 1.0).to(torch.complex64) * rot[:nb]
     return _fir_causal(x, C0_1)
+
+
+def modulate_edge_4sps(bits):
+    """8-PSK: bits uint8[N, 444] -> complex64[N, 625]: 3pi/8 rotation per symbol, one symbol of delay, C0 pulse."""
+    N = bits.shape[0]
+    dev = bits.device
+    b = bits.view(N, 148, 3).to(torch.int64)
+    idx = b[:, :, 0] | (b[:, :, 1] << 1) | (b[:, :, 2] << 2)
+    table = torch.tensor([complex(*p) for p in PSK8], dtype=torch.complex64, device=dev)
+    sym = table[idx]
+    k = torch.arange(148, device=dev, dtype=torch.float32)
+    rot = torch.polar(torch.ones(148, device=dev), k * (3.0 * math.pi / 8.0))
+    x = torch.zeros((N, 625), dtype=torch.complex64, device=dev)
+    x[:, 4 + 4 * torch.arange(148, device=dev)] = sym * rot
+    return _fir_causal(x, C0_4)
+
+
+def edge_burst_bits(n, tsc, gen, device):
+    """3 tail symbols (111) | 58 data | 26 training | 58 data | 3 tail: 444 bits"""
+    bits = torch.randint(0, 2, (n, 444), generator=gen, device=device, dtype=torch.uint8)
+    bits[:, :9] = 1
+    bits[:, -9:] = 1
+    tab = torch.stack([_bits(s, device) for s in EDGE_TSC_BITS])
+    bits[:, 9 + 174:9 + 174 + 78] = tab[tsc.long()]
+    return bits
+
+
+def make_edge_bursts(n, device="cpu", seed=SEED + 4, max_toa=3, amp_range=(2000.0, 12000.0), snr_range=(18.0, 35.0),
+                     delay_sym=(0.0, 3.0), chunk=65536):
+    """EDGE (8-PSK) normal bursts, 4 SPS, burst i uses TSC i%8; slots marked EDGE."""
+    device = torch.device(device)
+    iq = torch.empty((n, 625, 2), dtype=torch.int16, device=device)
+    params = np.zeros(n, dtype=PARAMS_DTYPE)
+    params["type"] = T_EDGE
+    params["max_toa"] = max_toa
+    params["tsc"] = (np.arange(n) % 8).astype(np.uint8)
+    all_bits = np.zeros((n, 444), dtype=np.uint8)
+    for c0 in range(0, n, chunk):
+        c1 = min(n, c0 + chunk)
+        m = c1 - c0
+        gen = _gen(seed + 31337 * (c0 // chunk), device)
+        t = torch.from_numpy(params["tsc"][c0:c1]).to(device)
+        bits = edge_burst_bits(m, t, gen, device)
+        wave = modulate_edge_4sps(bits)
+        u = torch.rand((3, m), generator=gen, device=device)
+        amp = amp_range[0] * torch.pow(torch.tensor(amp_range[1] / amp_range[0], device=device), u[0])
+        snr = snr_range[0] + (snr_range[1] - snr_range[0]) * u[1]
+        dly = delay_sym[0] + (delay_sym[1] - delay_sym[0]) * u[2]
+        iq[c0:c1] = _channel(wave, amp, snr, (dly - BASE_TOA[4]) * 4.0, torch.zeros(m, dtype=torch.bool, device=device), gen)
+        all_bits[c0:c1] = bits.cpu().numpy()
+    return iq, params, all_bits
 
 
 def _frac_delay(x, delay):

@@ -42,7 +42,8 @@ SEQ = np.dtype([("taps", "<c8", 64), ("gain", "<c8"), ("gain_inv", "<c8"), ("ci_
 BLOB = np.dtype([("magic", "<u4"), ("version", "<u4"), ("dec_taps", "<f4", 16), ("delay_filt", "<f4", (64, 20)),
                  ("rrot1", "<c8", 160), ("c0_inv", "<f4", 8), ("seq", SEQ, 21), ("sincv", "<f4", 4096),
                  ("chan_taps", "<f4", (4, 16)), ("rs6548_taps", "<f4", (65, 16)),
-                 ("comp_filt", "<f4", (65, 36))])
+                 ("comp_filt", "<f4", (65, 36)), ("edge_derot", "<c8", 16), ("edge_ideal", "<c8", 9),
+                 ("edge_rot2", "<c8", 2), ("edge_step", "<f4"), ("edge_pad", "<f4")])
 
 
 def test_tables_bit_identical_to_oracle(lib):

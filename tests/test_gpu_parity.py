@@ -54,7 +54,7 @@ def check_parity(g_res, g_soft, o_res, o_soft, soft_atol=0.0):
     fin = np.isfinite(o_res["rssi"])
     np.testing.assert_allclose(g_res["rssi"][fin], o_res["rssi"][fin], rtol=0, atol=2e-5)
     assert np.array_equal(np.isfinite(g_res["rssi"]), fin)
-    np.testing.assert_allclose(g_res["ci"], o_res["ci"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(g_res["ci"], o_res["ci"], rtol=0, atol=1e-4 if soft_atol else 2e-5)
 
 
 def test_normal_bursts_4sps_all_tsc(trx):
@@ -209,3 +209,40 @@ def test_full_size_access_bursts(trx):
     tsel = torch.from_numpy(sel).to("cuda:0")
     o_res, o_soft = O.pull_batch(iq[tsel].cpu().numpy(), 4, params[sel])
     check_parity(r[sel], soft[tsel].cpu().numpy(), o_res, o_soft, soft_atol=FUSED_SOFT_ATOL)
+
+
+def test_edge_8psk_bursts(trx):
+    """EDGE slots -- detectEdgeBurst (:1906-1924) + demodEdgeBurst (:2105-2128): 5-tap equaliser,
+    3pi/8 derotation, EVM C/I, Manhattan soft slicing to 444 soft bits.  No reference fixture pins 8-PSK: the oracle's
+    restatement is the checker ("parity unpinned" for this branch)."""
+    from osmo_trx_amd import synth
+    iq, params, bits = synth.make_edge_bursts(1024, "cpu")
+    params["type"][7::16] = O.TSC            # GMSK detection attempted on an 8-PSK burst
+    for slice_bits in (False, True):
+        o_res, o_soft = O.pull_batch(iq.numpy(), 4, params, soft_stride=444, slice_bits=slice_bits)
+        assert (o_res["rc"] == O.EDGE).sum() > 900 and (o_res["nbits_div4"] == 111).sum() > 900
+        g_res, g_soft = run_gpu(trx, iq, params, 4, soft_stride=444, slice_bits=slice_bits, exact=True)
+        check_parity(g_res, g_soft, o_res, o_soft)
+        f_res, f_soft = run_gpu(trx, iq, params, 4, soft_stride=444, slice_bits=slice_bits, exact=False)
+        check_parity(f_res, f_soft, o_res, o_soft, soft_atol=5e-5)     # equaliser gain ~2 on top of the fused demod
+    det = o_res["rc"] == O.EDGE
+    mid = 0.5
+    assert ((g_soft[det] > mid).astype(np.uint8) != bits[det]).mean() < 0.03    # static equaliser: ~1 % raw BER
+    # generic kernel (complex64 input, L = 700 > 628) runs the same branch
+    cf = torch.view_as_complex(iq[:64].to(torch.float32)).contiguous()
+    cf700 = torch.zeros((64, 700), dtype=torch.complex64)
+    cf700[:, :625] = cf
+    o2_res = np.zeros(64, dtype=O.RESULT_DTYPE)
+    o2_soft = np.zeros((64, 444), dtype=np.float32)
+    for i in range(64):
+        x = cf700[i].numpy()
+        rc, e = O.detect_any_burst(x, int(params["tsc"][i]), 4.0, 4, int(params["type"][i]), 3)
+        o2_res["rc"][i] = rc
+        if rc > 0:
+            s = O.demod_any_burst(x, rc, 4, e)
+            o2_soft[i, :len(s)] = s
+            o2_res["toa"][i], o2_res["ci"][i] = e.toa, e.ci
+    g2_res, g2_soft = run_gpu(trx, cf700, params[:64], 4, soft_stride=444, slice_bits=False, full_scale=1.0)
+    assert np.array_equal(g2_res["rc"], o2_res["rc"]) and np.array_equal(g2_res["toa"], o2_res["toa"])
+    assert np.array_equal(g2_soft, o2_soft)
+    np.testing.assert_allclose(g2_res["ci"], o2_res["ci"], atol=1e-4)
