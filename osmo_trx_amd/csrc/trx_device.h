@@ -310,10 +310,21 @@ __device__ __forceinline__ int detect_burst(const c32 *sig, int sig_len, c32 *cz
 		}
 		if (num < 5)
 			return 0;
-		const float rms = (float)((double)sqrtf(avg / (float)num) + 0.00001);
-		const float ratio = sqrtf(norm2(amp0)) / rms;
-		if (ratio < thresh)
+		// The gate "|amp| / (sqrtf(avg/num) + 1e-5) < thresh" is a decision, so it must round as the reference
+		// does -- but two IEEE divisions, two correctly rounded square roots and an fp64 add cost ~45 VALU ops.
+		// A 1-ulp-per-op estimate (total error < 1e-6) decides every burst whose ratio is not within 4e-6 of
+		// the threshold; only those (about one in 1e5) take the exactly rounded path.
+		const float amp2 = norm2(amp0);
+		const float rms_e = __builtin_amdgcn_sqrtf(avg * __builtin_amdgcn_rcpf((float)num)) + 0.00001f;
+		const float ratio_e = __builtin_amdgcn_sqrtf(amp2) * __builtin_amdgcn_rcpf(rms_e);
+		if (ratio_e < thresh * (1.0f - 4e-6f))
 			return 0;
+		if (!(ratio_e > thresh * (1.0f + 4e-6f))) {
+			const float rms = (float)((double)sqrtf(avg / (float)num) + 0.00001);
+			const float ratio = sqrtf(amp2) / rms;
+			if (ratio < thresh)
+				return 0;
+		}
 	}
 
 	// ---- peakDetect (:1695): refined TOA (multiple of 1/512) and interpolated correlation value

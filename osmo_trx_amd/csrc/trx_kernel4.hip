@@ -275,7 +275,13 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 			const int fidx = uni(use_filt ? (int)floorf(frac * (float)TRX_DELAY_FILTS) : TRX_DELAY_FILTS);   // :1057; row 64 = identity
 			// (complex) 1.0 / amp = (1,0) * amp.inv()   (Complex.h:75,144-150)
 			const float an = norm2(amp);
-			const c32 ainv = make_float2(amp.x / an, -amp.y / an);
+			c32 ainv;
+			if (EXACT) {
+				ainv = make_float2(amp.x / an, -amp.y / an);
+			} else {                                                       // fused demodulator: 1-ulp reciprocal instead of two divisions
+				const float ian = __builtin_amdgcn_rcpf(an);
+				ainv = make_float2(amp.x * ian, -amp.y * ian);
+			}
 			const c32 scale = cmul(make_float2(1.0f, 0.0f), ainv);
 			const bool is_edge = (rc == TRXHIP_EDGE);                     // 8-PSK: all 156 symbols go through LDS to edge_post()
 			nbits = is_edge ? 444 : 148;
