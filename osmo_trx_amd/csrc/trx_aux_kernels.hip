@@ -129,17 +129,17 @@ channelize_kernel(const uint32_t *__restrict__ in, c32 *__restrict__ out, size_t
 
 	for (size_t T0 = (size_t)blockIdx.x * CH_TPB; T0 < n_total; T0 += (size_t)gridDim.x * CH_TPB) {
 		__syncthreads();
-		const long long first = ((long long)T0 - (CH_H - 1)) * CH_M;       // first wideband sample needed
-		const int nload = (CH_TPB + CH_H - 1) * CH_M;
-		for (int j = threadIdx.x; j < nload; j += CH_TPB) {
-			const long long s = first + j;
-			c32 v = make_float2(0.0f, 0.0f);
-			if (s >= 0 && (size_t)s < n_total * CH_M) {
-				const uint32_t u = in[s];
-				v = make_float2((float)(int16_t)(u & 0xffffu), (float)(int16_t)(u >> 16));
-			}
-			const int t = j / CH_M, n = j % CH_M;                          // sample n of time t -> path M-1-n
-			xs[CH_M - 1 - n][t] = v;
+		// one 16-byte load per time step: its 4 wideband samples are the 4 paths' inputs (path M-1-n <- sample n)
+		const uint4 *in4 = reinterpret_cast<const uint4 *>(in);
+		for (int t = threadIdx.x; t < CH_TPB + CH_H - 1; t += CH_TPB) {
+			const long long ts = (long long)T0 - (CH_H - 1) + t;               // absolute time step
+			uint4 u = make_uint4(0u, 0u, 0u, 0u);
+			if (ts >= 0 && (size_t)ts < n_total)
+				u = in4[ts];
+			const uint32_t w[4] = { u.x, u.y, u.z, u.w };
+#pragma unroll
+			for (int n = 0; n < CH_M; n++)
+				xs[CH_M - 1 - n][t] = make_float2((float)(int16_t)(w[n] & 0xffffu), (float)(int16_t)(w[n] >> 16));
 		}
 		__syncthreads();
 		const size_t T = T0 + threadIdx.x;
@@ -187,34 +187,52 @@ extern "C" int trx_launch_channelize(const int16_t *d_in, float *d_out, size_t n
 //   out[I] = sum_k in[n - 15 + k] * part[path][k],  n = (q*I)/p,  path = (q*I)%p     (Resampler.cpp:139-147,157-162)
 // (per-block processing with history splice in the reference == the continuous formula, because
 //  q*out_block == p*in_block; zero history before the first sample)
+// Tiling: one workgroup handles TM periods = p*TM outputs from q*TM inputs (+15 of history) staged in LDS with
+// coalesced loads; outputs are written coalesced; taps sit in LDS as [k][path] so that lanes (different
+// paths) spread over the banks.  Index math is 32-bit inside a tile (the tile base is a multiple of the period).
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-resample_kernel(const c32 *__restrict__ in, c32 *__restrict__ out, size_t n_in, size_t n_out, int p, int q,
-		size_t n_chan, size_t in_stride, size_t out_stride, const float *__restrict__ parts)
+#define RS_TPB 256
+#define RS_TILE_IN 3072                                                  // q*TM input samples per tile
+
+__global__ void __launch_bounds__(RS_TPB)
+resample_kernel(const c32 *__restrict__ in, c32 *__restrict__ out, size_t n_in, size_t n_out, int p, int q, int tm,
+		size_t n_tiles, size_t in_stride, size_t out_stride, const float *__restrict__ parts)
 {
-	extern __shared__ float taps_s[];                                  // p x 16
-	for (int i = threadIdx.x; i < p * 16; i += blockDim.x)
-		taps_s[i] = parts[i];
-	__syncthreads();
-	const size_t total = n_chan * n_out;
-	for (size_t o = blockIdx.x * (size_t)blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
-		const size_t c = o / n_out;
-		const size_t I = o - c * n_out;
-		const unsigned long long qi = (unsigned long long)q * I;
-		const long long n = (long long)(qi / p);
-		const int path = (int)(qi % p);
-		const float *h = taps_s + path * 16;
-		const c32 *x = in + c * in_stride;
-		float yr = 0.0f, yi = 0.0f;
-#pragma unroll
-		for (int k = 0; k < 16; k++) {
-			const long long j = n - 15 + k;
-			c32 xv = make_float2(0.0f, 0.0f);
-			if (j >= 0 && (size_t)j < n_in) xv = x[j];
-			yr += xv.x * h[k];
-			yi += xv.y * h[k];
+	extern __shared__ __attribute__((aligned(16))) char rs_smem[];
+	c32 *xs = reinterpret_cast<c32 *>(rs_smem);                          // [15 + q*tm]
+	float *taps = reinterpret_cast<float *>(xs + 16 + q * tm);           // [16][p + 1]
+	const int pst = p + 1;
+	for (int i = threadIdx.x; i < p * 16; i += RS_TPB)
+		taps[(i % 16) * pst + (i / 16)] = parts[i];
+	const size_t chan = blockIdx.y;
+	const c32 *x = in + chan * in_stride;
+	c32 *y = out + chan * out_stride;
+	const int tile_in = q * tm, tile_out = p * tm;
+	for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+		const long long n0 = (long long)tile * tile_in;                    // first input sample of the tile
+		__syncthreads();
+		for (int j = threadIdx.x; j < tile_in + 15; j += RS_TPB) {
+			const long long s = n0 - 15 + j;
+			xs[j] = (s >= 0 && (size_t)s < n_in) ? x[s] : make_float2(0.0f, 0.0f);
 		}
-		out[c * out_stride + I] = make_float2(yr, yi);
+		__syncthreads();
+		const size_t o0 = tile * (size_t)tile_out;
+		for (int o = threadIdx.x; o < tile_out; o += RS_TPB) {
+			if (o0 + o >= n_out)
+				break;
+			const unsigned qi = (unsigned)q * (unsigned)o;
+			const int n = (int)(qi / (unsigned)p), path = (int)(qi % (unsigned)p);
+			const c32 *xp = xs + n;                                        // xs[j] = in[n0 - 15 + j]
+			float yr = 0.0f, yi = 0.0f;
+#pragma unroll
+			for (int k = 0; k < 16; k++) {
+				const c32 xv = xp[k];
+				const float h = taps[k * pst + path];
+				yr += xv.x * h;
+				yi += xv.y * h;
+			}
+			y[o0 + o] = make_float2(yr, yi);
+		}
 	}
 }
 
@@ -222,14 +240,16 @@ extern "C" int trx_launch_resample(const float *d_in, float *d_out, size_t n_in,
 				   size_t in_stride, size_t out_stride, const trx_tables *d_tab, hipStream_t stream)
 {
 	const size_t n_out = n_in / q * p;
-	const size_t total = n_chan * n_out;
-	if (total == 0)
+	if (n_chan * n_out == 0)
 		return 0;
 	const float *parts = (p == 65) ? &d_tab->rs6548_taps[0][0] : &d_tab->dec_taps[0];
-	size_t blocks = (total + 255) / 256;
-	if (blocks > 256 * 8) blocks = 256 * 8;
-	hipLaunchKernelGGL(resample_kernel, dim3((unsigned)blocks), dim3(256), (size_t)p * 16 * sizeof(float), stream,
-			   reinterpret_cast<const c32 *>(d_in), reinterpret_cast<c32 *>(d_out), n_in, n_out, p, q, n_chan,
+	const int tm = RS_TILE_IN / q;
+	const size_t n_tiles = (n_out + (size_t)p * tm - 1) / ((size_t)p * tm);
+	size_t gx = n_tiles;
+	if (gx > 2048) gx = 2048;
+	const size_t lds = (size_t)(16 + q * tm) * sizeof(c32) + (size_t)16 * (p + 1) * sizeof(float);
+	hipLaunchKernelGGL(resample_kernel, dim3((unsigned)gx, (unsigned)n_chan), dim3(RS_TPB), lds, stream,
+			   reinterpret_cast<const c32 *>(d_in), reinterpret_cast<c32 *>(d_out), n_in, n_out, p, q, tm, n_tiles,
 			   in_stride, out_stride, parts);
 	return hipGetLastError() == hipSuccess ? 0 : TRXHIP_EIO;
 }

@@ -283,6 +283,8 @@ int trxhip_channelize_batch(trxhip_ctx *ctx, const int16_t *d_in, float *d_out, 
 		return TRXHIP_EINVAL;
 	if (m != 4 || h_len != 16)
 		return TRXHIP_ENOTSUP;                 /* the reference instantiates Channelizer(4, 192, 16) only */
+	if ((reinterpret_cast<uintptr_t>(d_in) & 15) != 0)
+		return TRXHIP_EINVAL;                  /* one 16-byte load per time step */
 	if (with_device(ctx))
 		return TRXHIP_EIO;
 	return trx_launch_channelize(d_in, d_out, n_blocks * (size_t)block_len, ctx->d_tables,
