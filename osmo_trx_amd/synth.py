@@ -324,3 +324,38 @@ def make_wideband_stream(n_blocks, device="cpu", seed=SEED + 3, m=4, block_len=1
         out = out + base * torch.polar(torch.ones(n, device=device), 2 * math.pi * (k / m) * t)
     noise = torch.randn((n, 2), generator=gen, device=device) * 50.0
     return torch.round(torch.view_as_real(out) + noise).clamp_(-32768, 32767).to(torch.int16).contiguous()
+
+
+def make_multi_arfcn_wideband(n_slots, device="cpu", carriers=(0, 1, 3), seed=SEED + 5, amp=3000.0, noise=20.0, m=4):
+    """BASELINE.json configs[3], end to end: a wideband int16 stream carrying one GSM carrier per filterbank
+    channel in `carriers`, each a back-to-back sequence of 4-SPS normal bursts (625 samples per timeslot).
+    Each carrier is generated at 4 SPS, resampled 48/65 to the channel rate (what Resampler(65,48) undoes),
+    interpolated x4 and shifted to channel k's centre frequency k/m cycles per wideband sample.
+    n_slots must be a multiple of 52 (so that every rate holds an integer number of blocks).
+    Returns (wide int16[n_blocks*192*m, 2], n_blocks, bits uint8[len(carriers), n_slots, 148], tsc uint8[n_slots])."""
+    assert n_slots % 52 == 0
+    device = torch.device(device)
+    gen = _gen(seed, device)
+    n4 = n_slots * 625
+    nc = n4 * 48 // 65
+    nw = nc * m
+    tsc = (torch.arange(n_slots, device=device) % 8).to(torch.uint8)
+    W = torch.zeros(nw, dtype=torch.complex64, device=device)
+    all_bits = []
+    f = torch.fft.fftfreq(nc, device=device)                                # channel-rate bin -> signed index
+    kbin = torch.round(f * nc).to(torch.int64)
+    for k in carriers:
+        bits = normal_burst_bits(n_slots, tsc, gen, device)
+        all_bits.append(bits.cpu().numpy())
+        wave = modulate_laurent_4sps(bits)                                  # [n_slots, 625]
+        phase = torch.rand(n_slots, generator=gen, device=device) * (2 * math.pi)
+        s = (wave * torch.polar(torch.full((n_slots,), float(amp), device=device), phase)[:, None]).reshape(-1)
+        X = torch.fft.fft(s)
+        # keep the nc lowest-frequency bins (48/65 resampling), place them around wideband bin k*nc (x m, shift)
+        idx4 = kbin % n4
+        Y = X[idx4] * (nc / n4)
+        W[(kbin + k * nc) % nw] += Y * m
+    w = torch.fft.ifft(W)
+    out = torch.view_as_real(w) + torch.randn((nw, 2), generator=gen, device=device) * noise
+    wide = torch.round(out).clamp_(-32768, 32767).to(torch.int16).contiguous()
+    return wide, nc // 192, np.stack(all_bits), tsc.cpu().numpy()
