@@ -370,6 +370,70 @@ __device__ __forceinline__ int detect_burst(const c32 *sig, int sig_len, c32 *cz
 
 
 // ------------------------------------------------------------------------------------------------
+// detectAnyBurst() (sigProcLib.cpp:1926-1957) for one burst: up to 3 detectGeneralBurst() windows, first hit wins
+// (TSC; EDGE with fall-through to TSC :1933-1941; RACH / EXT_RACH with TS0..TS2 :1788-1800).
+//   decimate(lo, hi): make sig[lo..hi) valid (4 SPS: downsampleBurst restricted to what the correlation and
+//                     computeCI read, :1587-1601); a no-op at 1 SPS where sig is the burst itself
+//   lseq / lhdr     : LDS sequence table and headers (LSEQ_* layout)
+// Returns rc exactly as detectAnyBurst(): CorrType (>0) | 0 | -SignalError.  Wave-uniform.
+// ------------------------------------------------------------------------------------------------
+struct DetectOut { float toa; c32 amp; float ci; int tsc; };
+
+template <bool PADDED, typename DecimateFn>
+__device__ __forceinline__ int detect_any_burst(int type, int tsc, int max_toa, int clip, DecimateFn decimate,
+						 const c32 *sig, int sig_len, c32 *cz, const c32 *lseq, const float *lhdr,
+						 float thresh, const float *sincv, const PeakConst &pkc, int lane, int slice,
+						 DetectOut *out)
+{
+	int ncand = 0;
+	if (max_toa > TRXHIP_MAX_TOA)
+		return -TRXHIP_SIGERR_UNSUPPORTED;
+	if (type == TRXHIP_TSC || type == TRXHIP_EDGE) {
+		if (tsc > 7)
+			return -TRXHIP_SIGERR_UNSUPPORTED;               // :1893, :1912
+		ncand = (type == TRXHIP_EDGE) ? 2 : 1;
+	} else if (type == TRXHIP_RACH || type == TRXHIP_EXT_RACH) {
+		ncand = (type == TRXHIP_EXT_RACH) ? 3 : 1;           // :1791
+	}
+
+	int dec_lo = 1 << 30, dec_hi = 0;                        // range of sig[] already valid
+	for (int c = 0; c < ncand; c++) {
+		// one detectGeneralBurst() call (:1732-1771): sequence + window
+		int slot, target, head, tail, N;
+		if (type == TRXHIP_RACH || type == TRXHIP_EXT_RACH) {
+			slot = 8 + c; target = 48; head = 8; tail = 8 + max_toa; N = 40;       // :1788-1790
+		} else if (type == TRXHIP_EDGE && c == 0) {
+			slot = 11 + tsc; target = 82; head = 6; tail = 6 + max_toa; N = 16;    // :1915-1918
+		} else {
+			slot = tsc; target = 82; head = 10; tail = 6 + max_toa; N = 16;        // :1896-1899
+		}
+		const c32 *taps = lseq + ((slot < 8) ? LSEQ_TSC(slot) : (slot < 11) ? LSEQ_RACH(slot - 8) : LSEQ_EDGE(slot - 11));
+		const float *hdr = lhdr + 8 * slot;
+		const int start = target - head - 1;                 // :1752
+		const int len = head + tail;                         // :1753
+
+		int lo = start - (N - 1); if (lo < 0) lo = 0;
+		int hi = start + len;     if (hi > sig_len) hi = sig_len;
+		if (lo < dec_lo || hi > dec_hi) {
+			decimate(lo, hi);
+			dec_lo = lo; dec_hi = hi;
+		}
+		float t; c32 a; float cc;
+		const int hit = detect_burst<PADDED>(sig, sig_len, cz, taps, hdr, N, thresh, start, len, sincv, pkc, lane, &t, &a, &cc, slice);
+		wave_sync();
+		if (hit) {
+			out->toa = t - (float)head;                      // :1768
+			out->amp = a;
+			out->ci = cc;
+			if (slot >= 8 && slot < 11) { out->tsc = slot - 8; return type; }    // :1797
+			out->tsc = tsc;
+			return (slot >= 11) ? TRXHIP_EDGE : TRXHIP_TSC;  // :1953-1954
+		}
+	}
+	return (ncand > 0 && clip) ? -TRXHIP_SIGERR_CLIP : 0;    // :1764
+}
+
+// ------------------------------------------------------------------------------------------------
 // 8-PSK tail of demodEdgeBurst() (sigProcLib.cpp:2105-2128) on the 1-SPS burst dec[0..n_dec) (LDS):
 //   eq  = convolve(dec, c0_inv, NO_DELAY)            5 real taps, zero outside            (:2116, :405-422)
 //   rot = derotateEdgeBurst(eq, 1)                   x (cosf(p), -sinf(p)), p = (i%16)*3pi/8  (:691-711)

@@ -198,70 +198,27 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 				amp = make_float2(unif(e.y), unif(e.z));
 				out_tsc = tsc;
 			} else if (type != TRXHIP_IDLE && !ABL(3)) {            // Transceiver.cpp:754-755
-				// ---- detectAnyBurst (:1926-1957): up to 3 candidate windows, first hit wins
-				int ncand = 0;
-				rc = 0;
-				if (max_toa > TRXHIP_MAX_TOA) {
-					rc = -TRXHIP_SIGERR_UNSUPPORTED;
-				} else if (type == TRXHIP_TSC || type == TRXHIP_EDGE) {
-					if (tsc > 7) rc = -TRXHIP_SIGERR_UNSUPPORTED;           // :1893, :1912
-					else ncand = (type == TRXHIP_EDGE) ? 2 : 1;                // EDGE falls through to TSC (:1933-1941)
-				} else if (type == TRXHIP_RACH || type == TRXHIP_EXT_RACH) {
-					ncand = (type == TRXHIP_EXT_RACH) ? 3 : 1;                 // :1791
-				}
-
-				int dec_lo = 1 << 30, dec_hi = 0;
-				int det_type = 0;
-				for (int c = 0; c < ncand; c++) {
-					int slot, target, head, tail, N;
-					if (type == TRXHIP_RACH || type == TRXHIP_EXT_RACH) {
-						slot = 8 + c; target = 48; head = 8; tail = 8 + max_toa; N = 40;       // :1788-1790
-					} else if (type == TRXHIP_EDGE && c == 0) {
-						slot = 11 + tsc; target = 82; head = 6; tail = 6 + max_toa; N = 16;    // :1915-1918
-					} else {
-						slot = tsc; target = 82; head = 10; tail = 6 + max_toa; N = 16;        // :1896-1899
-					}
-					const c32 *taps = lseq + ((slot < 8) ? LSEQ_TSC(slot) : (slot < 11) ? LSEQ_RACH(slot - 8) : LSEQ_EDGE(slot - 11));
-					const float *hdr = lhdr + 8 * slot;
-					const int start = target - head - 1;                   // :1752
-					const int len = head + tail;                           // :1753
-
-					// downsampleBurst (:1587-1601) restricted to what correlate/computeCI read:
-					// dec[i] = sum_k x[4i-15+k] * g[k];  x[4(i-4) + k'] with k' = k+1 -> phase k'&3, m = i-4 + k'>>2
-					int lo = start - (N - 1); if (lo < 0) lo = 0;
-					int hi = start + len;     if (hi > 156) hi = 156;
-					if (lo < dec_lo || hi > dec_hi) {
-						for (int i = lo + lane; i < hi; i += WAVE) {
-							const c32 *pd = P + PH_M0 + i - 4;
-							float yr = 0.0f, yi = 0.0f;
+				// ---- detectAnyBurst (:1926-1957); decimation on the polyphase layout:
+				// dec[i] = sum_k x[4i-15+k] * g[k];  x[4(i-4) + k'] with k' = k+1 -> phase k'&3, m = i-4 + k'>>2
+				auto decimate = [&](int lo, int hi) {
+					for (int i = lo + lane; i < hi; i += WAVE) {
+						const c32 *pd = P + PH_M0 + i - 4;
+						float yr = 0.0f, yi = 0.0f;
 #pragma unroll
-							for (int k = 0; k < 16; k++) {
-								const c32 x = pd[((k + 1) & 3) * PH_A + ((k + 1) >> 2)];
-								const float g = gdec[k];
-								yr += x.x * g;
-								yi += x.y * g;
-							}
-							dec[i] = make_float2(yr, yi);
+						for (int k = 0; k < 16; k++) {
+							const c32 x = pd[((k + 1) & 3) * PH_A + ((k + 1) >> 2)];
+							const float g = gdec[k];
+							yr += x.x * g;
+							yi += x.y * g;
 						}
-						dec_lo = lo; dec_hi = hi;
-						wave_sync();
+						dec[i] = make_float2(yr, yi);
 					}
-					float t; c32 a; float cc;
-					const int hit = detect_burst<true>(dec, 156, cz, taps, hdr, N, thresh, start, len, sincv, pkc, lane, &t, &a, &cc, slice);
 					wave_sync();
-					if (hit) {
-						rc = 1;
-						toa = t - (float)head;                             // :1768
-						amp = a;
-						ci = cc;
-						if (slot >= 8 && slot < 11) { out_tsc = slot - 8; det_type = type; }
-						else if (slot >= 11) { out_tsc = tsc; det_type = TRXHIP_EDGE; }
-						else { out_tsc = tsc; det_type = TRXHIP_TSC; }
-						break;
-					}
-				}
-				if (rc > 0) rc = det_type;                                  // :1953-1954
-				else if (rc == 0 && ncand > 0 && clip) rc = -TRXHIP_SIGERR_CLIP;   // :1764
+				};
+				DetectOut d;
+				rc = detect_any_burst<true>(type, tsc, max_toa, clip, decimate, dec, 156, cz, lseq, lhdr, thresh, sincv, pkc,
+							    lane, slice, &d);
+				if (rc > 0) { toa = d.toa; amp = d.amp; ci = d.ci; out_tsc = d.tsc; }
 			}
 		}
 
