@@ -386,15 +386,15 @@ __device__ __forceinline__ int detect_any_burst(int type, int tsc, int max_toa, 
 						 DetectOut *out)
 {
 	int ncand = 0;
-	if (max_toa > TRXHIP_MAX_TOA)
-		return -TRXHIP_SIGERR_UNSUPPORTED;
 	if (type == TRXHIP_TSC || type == TRXHIP_EDGE) {
 		if (tsc > 7)
 			return -TRXHIP_SIGERR_UNSUPPORTED;               // :1893, :1912
 		ncand = (type == TRXHIP_EDGE) ? 2 : 1;
 	} else if (type == TRXHIP_RACH || type == TRXHIP_EXT_RACH) {
 		ncand = (type == TRXHIP_EXT_RACH) ? 3 : 1;           // :1791
-	}
+	}                                                        // other types: "Invalid correlation type", rc = 0 (:1949-1950)
+	if (ncand > 0 && max_toa > TRXHIP_MAX_TOA)
+		return -TRXHIP_SIGERR_UNSUPPORTED;                   // this implementation's window limit (trxhip.h)
 
 	int dec_lo = 1 << 30, dec_hi = 0;                        // range of sig[] already valid
 	for (int c = 0; c < ncand; c++) {

@@ -246,3 +246,66 @@ def test_edge_8psk_bursts(trx):
     assert np.array_equal(g2_res["rc"], o2_res["rc"]) and np.array_equal(g2_res["toa"], o2_res["toa"])
     assert np.array_equal(g2_soft, o2_soft)
     np.testing.assert_allclose(g2_res["ci"], o2_res["ci"], atol=1e-4)
+
+
+def _fuzz_batch(n, L, rng):
+    """Adversarial mix: random slot types / TSCs / search windows over bursts with wild timing, silence,
+    full-scale saturation, DC, and single impulses."""
+    from osmo_trx_amd import synth
+    iq_nb, p_nb, _ = synth.make_normal_bursts(n, "cpu", 4, seed=int(rng.integers(1 << 30)), max_toa=30,
+                                              delay_sym=(-9.0, 34.0), p_noise=0.1, p_clip=0.05)
+    iq_rb, p_rb, _ = synth.make_access_bursts(n, "cpu", seed=int(rng.integers(1 << 30)), ext=True)
+    iq = iq_nb.clone()
+    pick = torch.from_numpy(rng.random(n) < 0.35)
+    iq[pick] = iq_rb[pick]
+    params = p_nb.copy()
+    params["type"] = rng.choice([O.OFF, O.TSC, O.EXT_RACH, O.RACH, O.SCH, O.EDGE, O.IDLE, 9], size=n,
+                                p=[0.04, 0.4, 0.12, 0.2, 0.02, 0.15, 0.05, 0.02])
+    params["tsc"] = rng.integers(0, 9, size=n)                      # 8 is invalid
+    params["max_toa"] = rng.choice([0, 1, 3, 30, 63, 100, 112, 113, 400], size=n)
+    special = rng.random(n)
+    iq[torch.from_numpy(special < 0.02)] = 0                         # silence: energy 0, rssi inf
+    iq[torch.from_numpy((special >= 0.02) & (special < 0.04))] = 32767
+    iq[torch.from_numpy((special >= 0.04) & (special < 0.05))] = -32768
+    imp = np.where((special >= 0.05) & (special < 0.07))[0]
+    for i in imp:
+        iq[i] = 0
+        iq[i, int(rng.integers(0, 625)), 0] = 20000
+    if L != 625:
+        out = torch.zeros((n, L, 2), dtype=torch.int16)
+        m = min(L, 625)
+        out[:, :m] = iq[:, :m]
+        iq = out
+    return iq, params
+
+
+@pytest.mark.parametrize("L,soft_stride", [(625, 148), (625, 444), (624, 156), (628, 100), (625, 1), (640, 148), (700, 200)])
+def test_fuzz_against_oracle(trx, L, soft_stride):
+    """Random slot types, invalid TSCs, every search-window size (incl. beyond TRXHIP_MAX_TOA), TOAs from -9 to +63
+    symbols, silence / saturation / impulses, burst lengths either side of the fast kernel's range, odd soft strides."""
+    rng = np.random.default_rng(1000 * L + soft_stride)
+    iq, params = _fuzz_batch(768, L, rng)
+    big = params["max_toa"] > 112
+    for slice_bits in (True, False):
+        o_res, o_soft = O.pull_batch(iq.numpy(), 4, params, soft_stride=soft_stride, slice_bits=slice_bits)
+        # documented limit: max_toa > TRXHIP_MAX_TOA is rejected with -SIGERR_UNSUPPORTED instead of searched
+        live = big & ~np.isin(params["type"], [O.OFF, O.IDLE, O.SCH, 9]) & ~((params["tsc"] > 7) & np.isin(params["type"], [O.TSC, O.EDGE]))
+        o_res["rc"][live] = -O.SIGERR_UNSUPPORTED
+        for f in ("toa", "amp_re", "amp_im", "ci", "tsc", "nbits_div4"):
+            o_res[f][live] = 0
+        o_res["idle"][live] = 1
+        o_soft[live] = 0
+        g_res, g_soft = run_gpu(trx, iq, params, 4, soft_stride=soft_stride, slice_bits=slice_bits, exact=True)
+        check_parity(g_res, g_soft, o_res, o_soft)
+        f_res, f_soft = run_gpu(trx, iq, params, 4, soft_stride=soft_stride, slice_bits=slice_bits, exact=False)
+        check_parity(f_res, f_soft, o_res, o_soft, soft_atol=5e-5)
+
+
+def test_no_soft_output_pointer(trx):
+    from osmo_trx_amd import synth
+    iq, params, _ = synth.make_normal_bursts(256, "cpu", 4, seed=3)
+    d_iq, d_p = iq.to("cuda:0"), trx.params_tensor(params)
+    res, _ = trx.detect_demod(d_iq, d_p, sps=4)
+    res2, soft2 = trx.detect_demod(d_iq, d_p, sps=4, want_soft=False)
+    torch.cuda.synchronize()
+    assert soft2 is None and torch.equal(res, res2)
