@@ -183,6 +183,21 @@ int trxhip_channelize_batch(trxhip_ctx *ctx, const int16_t *d_in, float *d_out,
 int trxhip_resample_batch(trxhip_ctx *ctx, const float *d_in, float *d_out, size_t n_in, int p, int q,
 			  size_t n_chan, size_t in_stride, size_t out_stride, void *stream);
 
+/* ---- streaming multi-ARFCN receive front end: RadioInterfaceMulti::pullBuffer(), radioInterfaceMulti.cpp:237-314 ----
+ * Channelizer(4, block_len, 16)::rotate followed by Resampler(p, q, 16)::rotate on every filterbank channel, called
+ * chunk after chunk: the object carries what the reference carries between calls (Channelizer::hist,
+ * Channelizer.cpp:86-88; history[lchan], radioInterfaceMulti.cpp:283-300), so any chunking of a stream gives the
+ * result of processing it in one piece.  (p,q) = (65,48) in RadioInterfaceMulti; RadioInterfaceResamp uses the
+ * same Resampler with (65,96) and (52,75), radioInterfaceResamp.cpp:36-41: block_len must be a multiple of q. */
+typedef struct trxhip_rx_frontend trxhip_rx_frontend;
+int  trxhip_rx_frontend_create(trxhip_ctx *ctx, int block_len, int p, int q, trxhip_rx_frontend **out);
+void trxhip_rx_frontend_destroy(trxhip_rx_frontend *f);
+int  trxhip_rx_frontend_reset(trxhip_rx_frontend *f, void *stream);           /* zero the carried history */
+/* d_wide: n_blocks * block_len * 4 wideband int16 IQ samples (16-byte aligned);
+ * d_out : 4 channels x (n_blocks*block_len*p/q) complex64, channel c at d_out + 2*c*out_stride floats */
+int  trxhip_rx_frontend_pull(trxhip_rx_frontend *f, const int16_t *d_wide, size_t n_blocks, float *d_out,
+			     size_t out_stride, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,10 +69,11 @@ def build_host(force=False):
     shim_src = os.path.join(HOST, "sigProcLib.cpp")
     if not os.path.exists(shim_src):
         return built
+    shim_srcs = [shim_src, os.path.join(HOST, "MultiArfcnRx.cpp")]
     shim = os.path.join(LIBDIR, "libtrxsigproc.so")
-    deps = [shim_src] + [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".h")]
+    deps = shim_srcs + [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".h")]
     if force or _stale(shim, deps + [LIB]):
-        _run([HIPCC, "-shared"] + COMMON + ["-I", HOST, "-I", os.path.join(ROOT, "include"), "-o", shim, shim_src,
+        _run([HIPCC, "-shared"] + COMMON + ["-I", HOST, "-I", os.path.join(ROOT, "include"), "-o", shim] + shim_srcs + [
               "-L", LIBDIR, "-ltrxhip", "-Wl,-rpath,$ORIGIN"])
     built.append(shim)
     for prog in ("sigproc_selftest",):

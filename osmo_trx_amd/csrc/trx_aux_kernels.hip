@@ -118,8 +118,8 @@ extern "C" int trx_launch_convolve(const float *d_x, int x_len, const float *d_h
 #define CH_TPB 256
 
 __global__ void __launch_bounds__(CH_TPB)
-channelize_kernel(const uint32_t *__restrict__ in, c32 *__restrict__ out, size_t n_total,
-		  const trx_tables *__restrict__ tab)
+channelize_kernel(const uint32_t *__restrict__ in, c32 *__restrict__ out, size_t n_total, size_t out_stride,
+		  const trx_tables *__restrict__ tab, const uint4 *__restrict__ hist)
 {
 	// wideband samples (T0-15)*4 .. (T0+TPB)*4 as fp32, stored per path: xs[p][t], t = T - (T0-15)
 	__shared__ c32 xs[CH_M][CH_TPB + CH_H];
@@ -136,6 +136,8 @@ channelize_kernel(const uint32_t *__restrict__ in, c32 *__restrict__ out, size_t
 			uint4 u = make_uint4(0u, 0u, 0u, 0u);
 			if (ts >= 0 && (size_t)ts < n_total)
 				u = in4[ts];
+			else if (ts < 0 && hist)
+				u = hist[(CH_H - 1) + ts];                                     // carried history: time steps -15..-1
 			const uint32_t w[4] = { u.x, u.y, u.z, u.w };
 #pragma unroll
 			for (int n = 0; n < CH_M; n++)
@@ -162,23 +164,50 @@ channelize_kernel(const uint32_t *__restrict__ in, c32 *__restrict__ out, size_t
 			const c32 t2 = make_float2(yp[0].x - yp[2].x, yp[0].y - yp[2].y);
 			const c32 t3 = make_float2(yp[1].x + yp[3].x, yp[1].y + yp[3].y);
 			const c32 t4 = make_float2(yp[1].x - yp[3].x, yp[1].y - yp[3].y);
-			out[0 * n_total + T] = make_float2(t1.x + t3.x, t1.y + t3.y);
-			out[1 * n_total + T] = make_float2(t2.x + t4.y, t2.y - t4.x);   // t2 - j*t4
-			out[2 * n_total + T] = make_float2(t1.x - t3.x, t1.y - t3.y);
-			out[3 * n_total + T] = make_float2(t2.x - t4.y, t2.y + t4.x);   // t2 + j*t4
+			out[0 * out_stride + T] = make_float2(t1.x + t3.x, t1.y + t3.y);
+			out[1 * out_stride + T] = make_float2(t2.x + t4.y, t2.y - t4.x);   // t2 - j*t4
+			out[2 * out_stride + T] = make_float2(t1.x - t3.x, t1.y - t3.y);
+			out[3 * out_stride + T] = make_float2(t2.x - t4.y, t2.y + t4.x);   // t2 + j*t4
 		}
 	}
 }
 
-extern "C" int trx_launch_channelize(const int16_t *d_in, float *d_out, size_t n_total, const trx_tables *d_tab,
-				     hipStream_t stream)
+// tail of a chunk -> history for the next one: the last 15 time steps (wideband) / samples (per channel)
+__global__ void save_wide_hist_kernel(const uint4 *__restrict__ in4, size_t n_total, uint4 *__restrict__ hist)
+{
+	const int t = threadIdx.x;
+	if (t < CH_H - 1) {
+		const long long ts = (long long)n_total - (CH_H - 1) + t;
+		const uint4 v = (ts >= 0) ? in4[ts] : hist[t + (int)n_total];       // chunk shorter than the history: shift
+		__syncthreads();
+		hist[t] = v;
+	}
+}
+
+__global__ void save_chan_hist_kernel(const c32 *__restrict__ x, size_t n_in, size_t in_stride, c32 *__restrict__ hist)
+{
+	const int t = threadIdx.x, c = blockIdx.x;
+	if (t < 15) {
+		const long long s = (long long)n_in - 15 + t;
+		const c32 v = (s >= 0) ? x[c * in_stride + s] : hist[c * 16 + t + (int)n_in];
+		__syncthreads();
+		hist[c * 16 + t] = v;
+	}
+}
+
+extern "C" int trx_launch_channelize(const int16_t *d_in, float *d_out, size_t n_total, size_t out_stride,
+				     const trx_tables *d_tab, void *d_hist_io, hipStream_t stream)
 {
 	if (n_total == 0)
 		return 0;
 	size_t blocks = (n_total + CH_TPB - 1) / CH_TPB;
 	if (blocks > 256 * 8) blocks = 256 * 8;
 	hipLaunchKernelGGL(channelize_kernel, dim3((unsigned)blocks), dim3(CH_TPB), 0, stream,
-			   reinterpret_cast<const uint32_t *>(d_in), reinterpret_cast<c32 *>(d_out), n_total, d_tab);
+			   reinterpret_cast<const uint32_t *>(d_in), reinterpret_cast<c32 *>(d_out), n_total, out_stride, d_tab,
+			   reinterpret_cast<const uint4 *>(d_hist_io));
+	if (d_hist_io)
+		hipLaunchKernelGGL(save_wide_hist_kernel, dim3(1), dim3(64), 0, stream, reinterpret_cast<const uint4 *>(d_in),
+				   n_total, reinterpret_cast<uint4 *>(d_hist_io));
 	return hipGetLastError() == hipSuccess ? 0 : TRXHIP_EIO;
 }
 
@@ -196,7 +225,8 @@ extern "C" int trx_launch_channelize(const int16_t *d_in, float *d_out, size_t n
 
 __global__ void __launch_bounds__(RS_TPB)
 resample_kernel(const c32 *__restrict__ in, c32 *__restrict__ out, size_t n_in, size_t n_out, int p, int q, int tm,
-		size_t n_tiles, size_t in_stride, size_t out_stride, const float *__restrict__ parts)
+		size_t n_tiles, size_t in_stride, size_t out_stride, const float *__restrict__ parts,
+		const c32 *__restrict__ hist)
 {
 	extern __shared__ __attribute__((aligned(16))) char rs_smem[];
 	c32 *xs = reinterpret_cast<c32 *>(rs_smem);                          // [15 + q*tm]
@@ -213,7 +243,10 @@ resample_kernel(const c32 *__restrict__ in, c32 *__restrict__ out, size_t n_in, 
 		__syncthreads();
 		for (int j = threadIdx.x; j < tile_in + 15; j += RS_TPB) {
 			const long long s = n0 - 15 + j;
-			xs[j] = (s >= 0 && (size_t)s < n_in) ? x[s] : make_float2(0.0f, 0.0f);
+			c32 v = make_float2(0.0f, 0.0f);
+			if (s >= 0 && (size_t)s < n_in) v = x[s];
+			else if (s < 0 && hist) v = hist[chan * 16 + 15 + s];               // carried history: samples -15..-1
+			xs[j] = v;
 		}
 		__syncthreads();
 		const size_t o0 = tile * (size_t)tile_out;
@@ -237,12 +270,11 @@ resample_kernel(const c32 *__restrict__ in, c32 *__restrict__ out, size_t n_in, 
 }
 
 extern "C" int trx_launch_resample(const float *d_in, float *d_out, size_t n_in, int p, int q, size_t n_chan,
-				   size_t in_stride, size_t out_stride, const trx_tables *d_tab, hipStream_t stream)
+				   size_t in_stride, size_t out_stride, const float *parts, void *d_hist_io, hipStream_t stream)
 {
 	const size_t n_out = n_in / q * p;
 	if (n_chan * n_out == 0)
 		return 0;
-	const float *parts = (p == 65) ? &d_tab->rs6548_taps[0][0] : &d_tab->dec_taps[0];
 	const int tm = RS_TILE_IN / q;
 	const size_t n_tiles = (n_out + (size_t)p * tm - 1) / ((size_t)p * tm);
 	size_t gx = n_tiles;
@@ -250,7 +282,10 @@ extern "C" int trx_launch_resample(const float *d_in, float *d_out, size_t n_in,
 	const size_t lds = (size_t)(16 + q * tm) * sizeof(c32) + (size_t)16 * (p + 1) * sizeof(float);
 	hipLaunchKernelGGL(resample_kernel, dim3((unsigned)gx, (unsigned)n_chan), dim3(RS_TPB), lds, stream,
 			   reinterpret_cast<const c32 *>(d_in), reinterpret_cast<c32 *>(d_out), n_in, n_out, p, q, tm, n_tiles,
-			   in_stride, out_stride, parts);
+			   in_stride, out_stride, parts, reinterpret_cast<const c32 *>(d_hist_io));
+	if (d_hist_io)
+		hipLaunchKernelGGL(save_chan_hist_kernel, dim3((unsigned)n_chan), dim3(64), 0, stream,
+				   reinterpret_cast<const c32 *>(d_in), n_in, in_stride, reinterpret_cast<c32 *>(d_hist_io));
 	return hipGetLastError() == hipSuccess ? 0 : TRXHIP_EIO;
 }
 

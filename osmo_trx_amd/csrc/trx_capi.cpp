@@ -21,10 +21,10 @@ extern "C" int trx_launch_pack_trxd(const trxhip_burst_result *d_results, const 
 extern "C" int trx_launch_convolve(const float *d_x, int x_len, const float *d_h, int h_len, int h_complex,
 				   float *d_y, int y_len, int start, int len, size_t n_vec, hipStream_t stream);
 extern "C" int trx_launch_convert_short_float(float *d_out, const int16_t *d_in, size_t len, hipStream_t stream);
-extern "C" int trx_launch_channelize(const int16_t *d_in, float *d_out, size_t n_total, const trx_tables *d_tab,
-				     hipStream_t stream);
+extern "C" int trx_launch_channelize(const int16_t *d_in, float *d_out, size_t n_total, size_t out_stride,
+				     const trx_tables *d_tab, void *d_hist_io, hipStream_t stream);
 extern "C" int trx_launch_resample(const float *d_in, float *d_out, size_t n_in, int p, int q, size_t n_chan,
-				   size_t in_stride, size_t out_stride, const trx_tables *d_tab, hipStream_t stream);
+				   size_t in_stride, size_t out_stride, const float *d_parts, void *d_hist_io, hipStream_t stream);
 
 extern "C" int trx_launch_energy_detect(const float *d_x, size_t n_bursts, int burst_len, unsigned window, float *d_out,
 					hipStream_t stream);
@@ -287,8 +287,8 @@ int trxhip_channelize_batch(trxhip_ctx *ctx, const int16_t *d_in, float *d_out, 
 		return TRXHIP_EINVAL;                  /* one 16-byte load per time step */
 	if (with_device(ctx))
 		return TRXHIP_EIO;
-	return trx_launch_channelize(d_in, d_out, n_blocks * (size_t)block_len, ctx->d_tables,
-				     static_cast<hipStream_t>(stream));
+	const size_t n_total = n_blocks * (size_t)block_len;
+	return trx_launch_channelize(d_in, d_out, n_total, n_total, ctx->d_tables, nullptr, static_cast<hipStream_t>(stream));
 }
 
 int trxhip_resample_batch(trxhip_ctx *ctx, const float *d_in, float *d_out, size_t n_in, int p, int q,
@@ -302,8 +302,91 @@ int trxhip_resample_batch(trxhip_ctx *ctx, const float *d_in, float *d_out, size
 		return TRXHIP_EINVAL;                  /* Resampler.cpp:100-104 */
 	if (with_device(ctx))
 		return TRXHIP_EIO;
-	return trx_launch_resample(d_in, d_out, n_in, p, q, n_chan, in_stride, out_stride, ctx->d_tables,
+	const float *parts = (p == 65) ? &ctx->d_tables->rs6548_taps[0][0] : &ctx->d_tables->dec_taps[0];
+	return trx_launch_resample(d_in, d_out, n_in, p, q, n_chan, in_stride, out_stride, parts, nullptr,
 				   static_cast<hipStream_t>(stream));
+}
+
+/* ---- streaming Rx front end: RadioInterfaceMulti::pullBuffer (radioInterfaceMulti.cpp:237-314) ---- */
+struct trxhip_rx_frontend {
+	trxhip_ctx *ctx;
+	int block_len, p, q;
+	float *d_parts;          /* [p][16] resampler partitions */
+	void *d_wide_hist;       /* 15 time steps x 4 int16 IQ samples */
+	void *d_chan_hist;       /* [4][16] complex64 */
+	float *d_chan;           /* [4][cap] channelizer output scratch */
+	size_t cap;
+};
+
+int trxhip_rx_frontend_create(trxhip_ctx *ctx, int block_len, int p, int q, trxhip_rx_frontend **out)
+{
+	if (!ctx || !out || block_len < 16 || p < 1 || q < 1 || p > 128 || q > 3072 || (block_len % q) != 0)
+		return TRXHIP_EINVAL;                  /* Resampler::rotate needs whole q-sample groups per block (Resampler.cpp:100-112) */
+	if (with_device(ctx))
+		return TRXHIP_EIO;
+	trxhip_rx_frontend *f = new (std::nothrow) trxhip_rx_frontend();
+	if (!f)
+		return TRXHIP_ENOMEM;
+	f->ctx = ctx; f->block_len = block_len; f->p = p; f->q = q; f->d_chan = nullptr; f->cap = 0;
+	float *taps = static_cast<float *>(malloc((size_t)p * 16 * sizeof(float)));
+	if (!taps) { delete f; return TRXHIP_ENOMEM; }
+	trx_polyphase_taps((unsigned)p, (unsigned)q, 16, 1.0f, taps);
+	bool ok = hipMalloc((void **)&f->d_parts, (size_t)p * 16 * sizeof(float)) == hipSuccess &&
+		  hipMalloc(&f->d_wide_hist, 16 * 16) == hipSuccess && hipMalloc(&f->d_chan_hist, 4 * 16 * 8) == hipSuccess &&
+		  hipMemcpy(f->d_parts, taps, (size_t)p * 16 * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
+		  hipMemset(f->d_wide_hist, 0, 16 * 16) == hipSuccess && hipMemset(f->d_chan_hist, 0, 4 * 16 * 8) == hipSuccess;
+	free(taps);
+	if (!ok) { trxhip_rx_frontend_destroy(f); return TRXHIP_ENOMEM; }
+	*out = f;
+	return TRXHIP_OK;
+}
+
+void trxhip_rx_frontend_destroy(trxhip_rx_frontend *f)
+{
+	if (!f)
+		return;
+	if (with_device(f->ctx) == 0) {
+		if (f->d_parts) hipFree(f->d_parts);
+		if (f->d_wide_hist) hipFree(f->d_wide_hist);
+		if (f->d_chan_hist) hipFree(f->d_chan_hist);
+		if (f->d_chan) hipFree(f->d_chan);
+	}
+	delete f;
+}
+
+int trxhip_rx_frontend_reset(trxhip_rx_frontend *f, void *stream)
+{
+	if (!f || with_device(f->ctx))
+		return TRXHIP_EINVAL;
+	if (hipMemsetAsync(f->d_wide_hist, 0, 16 * 16, static_cast<hipStream_t>(stream)) != hipSuccess ||
+	    hipMemsetAsync(f->d_chan_hist, 0, 4 * 16 * 8, static_cast<hipStream_t>(stream)) != hipSuccess)
+		return TRXHIP_EIO;
+	return TRXHIP_OK;
+}
+
+int trxhip_rx_frontend_pull(trxhip_rx_frontend *f, const int16_t *d_wide, size_t n_blocks, float *d_out,
+			    size_t out_stride, void *stream)
+{
+	if (!f || !d_wide || !d_out || (reinterpret_cast<uintptr_t>(d_wide) & 15) != 0)
+		return TRXHIP_EINVAL;
+	if (n_blocks == 0)
+		return TRXHIP_OK;
+	if (with_device(f->ctx))
+		return TRXHIP_EIO;
+	const size_t n_total = n_blocks * (size_t)f->block_len;
+	if (out_stride < n_total / f->q * f->p)
+		return TRXHIP_EINVAL;
+	if (n_total > f->cap) {
+		if (f->d_chan) hipFree(f->d_chan);
+		f->d_chan = nullptr;
+		if (hipMalloc((void **)&f->d_chan, 4 * n_total * 8) != hipSuccess) { f->cap = 0; return TRXHIP_ENOMEM; }
+		f->cap = n_total;
+	}
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	int rc = trx_launch_channelize(d_wide, f->d_chan, n_total, f->cap, f->ctx->d_tables, f->d_wide_hist, s);
+	if (rc)
+		return rc;
+	return trx_launch_resample(f->d_chan, d_out, n_total, f->p, f->q, 4, f->cap, out_stride, f->d_parts, f->d_chan_hist, s);
 }
 
 }  // extern "C"

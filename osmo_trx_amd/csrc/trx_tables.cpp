@@ -326,6 +326,7 @@ private:
 		}
 	}
 
+public:
 	// Resampler::initFilters, Resampler.cpp:47-96 (+ its sinc :39-45)
 	static void polyphase(size_t p, size_t q, size_t filt_len, float bw, float *out, size_t out_stride)
 	{
@@ -348,6 +349,7 @@ private:
 				out[n * out_stride + (filt_len - 1 - i)] = proto[i * p + n] * scale;   // stored reversed
 	}
 
+private:
 	// ChannelizerBase::initFilters, ChannelizerBase.cpp:68-134 (+ its sinc :37-43)
 	void channelizer_filters(size_t m, size_t h_len)
 	{
@@ -423,6 +425,11 @@ private:
 };
 
 }  // namespace
+
+void trx_polyphase_taps(unsigned p, unsigned q, unsigned filt_len, float bw, float *out)
+{
+	TableBuilder::polyphase(p, q, filt_len, bw, out, filt_len);
+}
 
 int trx_tables_generate(trx_tables *out)
 {

@@ -72,3 +72,6 @@ int trx_sincv_swz(int q) { return q ^ ((q >> 4) & 31); }
 
 // Host-side generation (no GPU needed).  Returns 0 on success.
 int trx_tables_generate(trx_tables *out);
+
+// Resampler::initFilters (Resampler.cpp:47-96) for an arbitrary rational ratio: out[path * filt_len + k], reversed taps
+void trx_polyphase_taps(unsigned p, unsigned q, unsigned filt_len, float bw, float *out);

@@ -84,6 +84,9 @@ size_t soft_cap(int sps, size_t burst_size) { size_t n = soft_len(sps, burst_siz
 
 }  // namespace
 
+/* the context for the other host classes of the shim (MultiArfcnRx) */
+trxhip_ctx *trx_shim_context(void) { return g_ctx; }
+
 bool sigProcLibSetup()
 {
 	std::lock_guard<std::mutex> lk(g_mu);

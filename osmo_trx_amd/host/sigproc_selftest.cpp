@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "sigProcLib.h"
+#include "MultiArfcnRx.h"
 
 static std::vector<char> slurp(const char *path)
 {
@@ -87,6 +88,31 @@ int main(int argc, char **argv)
 		}
 		fclose(fr);
 		fclose(fs);
+		sigProcLibDestroy();
+		return 0;
+	}
+	// multi <wide.s16> <n_blocks> <chans> <out_prefix>: RadioInterfaceMulti Rx in chunks of 1, 2, 3, ... blocks
+	if (!strcmp(argv[1], "multi") && argc == 6) {
+		std::vector<char> raw = slurp(argv[2]);
+		size_t n_blocks = atol(argv[3]), chans = atol(argv[4]);
+		MultiArfcnRx rx(chans);
+		if (!rx.init()) { fprintf(stderr, "MultiArfcnRx::init failed\n"); return 5; }
+		std::vector<std::vector<complex> > out;
+		const int16_t *w = reinterpret_cast<const int16_t *>(raw.data());
+		size_t pos = 0, step = 1;
+		while (pos < n_blocks) {
+			size_t nb = step < n_blocks - pos ? step : n_blocks - pos;
+			if (rx.pullBuffer(w + pos * 192 * 4 * 2, nb, out)) { fprintf(stderr, "pullBuffer failed\n"); return 6; }
+			pos += nb;
+			step++;
+		}
+		for (size_t l = 0; l < chans; l++) {
+			char path[512];
+			snprintf(path, sizeof(path), "%s%zu.cf32", argv[5], l);
+			FILE *f = fopen(path, "wb");
+			fwrite(out[l].data(), sizeof(complex), out[l].size(), f);
+			fclose(f);
+		}
 		sigProcLibDestroy();
 		return 0;
 	}

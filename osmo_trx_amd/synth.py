@@ -307,7 +307,7 @@ def make_idle_off_mix(params, every=16):
     return p
 
 
-def make_wideband_stream(n_blocks, device="cpu", seed=SEED + 3, m=4, block_len=192):
+def make_wideband_stream(n_blocks, device="cpu", seed=SEED + 3, m=4, block_len=192):  # noqa: D401
     """BASELINE.json configs[3]: wideband int16 stream for the 4-path channelizer: three GMSK-like carriers
     at the filterbank centre frequencies k/4 (k = 0, 1, 3) + noise.  Returns int16[n_blocks*block_len*m, 2]."""
     device = torch.device(device)

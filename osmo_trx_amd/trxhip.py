@@ -61,6 +61,10 @@ SYMBOLS = {
     "trxhip_convert_short_float": (_I, [_VP, _VP, _VP, _SZ, _VP]),
     "trxhip_channelize_batch": (_I, [_VP, _VP, _VP, _SZ, _I, _I, _I, _VP]),
     "trxhip_resample_batch": (_I, [_VP, _VP, _VP, _SZ, _I, _I, _SZ, _SZ, _SZ, _VP]),
+    "trxhip_rx_frontend_create": (_I, [_VP, _I, _I, _I, C.POINTER(_VP)]),
+    "trxhip_rx_frontend_destroy": (None, [_VP]),
+    "trxhip_rx_frontend_reset": (_I, [_VP, _VP]),
+    "trxhip_rx_frontend_pull": (_I, [_VP, _VP, _SZ, _VP, _SZ, _VP]),
 }
 
 
@@ -268,3 +272,37 @@ class TrxHip:
         _check(self.L.trxhip_resample_batch(self.h, self._dev(x), self._dev(out), n_in, p, q, n_chan, n_in, n_out,
                                             self._stream(stream)), "trxhip_resample_batch")
         return out
+
+
+class RxFrontEnd:
+    """Streaming Channelizer(4, block_len, 16) + Resampler(p, q, 16) with carried history (trxhip_rx_frontend_*)."""
+
+    def __init__(self, trx, block_len=192, p=65, q=48):
+        self.trx = trx
+        self.block_len, self.p, self.q = block_len, p, q
+        h = _VP()
+        _check(trx.L.trxhip_rx_frontend_create(trx.h, block_len, p, q, C.byref(h)), "trxhip_rx_frontend_create")
+        self.h = h
+
+    def reset(self, stream=None):
+        _check(self.trx.L.trxhip_rx_frontend_reset(self.h, self.trx._stream(stream)), "trxhip_rx_frontend_reset")
+
+    def pull(self, wide_iq, n_blocks, stream=None):
+        """wide_iq: int16[n_blocks*block_len*4, 2] -> complex64[4, n_blocks*block_len*p/q]"""
+        torch = self.trx.torch
+        n_out = n_blocks * self.block_len // self.q * self.p
+        out = torch.empty((4, n_out), dtype=torch.complex64, device=wide_iq.device)
+        _check(self.trx.L.trxhip_rx_frontend_pull(self.h, self.trx._dev(wide_iq, torch.int16), n_blocks, self.trx._dev(out),
+                                                  n_out, self.trx._stream(stream)), "trxhip_rx_frontend_pull")
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.trx.L.trxhip_rx_frontend_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -278,3 +278,46 @@ def test_multi_arfcn_end_to_end(trx):
         if rc > 0:
             assert e.toa == r["toa"][i] and e.amp[0] == r["amp_re"][i] and e.amp[1] == r["amp_im"][i]
             assert np.array_equal(O.demod_any_burst(xb, rc, 4, e), s[i])
+
+
+@pytest.mark.parametrize("p,q,block_len", [(65, 48, 192), (65, 96, 192), (52, 75, 300)])
+def test_streaming_front_end_any_chunking(trx, p, q, block_len):
+    """trxhip_rx_frontend_*: the reference's per-call history carry (Channelizer.cpp:86-88, radioInterfaceMulti.cpp:
+    283-300).  Any chunking of the stream must give, bit for bit, the one-piece result; the one-piece result is the
+    oracle's (Channelizer blocks + Resampler(p,q) with the RadioInterfaceMulti / RadioInterfaceResamp ratios)."""
+    from osmo_trx_amd import synth
+    from osmo_trx_amd.trxhip import RxFrontEnd
+    n_blocks = 60
+    wide = synth.make_wideband_stream(n_blocks, "cuda:0", block_len=block_len)
+    fe = RxFrontEnd(trx, block_len, p, q)
+    whole = fe.pull(wide, n_blocks)
+    fe.reset()
+    pieces, pos = [], 0
+    for nb in (1, 7, 2, 19, 1, 30):
+        seg = wide[pos * block_len * 4:(pos + nb) * block_len * 4].contiguous()
+        pieces.append(fe.pull(seg, nb))
+        pos += nb
+    assert pos == n_blocks
+    torch.cuda.synchronize()
+    chunked = torch.cat(pieces, dim=1)
+    assert torch.equal(chunked, whole)
+    # oracle: channelizer block by block, then Resampler(p, q) on the continuous channel stream
+    L = O.lib()
+    c = L.orc_channelizer_new(4, block_len, 16)
+    x = wide.cpu().numpy().astype(np.float32).view(np.complex64).reshape(n_blocks, block_len * 4)
+    chan = np.zeros((4, n_blocks * block_len), dtype=np.complex64)
+    for b in range(n_blocks):
+        out = np.zeros((4, block_len), dtype=np.complex64)
+        blk = np.ascontiguousarray(x[b])
+        assert L.orc_channelizer_rotate(c, blk.ctypes.data, block_len * 4, out.ctypes.data) == 0
+        chan[:, b * block_len:(b + 1) * block_len] = out
+    L.orc_channelizer_free(c)
+    r = L.orc_resampler_new(p, q, 16, 1.0)
+    n_in = n_blocks * block_len
+    for k in range(4):
+        padded = np.concatenate([np.zeros(16, dtype=np.complex64), chan[k]])
+        ref = np.zeros(n_in // q * p, dtype=np.complex64)
+        L.orc_resampler_rotate(r, padded[16:].ctypes.data, n_in, ref.ctypes.data, len(ref))
+        assert np.array_equal(whole[k].cpu().numpy().view(np.float32), ref.view(np.float32)), k
+    L.orc_resampler_free(r)
+    fe.close()

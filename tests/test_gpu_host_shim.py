@@ -76,3 +76,32 @@ def test_pull_radio_vector_batch(exe, tmp_path):
     np.testing.assert_allclose(soft[det], o_soft[det], rtol=0, atol=1e-5)
     sure = np.abs(o_soft[det] - 0.5) > 1e-4
     assert np.array_equal((soft[det] > 0.5)[sure], (o_soft[det] > 0.5)[sure])
+
+
+def test_multi_arfcn_rx_class(exe, tmp_path):
+    """MultiArfcnRx = the Rx half of RadioInterfaceMulti (radioInterfaceMulti.cpp:237-314) driven from C++ in chunks of
+    1, 2, 3, ... blocks: logical channels 0,1,2 <- filterbank channels 1,0,3 (getLogicalChan, :87-122), each equal to
+    the oracle's Channelizer + Resampler(65,48) chain on the whole stream."""
+    from osmo_trx_amd import synth
+    n_blocks = 45
+    wide = synth.make_wideband_stream(n_blocks, "cpu")
+    (tmp_path / "w.s16").write_bytes(wide.numpy().tobytes())
+    subprocess.check_call([exe, "multi", str(tmp_path / "w.s16"), str(n_blocks), "3", str(tmp_path / "ch")])
+    L = O.lib()
+    c = L.orc_channelizer_new(4, 192, 16)
+    x = wide.numpy().astype(np.float32).view(np.complex64).reshape(n_blocks, 768)
+    chan = np.zeros((4, n_blocks * 192), dtype=np.complex64)
+    for b in range(n_blocks):
+        out = np.zeros((4, 192), dtype=np.complex64)
+        blk = np.ascontiguousarray(x[b])
+        L.orc_channelizer_rotate(c, blk.ctypes.data, 768, out.ctypes.data)
+        chan[:, b * 192:(b + 1) * 192] = out
+    L.orc_channelizer_free(c)
+    r = L.orc_resampler_new(65, 48, 16, 1.0)
+    for lchan, pchan in ((0, 1), (1, 0), (2, 3)):
+        padded = np.concatenate([np.zeros(16, dtype=np.complex64), chan[pchan]])
+        ref = np.zeros(n_blocks * 260, dtype=np.complex64)
+        L.orc_resampler_rotate(r, padded[16:].ctypes.data, n_blocks * 192, ref.ctypes.data, len(ref))
+        got = np.fromfile(tmp_path / f"ch{lchan}.cf32", dtype=np.complex64)
+        assert np.array_equal(got.view(np.float32), ref.view(np.float32)), lchan
+    L.orc_resampler_free(r)
