@@ -34,8 +34,31 @@ typedef float2 c32;
 // mask so that per-phase cost can be measured on the GPU.  The product library is built without it.
 #ifdef TRX_DIAG
 #define ABL(bit) ((slice >> (8 + (bit))) & 1)
+// per-phase cycle accounting (s_memtime deltas summed over all bursts by lane 0 of every wave)
+#define TRX_DIAG_WAVES 8192
+static __device__ unsigned long long g_trx_diag[TRX_DIAG_WAVES * 24];   // per wave (no atomics); one copy per translation unit
+#define DIAG_DECL unsigned long long diag_acc[24] = {0}; unsigned long long diag_prev = __builtin_readcyclecounter()
+#define DIAG_ARG , unsigned long long *diag_acc, unsigned long long &diag_prev
+#define DIAG_PASS , diag_acc, diag_prev
+#define DIAG_MARK(k)                                                                            \
+	do {                                                                                    \
+		const unsigned long long _t = __builtin_readcyclecounter();                     \
+		diag_acc[k] += _t - diag_prev;                                                  \
+		diag_prev = _t;                                                                 \
+	} while (0)
+#define DIAG_FLUSH()                                                                            \
+	do {                                                                                    \
+		const unsigned _w = (blockIdx.x * 16 + (threadIdx.x >> 6)) % TRX_DIAG_WAVES;    \
+		if ((threadIdx.x & 63) == 0)                                                    \
+			for (int _k = 0; _k < 24; _k++) g_trx_diag[_w * 24 + _k] += diag_acc[_k]; \
+	} while (0)
 #else
 #define ABL(bit) 0
+#define DIAG_DECL
+#define DIAG_ARG
+#define DIAG_PASS
+#define DIAG_MARK(k)
+#define DIAG_FLUSH()
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -249,7 +272,7 @@ __device__ __forceinline__ void peak_detect_spec(const c32 *cz, int max_idx, con
 template <bool PADDED>
 __device__ __forceinline__ int detect_burst(const c32 *sig, int sig_len, c32 *cz, const c32 *taps, const float *hdr,
 					     int N, float thresh, int start, int len, const float *sincv, const PeakConst &pc, int lane,
-					     float *toa_out, c32 *amp_out, float *ci_out, int slice)
+					     float *toa_out, c32 *amp_out, float *ci_out, int slice DIAG_ARG)
 {
 	// ---- correlate: corr[i] = sum_k SIG(i + start - (N-1) + k) * seq[k]   (:1674, convolve_base.c:72-85)
 	// N is 16 (TSC/EDGE) or 40 (RACH): tap loop unrolled by 8 so the LDS reads pipeline
@@ -282,6 +305,7 @@ __device__ __forceinline__ int detect_burst(const c32 *sig, int sig_len, c32 *cz
 	if (lane < TRX_CZ_PAD)
 		cz[len + lane] = make_float2(0.0f, 0.0f);    // right zero pad (len varies per burst)
 
+	DIAG_MARK(3);
 	// arg-max across lanes: wave max (DPP), then the lowest index holding it (ballot + scalar ff1)
 	const float m = wave_max(best);
 	if (!(m > 0.0f))
@@ -297,6 +321,7 @@ __device__ __forceinline__ int detect_burst(const c32 *sig, int sig_len, c32 *cz
 	const c32 amp0 = cz[bidx];
 
 	if (ABL(9)) { *toa_out = (float)bidx; *amp_out = amp0; *ci_out = 0.0f; return 1; }
+	DIAG_MARK(4);
 	// ---- computePeakRatio (:1541-1571): terms in the reference's order; out-of-range terms read the
 	// zero pads (adding +0 is exact), their count is arithmetic
 	{
@@ -327,6 +352,7 @@ __device__ __forceinline__ int detect_burst(const c32 *sig, int sig_len, c32 *cz
 		}
 	}
 
+	DIAG_MARK(5);
 	// ---- peakDetect (:1695): refined TOA (multiple of 1/512) and interpolated correlation value
 	int toa512;
 	c32 xcorr;
@@ -342,6 +368,7 @@ __device__ __forceinline__ int detect_burst(const c32 *sig, int sig_len, c32 *cz
 	xcorr.y = unif(xcorr.y);
 	const float toa = (float)toa512 * (1.0f / 512.0f);   // exact
 
+	DIAG_MARK(6);
 	// ---- computeCI (:1608-1639)
 	float ci = 0.0f;
 	{
@@ -365,6 +392,7 @@ __device__ __forceinline__ int detect_burst(const c32 *sig, int sig_len, c32 *cz
 	*amp_out = cmul(xcorr, make_float2(hdr[2], hdr[3]));   // xcorr / sync->gain  (:1701)
 	*toa_out = unif(toa - hdr[5]);                           // :1704
 	*ci_out = ci;
+	DIAG_MARK(7);
 	return 1;
 }
 
@@ -383,7 +411,7 @@ template <bool PADDED, typename DecimateFn>
 __device__ __forceinline__ int detect_any_burst(int type, int tsc, int max_toa, int clip, DecimateFn decimate,
 						 const c32 *sig, int sig_len, c32 *cz, const c32 *lseq, const float *lhdr,
 						 float thresh, const float *sincv, const PeakConst &pkc, int lane, int slice,
-						 DetectOut *out)
+						 DetectOut *out DIAG_ARG)
 {
 	int ncand = 0;
 	if (type == TRXHIP_TSC || type == TRXHIP_EDGE) {
@@ -418,8 +446,9 @@ __device__ __forceinline__ int detect_any_burst(int type, int tsc, int max_toa, 
 			decimate(lo, hi);
 			dec_lo = lo; dec_hi = hi;
 		}
+		DIAG_MARK(2);
 		float t; c32 a; float cc;
-		const int hit = detect_burst<PADDED>(sig, sig_len, cz, taps, hdr, N, thresh, start, len, sincv, pkc, lane, &t, &a, &cc, slice);
+		const int hit = detect_burst<PADDED>(sig, sig_len, cz, taps, hdr, N, thresh, start, len, sincv, pkc, lane, &t, &a, &cc, slice DIAG_PASS);
 		wave_sync();
 		if (hit) {
 			out->toa = t - (float)head;                      // :1768

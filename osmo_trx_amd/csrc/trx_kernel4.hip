@@ -29,6 +29,22 @@
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+#ifdef TRX_DIAG
+extern "C" int trxhip_diag_read(unsigned long long *out, int reset)
+{
+	static unsigned long long h[TRX_DIAG_WAVES * 24];
+	if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_trx_diag), sizeof(h)) != hipSuccess) return -1;
+	for (int k = 0; k < 32; k++) out[k] = 0;
+	for (int w = 0; w < TRX_DIAG_WAVES; w++)
+		for (int k = 0; k < 24; k++) out[k] += h[w * 24 + k];
+	if (reset) {
+		for (size_t i = 0; i < sizeof(h) / sizeof(h[0]); i++) h[i] = 0;
+		if (hipMemcpyToSymbol(HIP_SYMBOL(g_trx_diag), h, sizeof(h)) != hipSuccess) return -1;
+	}
+	return 0;
+}
+#endif
+
 __device__ __forceinline__ int fdiv(int a, int b) { const int q = a / b; return (a % b != 0 && a < 0) ? q - 1 : q; }   // b > 0
 __device__ __forceinline__ int cdiv(int a, int b) { return -fdiv(-a, b); }
 
@@ -147,6 +163,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 	// loader address: sample r*64 + lane -> phase lane&3, m = 16r + lane>>2
 	c32 *const pload = P + (lane & 3) * PH_A + PH_M0 + (lane >> 2);
 
+	DIAG_DECL;
 	for (unsigned b = first; b < n_bursts; b += total_waves) {
 		// Re-materialise the lane id per burst (2 VALU ops): otherwise every lane-derived address, tree-node
 		// offset and LUT base of every phase is hoisted out of this loop and kept live across it, which
@@ -154,6 +171,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 		int lane;
 		asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
 		const unsigned prm0 = (unsigned)uni((int)pre_prm);
+		DIAG_MARK(13);
 		const int type = prm0 & 0xff;
 		const int tsc = (prm0 >> 8) & 0xff;
 		const int max_toa = prm0 >> 16;
@@ -180,8 +198,10 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 						epart += norm2(v);
 			}
 		}
+		DIAG_MARK(14);
 		if (b + total_waves < n_bursts)
 			prefetch(b + total_waves);
+		DIAG_MARK(15);
 
 		if (type != TRXHIP_OFF) {                                   // Transceiver.cpp:704-707
 			amax = wave_max(amax);                                  // maxAmplitude(), :1711-1722
@@ -190,6 +210,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 			if (!ABL(2))
 				rssi = fs_db - 3.01029996f * __log2f(energy);       // 20*log10(fs/sqrt(e)), Transceiver.cpp:741,751
 			wave_sync();
+			DIAG_MARK(1);
 
 			if (ebp_in) {
 				const float4 e = ebp_in[b];
@@ -217,7 +238,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 				};
 				DetectOut d;
 				rc = detect_any_burst<true>(type, tsc, max_toa, clip, decimate, dec, 156, cz, lseq, lhdr, thresh, sincv, pkc,
-							    lane, slice, &d);
+							    lane, slice, &d DIAG_PASS);
 				if (rc > 0) { toa = d.toa; amp = d.amp; ci = d.ci; out_tsc = d.tsc; }
 			}
 		}
@@ -378,9 +399,11 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 					if (t == 0)
 						edge[slot + e] = cmul(make_float2(sr, si), scale);
 				};
+				DIAG_MARK(8);
 				if (need_lo && !ABL(6)) edge_round(i0l, 0);
 				if (need_hi && !ABL(6)) edge_round(i0h, 4);
 
+				DIAG_MARK(9);
 				const float4 *c4 = reinterpret_cast<const float4 *>(comp + fidx * 36);   // 35 taps, LDS broadcast reads
 				const int c = -24 - w;
 				const int i_min = cdiv(-36 - c, 4), i_max = fdiv(L + 1 - c, 4);
@@ -422,6 +445,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 							__builtin_amdgcn_sched_barrier(0);
 						}
 					}
+					DIAG_MARK(10);
 					// pin the three sums here: without it LLVM sinks all 105 FMAs below the per-output predicates
 					// and keeps every LDS operand alive (170 spilled VGPRs)
 #pragma unroll
@@ -465,6 +489,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 					so[i] = 0.0f;
 		}
 
+		DIAG_MARK(11);
 		// ---- result record: 32 bytes, one dword per lane 0..7
 		if (lane < 8) {
 			const bool det = rc > 0;
@@ -479,7 +504,9 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 					      ((uint32_t)(nbits / 4) << 24)) : word;
 			reinterpret_cast<uint32_t *>(results + b)[lane] = word;
 		}
+		DIAG_MARK(12);
 	}
+	DIAG_FLUSH();
 }
 
 extern "C" int trx_launch_pull4(const void *d_iq, int cf32, const trxhip_burst_params *d_params,
@@ -490,10 +517,16 @@ extern "C" int trx_launch_pull4(const void *d_iq, int cf32, const trxhip_burst_p
 	if (n_bursts == 0)
 		return 0;
 	const bool exact = (flags & TRXHIP_FLAG_EXACT_DEMOD) != 0;      // two kernels: the demodulator is a compile-time choice
-	const int wpb = exact ? K4_WPB_EXACT : K4_WPB_FUSED;
+	int wpb = exact ? K4_WPB_EXACT : K4_WPB_FUSED;
+#ifdef TRX_DIAG
+	if (const char *e = getenv("TRXHIP_WPB")) { const int v = atoi(e); if (v >= 1 && v <= wpb) wpb = v; }   // occupancy scan
+#endif
 	const size_t lds = K4_TABLES_BYTES + (size_t)wpb * K4_SLICE * sizeof(c32);
 	size_t need = (n_bursts + wpb - 1) / wpb;
 	size_t grid = (size_t)n_cu;
+#ifdef TRX_DIAG
+	if (const char *e = getenv("TRXHIP_GRID")) { const int v = atoi(e); if (v >= 1) grid = (size_t)v; }
+#endif
 	if (grid > need) grid = need;
 #define LAUNCH4(CF_, EX_)                                                                                       \
 	do {                                                                                                    \

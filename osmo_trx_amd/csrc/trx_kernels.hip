@@ -119,6 +119,7 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 	if (first < n_bursts)
 		prefetch(first);
 
+	DIAG_DECL;
 	for (unsigned b = first; b < n_bursts; b += total_waves) {
 		const unsigned prm0 = (unsigned)uni((int)pre_prm);
 		const int type = prm0 & 0xff;
@@ -209,11 +210,11 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 						wave_sync();
 					};
 					rc = detect_any_burst<true>(type, tsc, max_toa, clip, decimate, dec, 156, cz, lseq, lhdr, thresh, sincv,
-								    pkc, lane, slice, &d);
+								    pkc, lane, slice, &d DIAG_PASS);
 				} else {
 					auto nothing = [](int, int) {};
 					rc = detect_any_burst<false>(type, tsc, max_toa, clip, nothing, xs, L, cz, lseq, lhdr, thresh, sincv,
-								     pkc, lane, slice, &d);
+								     pkc, lane, slice, &d DIAG_PASS);
 				}
 				if (rc > 0) { toa = d.toa; amp = d.amp; ci = d.ci; out_tsc = d.tsc; }
 			}
