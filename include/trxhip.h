@@ -149,6 +149,17 @@ int trxhip_demod_batch_cf32(trxhip_ctx *ctx, const float *d_iq_cf32, const trxhi
 			    const float *d_ebp, trxhip_burst_result *d_results, float *d_soft,
 			    size_t n_bursts, int burst_len, int sps, int soft_stride, int flags, void *stream);
 
+/* detectSCHBurst() (sigProcLib.h:139-148, sigProcLib.cpp:1805-1861), the MS-side synchronisation-burst search, for
+ * n_bufs independent buffers of buf_len complex64 samples at 4 samples per symbol.  `state` is sch_detect_type in the
+ * reference's order; the search covers len = 156 (FULL), 8 (NARROW) or 15000 (BUFFER, 12 frames) symbol positions of
+ * the first 4*len samples (the reference decimates by 4 whatever `sps` says, :1841), so buf_len >= 4*len is required
+ * (the reference asserts, Vector.h:236-237).  sps other than 1 or 4 is the reference's "return -1": -TRXHIP_EINVAL.
+ * d_results[b]: rc = 1 / 0 (detectBurst()'s return), toa (symbols, head or 3+39+64 already subtracted, :1853-1858),
+ * amp, ci; toa = amp = 0 on a miss (:1846-1850); the other fields are zero. */
+enum { TRXHIP_SCH_DETECT_FULL = 0, TRXHIP_SCH_DETECT_NARROW = 1, TRXHIP_SCH_DETECT_BUFFER = 2 };
+int trxhip_detect_sch_batch_cf32(trxhip_ctx *ctx, const float *d_iq_cf32, trxhip_burst_result *d_results,
+				 size_t n_bufs, size_t buf_len, int sps, int state, float threshold, void *stream);
+
 /* energyDetect() on its own (sigProcLib.h:105, sigProcLib.cpp:1573-1585): mean |x|^2 of `window` samples at
  * stride 4 from sample 0 of each burst (complex64); d_energy: n_bursts floats. */
 int trxhip_energy_detect_batch_cf32(trxhip_ctx *ctx, const float *d_iq_cf32, size_t n_bursts, int burst_len,

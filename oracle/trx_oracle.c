@@ -747,29 +747,12 @@ static float compute_ci(const orc_cf *burst, int burst_size, const orc_corr_seq 
 	return 3.0103f * log2f(C / (S - C));
 }
 
-/* sigProcLib.cpp:1649-1709 */
-static int detect_burst(const orc_cf *burst, int n, orc_cf *corr, const orc_corr_seq *sync,
-			float thresh, int sps, int start, int len, orc_ebp *ebp)
+/* sigProcLib.cpp:1672-1708: detectBurst() from the correlation onwards (corr_in is at 1 SPS) */
+static int detect_burst_1sps(const orc_cf *corr_in, int corr_in_len, orc_cf *corr, const orc_corr_seq *sync,
+			     float thresh, int start, int len, orc_ebp *ebp)
 {
-	orc_cf dec[160];
-	const orc_cf *corr_in;
-	int corr_in_len;
+	const int sps = 1;
 	orc_cf xcorr;
-
-	switch (sps) {
-	case 1:
-		corr_in = burst;
-		corr_in_len = n;
-		break;
-	case 4:
-		downsample_burst(burst, 624, dec, 156);
-		corr_in = dec;
-		corr_in_len = 156;
-		sps = 1;
-		break;
-	default:
-		return -1;
-	}
 
 	/* Correlate :1674 (CUSTOM span) */
 	conv_span(corr_in, corr_in_len, sync->seq, sync->n, 0, corr, start, len);
@@ -787,6 +770,75 @@ static int detect_burst(const orc_cf *burst, int n, orc_cf *corr, const orc_corr
 	ebp->amp = cdiv(xcorr, sync->gain);
 	ebp->toa = ebp->toa - sync->toa;
 	return 1;
+}
+
+/* sigProcLib.cpp:1649-1709 */
+static int detect_burst(const orc_cf *burst, int n, orc_cf *corr, const orc_corr_seq *sync,
+			float thresh, int sps, int start, int len, orc_ebp *ebp)
+{
+	orc_cf dec[160];
+
+	switch (sps) {
+	case 1:
+		return detect_burst_1sps(burst, n, corr, sync, thresh, start, len, ebp);
+	case 4:
+		downsample_burst(burst, 624, dec, 156);
+		return detect_burst_1sps(dec, 156, corr, sync, thresh, start, len, ebp);
+	default:
+		return -1;
+	}
+}
+
+/* sigProcLib.cpp:1805-1861 detectSCHBurst.  The burst is always decimated by 4 here (:1841), whatever `sps`
+ * says, and only its first 4*len samples are used; n < 4*len trips the reference's copyToSegment assertion
+ * (Vector.h:236-237) and returns -1 here. */
+int orc_detect_sch_burst(const orc_cf *burst, int n, float thresh, int sps, int state, orc_ebp *ebp)
+{
+	if (!T_ready) orc_setup();
+	int rc, start, target, head, tail, len;
+
+	if ((sps != 1) && (sps != 4))
+		return -1;
+
+	target = 3 + 39 + 64;
+	switch (state) {
+	case ORC_SCH_DETECT_NARROW:
+		head = 4;
+		tail = 4;
+		break;
+	case ORC_SCH_DETECT_BUFFER:
+		target = 1;
+		head = 0;
+		tail = (12 * 8 * 625) / 4;
+		break;
+	case ORC_SCH_DETECT_FULL:
+	default:
+		head = target - 1;
+		tail = 39 + 3 + 9;
+		break;
+	}
+	start = (target - head) * 1 - 1;
+	len = (head + tail) * 1;
+	if (n < len * 4)
+		return -1;
+
+	orc_cf *corr = malloc(2 * (size_t)len * sizeof(orc_cf)), *dec = corr + len;
+	downsample_burst(burst, len * 4, dec, len);
+	rc = detect_burst_1sps(dec, len, corr, &T.sch, thresh, start, len, ebp);
+	free(corr);
+
+	if (rc < 0) {
+		return -1;
+	} else if (!rc) {
+		ebp->amp = cf(0.0f, 0.0f);
+		ebp->toa = 0.0f;
+		return 0;
+	}
+	if (state == ORC_SCH_DETECT_BUFFER)
+		ebp->toa = ebp->toa - (3 + 39 + 64);
+	else
+		ebp->toa = ebp->toa - head;
+	return rc;
 }
 
 /* sigProcLib.cpp:1711-1722 */

@@ -104,6 +104,10 @@ int   orc_detect_any_burst(const orc_cf *burst, int n, unsigned tsc, float thres
 			   int type, unsigned max_toa, orc_ebp *ebp);
 /* demodAnyBurst :2130-2137 -> number of soft values written (156 @4sps GMSK, n @1sps, 444 EDGE), <0 error */
 int   orc_demod_any_burst(const orc_cf *burst, int n, int type, int sps, orc_ebp *ebp, float *soft);
+
+/* sigProcLib.h:139-148 detectSCHBurst (sch_detect_type in the reference's order) */
+enum { ORC_SCH_DETECT_FULL = 0, ORC_SCH_DETECT_NARROW = 1, ORC_SCH_DETECT_BUFFER = 2 };
+int   orc_detect_sch_burst(const orc_cf *burst, int n, float thresh, int sps, int state, orc_ebp *ebp);
 /* modulateBurst :970-979; returns number of samples written to out (<= 640) */
 int   orc_modulate_burst(const uint8_t *bits, int nbits, int guard, int sps, int empty_pulse, orc_cf *out);
 /* modulateEdgeBurst(bits, 4, false) :917-936 -> 625 samples */

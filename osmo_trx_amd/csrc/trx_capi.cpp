@@ -28,6 +28,9 @@ extern "C" int trx_launch_resample(const float *d_in, float *d_out, size_t n_in,
 
 extern "C" int trx_launch_energy_detect(const float *d_x, size_t n_bursts, int burst_len, unsigned window, float *d_out,
 					hipStream_t stream);
+extern "C" int trx_launch_sch_detect(const float *d_iq, size_t buf_stride, trxhip_burst_result *d_results,
+				     const trx_tables *d_tab, size_t n_bufs, int len, int start, int toa_sub, float thresh,
+				     hipStream_t stream);
 extern "C" int trx_launch_vector_slicer(float *d_dst, const float *d_src, size_t len, hipStream_t stream);
 
 struct trxhip_ctx {
@@ -265,6 +268,33 @@ int trxhip_energy_detect_batch_cf32(trxhip_ctx *ctx, const float *d_iq, size_t n
 	if (with_device(ctx))
 		return TRXHIP_EIO;
 	return trx_launch_energy_detect(d_iq, n_bursts, burst_len, window, d_energy, static_cast<hipStream_t>(stream));
+}
+
+int trxhip_detect_sch_batch_cf32(trxhip_ctx *ctx, const float *d_iq, trxhip_burst_result *d_results, size_t n_bufs,
+				 size_t buf_len, int sps, int state, float threshold, void *stream)
+{
+	if (!ctx || (sps != 1 && sps != 4))
+		return TRXHIP_EINVAL;                  /* sigProcLib.cpp:1814-1815 */
+	/* window of the search (:1817-1838) */
+	int target = 3 + 39 + 64, head, tail;
+	switch (state) {
+	case TRXHIP_SCH_DETECT_NARROW: head = 4; tail = 4; break;
+	case TRXHIP_SCH_DETECT_BUFFER: target = 1; head = 0; tail = (12 * 8 * 625) / 4; break;
+	case TRXHIP_SCH_DETECT_FULL:
+	default: head = target - 1; tail = 39 + 3 + 9; break;
+	}
+	const int start = (target - head) * 1 - 1, len = (head + tail) * 1;
+	if (buf_len < 4 * (size_t)len)
+		return TRXHIP_EINVAL;
+	if (n_bufs == 0)
+		return TRXHIP_OK;
+	if (!d_iq || !d_results)
+		return TRXHIP_EINVAL;
+	if (with_device(ctx))
+		return TRXHIP_EIO;
+	const int toa_sub = (state == TRXHIP_SCH_DETECT_BUFFER) ? 3 + 39 + 64 : head;      /* :1853-1858 */
+	return trx_launch_sch_detect(d_iq, buf_len, d_results, ctx->d_tables, n_bufs, len, start, toa_sub, threshold,
+				     static_cast<hipStream_t>(stream));
 }
 
 int trxhip_vector_slicer(trxhip_ctx *ctx, float *d_dest, const float *d_src, size_t len, void *stream)

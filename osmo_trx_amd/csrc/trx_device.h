@@ -264,6 +264,101 @@ __device__ __forceinline__ void peak_detect_spec(const c32 *cz, int max_idx, con
 }
 
 // ------------------------------------------------------------------------------------------------
+// detectBurst() after fastPeakDetect (sigProcLib.cpp:1683-1708): edge gate, computePeakRatio gate, peakDetect,
+// computeCI, amp and toa.  One wave; `bidx` is the wave-uniform index of the first strict maximum of |corr|^2.
+//   cz     : correlation with TRX_CZ_PAD zeros either side; only cz[bidx-12 .. bidx+12] is read, so a caller
+//            with a long correlation (SCH buffer search) may pass a 25-sample window, biased so that it is
+//            indexed by the absolute position (WINDOWED: the ":1105" zeroing of cz[len-1] is then range-checked)
+//   sig    : what was correlated (computeCI reads N samples of it), sig_len its length
+//   hdr    : {gain.re, gain.im, ginv.re, ginv.im, ci_den, toa, n, 1/ci_den}
+// ------------------------------------------------------------------------------------------------
+template <bool WINDOWED>
+__device__ __forceinline__ int detect_tail(const c32 *sig, int sig_len, c32 *cz, const float *hdr, int N, float thresh,
+					    int start, int len, int bidx, const float *sincv, const PeakConst &pc, int lane,
+					    float *toa_out, c32 *amp_out, float *ci_out, int slice DIAG_ARG)
+{
+	if ((bidx < 3) || (bidx > len - 3))               // :1683
+		return 0;
+	wave_sync();
+	const c32 amp0 = cz[bidx];
+
+	if (ABL(9)) { *toa_out = (float)bidx; *amp_out = amp0; *ci_out = 0.0f; return 1; }
+	DIAG_MARK(4);
+	// ---- computePeakRatio (:1541-1571): terms in the reference's order; out-of-range terms read the
+	// zero pads (adding +0 is exact), their count is arithmetic
+	{
+		float avg = 0.0f;
+		int num = 0;
+#pragma unroll
+		for (int i = 2; i <= 5; i++) {
+			avg += norm2(cz[bidx - i]);
+			avg += norm2(cz[bidx + i]);              // bidx + i >= len reads zeros (pad = 12 > 5)
+			num += (bidx - i >= 0) + (bidx + i < len);
+		}
+		if (num < 5)
+			return 0;
+		// The gate "|amp| / (sqrtf(avg/num) + 1e-5) < thresh" is a decision, so it must round as the reference
+		// does -- but two IEEE divisions, two correctly rounded square roots and an fp64 add cost ~45 VALU ops.
+		// A 1-ulp-per-op estimate (total error < 1e-6) decides every burst whose ratio is not within 4e-6 of
+		// the threshold; only those (about one in 1e5) take the exactly rounded path.
+		const float amp2 = norm2(amp0);
+		const float rms_e = __builtin_amdgcn_sqrtf(avg * __builtin_amdgcn_rcpf((float)num)) + 0.00001f;
+		const float ratio_e = __builtin_amdgcn_sqrtf(amp2) * __builtin_amdgcn_rcpf(rms_e);
+		if (ratio_e < thresh * (1.0f - 4e-6f))
+			return 0;
+		if (!(ratio_e > thresh * (1.0f + 4e-6f))) {
+			const float rms = (float)((double)sqrtf(avg / (float)num) + 0.00001);
+			const float ratio = sqrtf(amp2) / rms;
+			if (ratio < thresh)
+				return 0;
+		}
+	}
+
+	DIAG_MARK(5);
+	// ---- peakDetect (:1695): refined TOA (multiple of 1/512) and interpolated correlation value
+	int toa512;
+	c32 xcorr;
+	// interpolatePoint() never reads the last correlation sample (:1105, :1109): zero it in the padded copy
+	if (lane == 0 && (!WINDOWED || len - 1 - bidx <= TRX_CZ_PAD))
+		cz[len - 1] = make_float2(0.0f, 0.0f);
+	wave_sync();
+	if (ABL(1)) { toa512 = bidx * 512; xcorr = amp0; }
+	else
+		peak_detect_spec(cz, bidx, sincv, pc, lane, &toa512, &xcorr);
+	toa512 = uni(toa512);
+	xcorr.x = unif(xcorr.x);
+	xcorr.y = unif(xcorr.y);
+	const float toa = (float)toa512 * (1.0f / 512.0f);   // exact
+
+	DIAG_MARK(6);
+	// ---- computeCI (:1608-1639)
+	float ci = 0.0f;
+	{
+		// roundf(toa): toa is k/512 -> round half away from zero on integers
+		const int rt = (toa512 >= 0) ? ((toa512 + 256) >> 9) : -((-toa512 + 256) >> 9);
+		const int ps = start + 1 - N + rt;
+		if (ps >= 0 && ps + N <= sig_len && !ABL(7)) {
+			// S = sum_i |sig[ps+i]|^2 in index order: lane i squares one sample, the sum walks the lanes
+			const float pw = norm2(sig[ps + (lane < N ? lane : 0)]);
+			float S = 0.0f;
+			for (int i = 0; i < N; i++)
+				S += lane_val(pw, i);
+			// C/I is an analogue report (tolerance 2e-5 dB in the tests): reciprocal-multiplies and the
+			// hardware log2 instead of three IEEE divisions and a software log
+			S *= (N == 16) ? 0.0625f : (N == 64) ? 0.015625f : 0.025f;   // S /= N  (N is 16, 40 or 64)
+			const float C = norm2(xcorr) * hdr[7];           // / ((N-1)*|gain|), reciprocal from the table
+			ci = 3.0103f * __log2f(C * __builtin_amdgcn_rcpf(S - C));
+		}
+	}
+
+	*amp_out = cmul(xcorr, make_float2(hdr[2], hdr[3]));   // xcorr / sync->gain  (:1701)
+	*toa_out = unif(toa - hdr[5]);                           // :1704
+	*ci_out = ci;
+	DIAG_MARK(7);
+	return 1;
+}
+
+// ------------------------------------------------------------------------------------------------
 // detectBurst() on the 1-SPS signal `sig` (sigProcLib.cpp:1649-1709); correlation kept in LDS (cz).
 //   PADDED: sig is readable (zero) over the whole correlation window, no range checks (4 SPS: dec[])
 //   taps  : LDS, wave-uniform -> broadcast reads; hdr: {gain.re, gain.im, ginv.re, ginv.im, ci_den, toa}
@@ -315,85 +410,7 @@ __device__ __forceinline__ int detect_burst(const c32 *sig, int sig_len, c32 *cz
 		const unsigned long long hit_lo = __ballot(best == m && bidx == lane);
 		bidx = hit_lo ? (__ffsll((unsigned long long)hit_lo) - 1) : (64 + __ffsll((unsigned long long)hit) - 1);
 	}
-	if ((bidx < 3) || (bidx > len - 3))               // :1683
-		return 0;
-	wave_sync();
-	const c32 amp0 = cz[bidx];
-
-	if (ABL(9)) { *toa_out = (float)bidx; *amp_out = amp0; *ci_out = 0.0f; return 1; }
-	DIAG_MARK(4);
-	// ---- computePeakRatio (:1541-1571): terms in the reference's order; out-of-range terms read the
-	// zero pads (adding +0 is exact), their count is arithmetic
-	{
-		float avg = 0.0f;
-		int num = 0;
-#pragma unroll
-		for (int i = 2; i <= 5; i++) {
-			avg += norm2(cz[bidx - i]);
-			avg += norm2(cz[bidx + i]);              // bidx + i >= len reads zeros (pad = 12 > 5)
-			num += (bidx - i >= 0) + (bidx + i < len);
-		}
-		if (num < 5)
-			return 0;
-		// The gate "|amp| / (sqrtf(avg/num) + 1e-5) < thresh" is a decision, so it must round as the reference
-		// does -- but two IEEE divisions, two correctly rounded square roots and an fp64 add cost ~45 VALU ops.
-		// A 1-ulp-per-op estimate (total error < 1e-6) decides every burst whose ratio is not within 4e-6 of
-		// the threshold; only those (about one in 1e5) take the exactly rounded path.
-		const float amp2 = norm2(amp0);
-		const float rms_e = __builtin_amdgcn_sqrtf(avg * __builtin_amdgcn_rcpf((float)num)) + 0.00001f;
-		const float ratio_e = __builtin_amdgcn_sqrtf(amp2) * __builtin_amdgcn_rcpf(rms_e);
-		if (ratio_e < thresh * (1.0f - 4e-6f))
-			return 0;
-		if (!(ratio_e > thresh * (1.0f + 4e-6f))) {
-			const float rms = (float)((double)sqrtf(avg / (float)num) + 0.00001);
-			const float ratio = sqrtf(amp2) / rms;
-			if (ratio < thresh)
-				return 0;
-		}
-	}
-
-	DIAG_MARK(5);
-	// ---- peakDetect (:1695): refined TOA (multiple of 1/512) and interpolated correlation value
-	int toa512;
-	c32 xcorr;
-	// interpolatePoint() never reads the last correlation sample (:1105, :1109): zero it in the padded copy
-	if (lane == 0)
-		cz[len - 1] = make_float2(0.0f, 0.0f);
-	wave_sync();
-	if (ABL(1)) { toa512 = bidx * 512; xcorr = amp0; }
-	else
-		peak_detect_spec(cz, bidx, sincv, pc, lane, &toa512, &xcorr);
-	toa512 = uni(toa512);
-	xcorr.x = unif(xcorr.x);
-	xcorr.y = unif(xcorr.y);
-	const float toa = (float)toa512 * (1.0f / 512.0f);   // exact
-
-	DIAG_MARK(6);
-	// ---- computeCI (:1608-1639)
-	float ci = 0.0f;
-	{
-		// roundf(toa): toa is k/512 -> round half away from zero on integers
-		const int rt = (toa512 >= 0) ? ((toa512 + 256) >> 9) : -((-toa512 + 256) >> 9);
-		const int ps = start + 1 - N + rt;
-		if (ps >= 0 && ps + N <= sig_len && !ABL(7)) {
-			// S = sum_i |sig[ps+i]|^2 in index order: lane i squares one sample, the sum walks the lanes
-			const float pw = norm2(sig[ps + (lane < N ? lane : 0)]);
-			float S = 0.0f;
-			for (int i = 0; i < N; i++)
-				S += lane_val(pw, i);
-			// C/I is an analogue report (tolerance 2e-5 dB in the tests): reciprocal-multiplies and the
-			// hardware log2 instead of three IEEE divisions and a software log
-			S *= (N == 16) ? 0.0625f : 0.025f;               // S /= N  (N is 16 or 40)
-			const float C = norm2(xcorr) * hdr[7];           // / ((N-1)*|gain|), reciprocal from the table
-			ci = 3.0103f * __log2f(C * __builtin_amdgcn_rcpf(S - C));
-		}
-	}
-
-	*amp_out = cmul(xcorr, make_float2(hdr[2], hdr[3]));   // xcorr / sync->gain  (:1701)
-	*toa_out = unif(toa - hdr[5]);                           // :1704
-	*ci_out = ci;
-	DIAG_MARK(7);
-	return 1;
+	return detect_tail<false>(sig, sig_len, cz, hdr, N, thresh, start, len, bidx, sincv, pc, lane, toa_out, amp_out, ci_out, slice DIAG_PASS);
 }
 
 

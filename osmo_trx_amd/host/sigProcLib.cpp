@@ -183,6 +183,29 @@ int detectAnyBurst(const signalVector &burst, unsigned tsc, float threshold, int
 	return res.rc;
 }
 
+int detectSCHBurst(signalVector &burst, float thresh, int sps, sch_detect_type state, struct estim_burst_params *ebp)
+{
+	Scratch &t = tls;
+	if ((sps != 1) && (sps != 4))
+		return -1;                                             /* sigProcLib.cpp:1814-1815 */
+	if (!g_ctx || !ebp || !t.ensure(1, burst.bytes(), 1))
+		return -1;
+	const int st = (state == sch_detect_type::SCH_DETECT_NARROW) ? TRXHIP_SCH_DETECT_NARROW
+		     : (state == sch_detect_type::SCH_DETECT_BUFFER) ? TRXHIP_SCH_DETECT_BUFFER : TRXHIP_SCH_DETECT_FULL;
+	trxhip_burst_result res;
+	if (!h2d(t.d_iq, burst.begin(), burst.bytes(), t.stream) ||
+	    trxhip_detect_sch_batch_cf32(g_ctx, static_cast<const float *>(t.d_iq), t.d_res, 1, burst.size(), sps, st, thresh,
+					 t.stream) != TRXHIP_OK ||
+	    !d2h(&res, t.d_res, sizeof(res), t.stream) || hipStreamSynchronize(t.stream) != hipSuccess)
+		return -1;
+	/* tsc is left alone, as in the reference (only detectBurst()'s fields are written, :1691-1704, :1846-1858) */
+	ebp->amp = complex(res.amp_re, res.amp_im);
+	ebp->toa = res.toa;
+	if (res.rc > 0)
+		ebp->ci = res.ci;
+	return res.rc;
+}
+
 SoftVector *demodAnyBurst(const signalVector &burst, CorrType type, int sps, struct estim_burst_params *ebp)
 {
 	Scratch &t = tls;

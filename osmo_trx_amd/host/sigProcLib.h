@@ -48,6 +48,16 @@ float energyDetect(const signalVector &rxBurst, unsigned windowLength);
 int detectAnyBurst(const signalVector &burst, unsigned tsc, float threshold, int sps, CorrType type,
 		   unsigned max_toa, struct estim_burst_params *ebp);
 
+/** SCH synchronisation-burst search of the MS side (sigProcLib.h:139-148, sigProcLib.cpp:1805-1861)
+ *  @return 1 if detected (ebp: toa, amp, ci), 0 if not (toa = amp = 0), -1 on error */
+enum class sch_detect_type {
+	SCH_DETECT_FULL,
+	SCH_DETECT_NARROW,
+	SCH_DETECT_BUFFER,
+};
+int detectSCHBurst(signalVector &rxBurst, float detectThreshold, int sps, sch_detect_type state,
+		   struct estim_burst_params *ebp);
+
 /** Demodulate burst based on type and output soft bits (sigProcLib.h:151-152).
  *  Returns a new SoftVector the caller deletes (Transceiver.cpp:805), or NULL. */
 SoftVector *demodAnyBurst(const signalVector &burst, CorrType type, int sps, struct estim_burst_params *ebp);

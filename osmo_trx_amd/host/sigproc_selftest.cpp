@@ -2,6 +2,7 @@
 // (burst-gen.cpp:274-290 for the captured burst; Transceiver.cpp:768-803 for the detect -> demod -> slice
 // sequence).  Reads inputs prepared by tests/test_gpu_host_shim.py, writes results as plain text/binary.
 //   sigproc_selftest capture <cfile> <out.txt>
+//   sigproc_selftest sch <cfile> <0 full | 1 narrow | 2 buffer> <out.txt>
 //   sigproc_selftest batch <iq.s16> <params.bin> <n> <sps> <burst_len> <out_results.bin> <out_soft.bin>
 #include <cstdio>
 #include <cstdlib>
@@ -55,6 +56,30 @@ int main(int argc, char **argv)
 			fprintf(o, "sliced0 %.9g %.9g %.9g\n", sliced[0], sliced[73], sliced[147]);
 		}
 		fprintf(o, "energy %.9g\n", energyDetect(sv, 80));
+		fclose(o);
+		sigProcLibDestroy();
+		return 0;
+	}
+
+	if (!strcmp(argv[1], "sch") && argc == 5) {
+		/* ms_rx_lower.cpp:213-250: detectSCHBurst() then demodAnyBurst(burst, SCH, 4, &ebp) on the first 625 samples */
+		std::vector<char> raw = slurp(argv[2]);
+		size_t n = raw.size() / sizeof(complex);
+		signalVector sv(reinterpret_cast<complex *>(raw.data()), 0, n);
+		const int st = atoi(argv[3]);
+		struct estim_burst_params ebp;
+		memset(&ebp, 0, sizeof(ebp));
+		int rc = detectSCHBurst(sv, BURST_THRESH, 4, st == 1 ? sch_detect_type::SCH_DETECT_NARROW
+						     : st == 2 ? sch_detect_type::SCH_DETECT_BUFFER : sch_detect_type::SCH_DETECT_FULL, &ebp);
+		FILE *o = fopen(argv[4], "w");
+		fprintf(o, "rc %d\ntoa %.9g\namp %.9g %.9g\nci %.9g\n", rc, ebp.toa, ebp.amp.real(), ebp.amp.imag(), ebp.ci);
+		if (rc > 0 && st == 0) {
+			signalVector one(reinterpret_cast<complex *>(raw.data()), 0, 625);
+			std::unique_ptr<SoftVector> soft(demodAnyBurst(one, SCH, 4, &ebp));
+			fprintf(o, "bits ");
+			for (size_t i = 0; soft && i < 148; i++) fputc(soft->bit(i) ? '1' : '0', o);
+			fputc('\n', o);
+		}
 		fclose(o);
 		sigProcLibDestroy();
 		return 0;

@@ -24,6 +24,7 @@ assert PARAMS_DTYPE.itemsize == 8 and RESULT_DTYPE.itemsize == 32
 TRXD_RECORD_BYTES = 156
 FLAG_SLICE = 1          # TRXHIP_FLAG_SLICE
 FLAG_EXACT_DEMOD = 2    # TRXHIP_FLAG_EXACT_DEMOD
+SCH_DETECT_FULL, SCH_DETECT_NARROW, SCH_DETECT_BUFFER = 0, 1, 2   # sch_detect_type (sigProcLib.h:139-143)
 
 
 class TrxHipError(RuntimeError):
@@ -54,6 +55,7 @@ SYMBOLS = {
     "trxhip_detect_demod_batch_cf32": (_I, [_VP, _VP, _VP, _VP, _VP, _SZ, _I, _I, _F, _F, _I, _I, _VP]),
     "trxhip_demod_batch_cf32": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _SZ, _I, _I, _I, _I, _VP]),
     "trxhip_energy_detect_batch_cf32": (_I, [_VP, _VP, _SZ, _I, C.c_uint, _VP, _VP]),
+    "trxhip_detect_sch_batch_cf32": (_I, [_VP, _VP, _VP, _SZ, _SZ, _I, _I, C.c_float, _VP]),
     "trxhip_vector_slicer": (_I, [_VP, _VP, _VP, _SZ, _VP]),
     "trxhip_pack_trxd_batch": (_I, [_VP, _VP, _VP, _I, _VP, _SZ, _F, _VP]),
     "trxhip_convolve_real_batch": (_I, [_VP, _VP, _I, _VP, _I, _VP, _I, _I, _I, _SZ, _VP]),
@@ -207,6 +209,16 @@ class TrxHip:
                                             self._stream(stream))
         _check(rc, "trxhip_demod_batch_cf32")
         return results, soft
+
+    def detect_sch(self, iq_cf32, state=0, sps=4, threshold=4.0, stream=None):
+        """detectSCHBurst() for complex64[n_bufs, buf_len] buffers; state = SCH_DETECT_FULL / _NARROW / _BUFFER.
+        Returns results uint8[n_bufs, 32] (rc, toa, amp, ci)."""
+        torch = self.torch
+        n, buf_len = iq_cf32.shape
+        results = torch.empty((n, 32), dtype=torch.uint8, device=iq_cf32.device)
+        _check(self.L.trxhip_detect_sch_batch_cf32(self.h, self._dev(iq_cf32), self._dev(results), n, buf_len, sps, state,
+                                                   threshold, self._stream(stream)), "trxhip_detect_sch_batch_cf32")
+        return results
 
     @staticmethod
     def results_to_numpy(results):

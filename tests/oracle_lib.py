@@ -83,6 +83,8 @@ def lib():
     L.orc_detect_any_burst.restype = C.c_int
     L.orc_detect_any_burst.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_float, C.c_int, C.c_int, C.c_uint,
                                        C.POINTER(Ebp)]
+    L.orc_detect_sch_burst.restype = C.c_int
+    L.orc_detect_sch_burst.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.POINTER(Ebp)]
     L.orc_demod_any_burst.restype = C.c_int
     L.orc_demod_any_burst.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(Ebp), C.c_void_p]
     L.orc_modulate_burst.restype = C.c_int
@@ -150,6 +152,17 @@ def detect_any_burst(burst, tsc, threshold, sps, ctype, max_toa):
     b = np.ascontiguousarray(burst, dtype=np.complex64)
     e = Ebp()
     rc = lib().orc_detect_any_burst(_ptr(b), len(b), tsc, threshold, sps, ctype, max_toa, C.byref(e))
+    return rc, e
+
+
+SCH_DETECT_FULL, SCH_DETECT_NARROW, SCH_DETECT_BUFFER = 0, 1, 2
+
+
+def detect_sch_burst(burst, threshold, sps, state):
+    """detectSCHBurst (sigProcLib.cpp:1805-1861).  Returns (rc, Ebp)."""
+    b = np.ascontiguousarray(burst, dtype=np.complex64)
+    e = Ebp()
+    rc = lib().orc_detect_sch_burst(_ptr(b), len(b), threshold, sps, state, C.byref(e))
     return rc, e
 
 

@@ -105,3 +105,29 @@ def test_multi_arfcn_rx_class(exe, tmp_path):
         got = np.fromfile(tmp_path / f"ch{lchan}.cf32", dtype=np.complex64)
         assert np.array_equal(got.view(np.float32), ref.view(np.float32)), lchan
     L.orc_resampler_free(r)
+
+
+def test_sch_through_sigproclib_api(exe, tmp_path):
+    """detectSCHBurst() + demodAnyBurst(SCH) of the shim (call pattern of ms_rx_lower.cpp:213-250) vs the oracle."""
+    import sch_util
+    rng = np.random.default_rng(21)
+    y, bits = sch_util.sch_burst(rng, 700, 9)
+    (tmp_path / "sch.cfile").write_bytes(y.tobytes())
+    buf, _ = sch_util.sch_burst(rng, 60000, 4 * 7000 + 2, amp=2000.0, noise=120.0)
+    (tmp_path / "buf.cfile").write_bytes(buf.tobytes())
+    for path, state, x in (("sch.cfile", 0, y), ("sch.cfile", 1, y), ("buf.cfile", 2, buf)):
+        out = tmp_path / f"sch{state}.txt"
+        subprocess.check_call([exe, "sch", str(tmp_path / path), str(state), str(out)])
+        kv = dict(line.split(" ", 1) for line in out.read_text().strip().splitlines())
+        rc, e = O.detect_sch_burst(x, 4.0, 4, state)
+        assert int(kv["rc"]) == rc
+        assert np.float32(float(kv["toa"])) == np.float32(e.toa)
+        ar, ai = (float(v) for v in kv["amp"].split())
+        assert abs(complex(ar, ai) - complex(e.amp[0], e.amp[1])) <= 1e-6 * max(abs(complex(e.amp[0], e.amp[1])), 1e-30)
+        if rc > 0:
+            assert abs(float(kv["ci"]) - e.ci) <= 2e-5
+        if state == 0:
+            assert rc == 1
+            soft = O.demod_any_burst(y[:625], 4, 4, e)
+            assert kv["bits"] == "".join("1" if v > 0 else "0" for v in soft[:148])
+            assert kv["bits"] == "".join("0" if b else "1" for b in bits)      # polarity: see tests/test_oracle.py

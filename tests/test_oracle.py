@@ -184,3 +184,48 @@ def test_vector_slicer_and_trxd_packing():
     u8 = np.zeros(len(dst), dtype=np.uint8)
     O.lib().orc_trxd_soft_u8(u8.ctypes.data, dst.ctypes.data, len(dst))
     np.testing.assert_array_equal(u8, [0, 0, 64, 128, 159, 255, 255])
+
+
+# ---- detectSCHBurst (sigProcLib.cpp:1805-1861) -----------------------------------------------------------------
+def test_sch_detect_full_and_demod():
+    """SCH_DETECT_FULL finds a synchronisation burst at the delay it was given, and demodAnyBurst(SCH) on the
+    detected parameters returns its 148 bits."""
+    import sch_util
+    rng = np.random.default_rng(7)
+    toas = []
+    for d in (0, 3, 10, 17):
+        y, bits = sch_util.sch_burst(rng, 700, d)
+        rc, e = O.detect_sch_burst(y, 4.0, 4, O.SCH_DETECT_FULL)
+        assert rc == 1
+        toas.append(e.toa)
+        soft = O.demod_any_burst(y[:625], 4, 4, e)            # CorrType SCH = 4 -> demodGmskBurst
+        # the correlation sequences are built from -(2b-1) (sigProcLib.cpp:1257-1260, SURVEY.md Appendix A), so amp
+        # carries the sign and a demodulated positive value is a transmitted 0
+        assert np.array_equal((soft[:148] < 0).astype(np.uint8), bits)
+    # the TOA follows the delay: 4 samples per symbol
+    d = np.diff(np.array(toas))
+    assert np.allclose(d, np.array([3, 7, 7]) / 4.0, atol=0.02)
+
+
+def test_sch_detect_states():
+    import sch_util
+    rng = np.random.default_rng(8)
+    y, _ = sch_util.sch_burst(rng, 700, 5)
+    # noise only: nothing found, toa and amp zeroed (:1846-1850)
+    z, _ = sch_util.sch_burst(rng, 700, 5, present=False)
+    rc, e = O.detect_sch_burst(z, 4.0, 4, O.SCH_DETECT_FULL)
+    assert rc == 0 and e.toa == 0.0 and e.amp[0] == 0.0 and e.amp[1] == 0.0
+    # NARROW decimates only 32 samples and then correlates 101 symbols into that 8-sample vector (:1820-1823,
+    # :1840-1842): it cannot detect anything -- restated as is
+    rc, e = O.detect_sch_burst(y, 4.0, 4, O.SCH_DETECT_NARROW)
+    assert rc == 0
+    # sps other than 1 / 4 and short buffers are errors
+    assert O.detect_sch_burst(y, 4.0, 2, O.SCH_DETECT_FULL)[0] == -1
+    assert O.detect_sch_burst(y[:600], 4.0, 4, O.SCH_DETECT_FULL)[0] == -1
+    # BUFFER: 12 frames, the burst anywhere inside; toa is relative to the burst start like FULL's
+    buf, _ = sch_util.sch_burst(rng, 60000, 4 * 5000 + 5, noise=100.0)
+    rc, e = O.detect_sch_burst(buf, 4.0, 4, O.SCH_DETECT_BUFFER)
+    rc_f, e_f = O.detect_sch_burst(buf[4 * 5000:4 * 5000 + 700], 4.0, 4, O.SCH_DETECT_FULL)
+    assert rc == 1 and rc_f == 1
+    # BUFFER subtracts 3+39+64 = 106 where FULL subtracts head = 105 (:1853-1858): one symbol apart by construction
+    assert abs((e.toa - 5000) - (e_f.toa - 1.0)) < 0.02
