@@ -160,6 +160,16 @@ enum { TRXHIP_SCH_DETECT_FULL = 0, TRXHIP_SCH_DETECT_NARROW = 1, TRXHIP_SCH_DETE
 int trxhip_detect_sch_batch_cf32(trxhip_ctx *ctx, const float *d_iq_cf32, trxhip_burst_result *d_results,
 				 size_t n_bufs, size_t buf_len, int sps, int state, float threshold, void *stream);
 
+/* delayVector() (sigProcLib.h:97, sigProcLib.cpp:1046-1098) for n_vec complex64 vectors of `len` samples, one delay
+ * (in samples) per vector in d_delays: 64-phase 20-tap fractional filter when |frac| > 0.01, then the integer shift
+ * with zero fill.  d_out must not alias d_in. */
+int trxhip_delay_vector_batch_cf32(trxhip_ctx *ctx, const float *d_in_cf32, float *d_out_cf32, const float *d_delays,
+				   size_t n_vec, int len, void *stream);
+
+/* scaleVector() (sigProcLib.h:94, sigProcLib.cpp:1188-1213): in-place x[i] *= (scale_re + j scale_im) over `len`
+ * complex64 samples. */
+int trxhip_scale_vector_cf32(trxhip_ctx *ctx, float *d_x_cf32, size_t len, float scale_re, float scale_im, void *stream);
+
 /* energyDetect() on its own (sigProcLib.h:105, sigProcLib.cpp:1573-1585): mean |x|^2 of `window` samples at
  * stride 4 from sample 0 of each burst (complex64); d_energy: n_bursts floats. */
 int trxhip_energy_detect_batch_cf32(trxhip_ctx *ctx, const float *d_iq_cf32, size_t n_bursts, int burst_len,

@@ -393,3 +393,81 @@ extern "C" int trx_launch_vector_slicer(float *d_dst, const float *d_src, size_t
 	hipLaunchKernelGGL(vector_slicer_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d_dst, d_src, len);
 	return hipGetLastError() == hipSuccess ? 0 : TRXHIP_EIO;
 }
+
+// delayVector() (sigProcLib.cpp:1046-1098) for a batch of equally long vectors, one delay per vector:
+//   whole = floor(d), frac = d - whole; |frac| > 0.01: fshift[m] = sum_k X(m - 9 + k) * h_f[k], f = floorf(frac * 64),
+//   20 real taps (convolve NO_DELAY, zero-padded :318-323), else fshift = x; out[i] = fshift[i - whole], 0 outside.
+// One workgroup per vector tile; taps are wave-uniform (scalar loads), sums in tap order.
+__global__ void __launch_bounds__(256)
+delay_vector_kernel(const c32 *__restrict__ in, c32 *__restrict__ out, const float *__restrict__ delays,
+		    const trx_tables *__restrict__ tab, int len)
+{
+	const size_t v = blockIdx.y;
+	const c32 *x = in + v * (size_t)len;
+	c32 *y = out + v * (size_t)len;
+	const float delay = delays[v];
+	const float fl = floorf(delay);
+	const int whole = (int)fl;
+	const float frac = delay - (float)whole;
+	const bool use_filt = (double)fabsf(frac) > 1e-2;                  // :1056
+	const int fidx = use_filt ? (int)floorf(frac * (float)TRX_DELAY_FILTS) : 0;
+	const float *h = tab->delay_filt[fidx];
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < len; i += gridDim.x * blockDim.x) {
+		const int m = i - whole;
+		c32 r = make_float2(0.0f, 0.0f);
+		if (m >= 0 && m < len) {
+			if (use_filt) {
+				float yr = 0.0f, yi = 0.0f;
+#pragma unroll
+				for (int k = 0; k < TRX_DELAY_HLEN; k++) {
+					const int j = m - 9 + k;
+					const c32 xv = (j >= 0 && j < len) ? x[j] : make_float2(0.0f, 0.0f);
+					yr += xv.x * h[k];
+					yi += xv.y * h[k];
+				}
+				r = make_float2(yr, yi);
+			} else {
+				r = x[m];
+			}
+		}
+		y[i] = r;
+	}
+}
+
+extern "C" int trx_launch_delay_vector(const float *d_in, float *d_out, const float *d_delays, const trx_tables *d_tab,
+				       size_t n_vec, int len, hipStream_t stream)
+{
+	if (n_vec == 0 || len == 0)
+		return 0;
+	unsigned bx = (unsigned)((len + 255) / 256);
+	if (bx > 64) bx = 64;
+	for (size_t v0 = 0; v0 < n_vec; v0 += 65535) {                     // gridDim.y limit
+		const size_t nv = (n_vec - v0 < 65535) ? n_vec - v0 : 65535;
+		hipLaunchKernelGGL(delay_vector_kernel, dim3(bx, (unsigned)nv), dim3(256), 0, stream,
+				   reinterpret_cast<const c32 *>(d_in) + v0 * (size_t)len,
+				   reinterpret_cast<c32 *>(d_out) + v0 * (size_t)len, d_delays + v0, d_tab, len);
+	}
+	return hipGetLastError() == hipSuccess ? 0 : TRXHIP_EIO;
+}
+
+// scaleVector() (sigProcLib.cpp:1188-1213): x[i] = x[i] * scale, Complex.h:74 operand order; in place
+__global__ void __launch_bounds__(256)
+scale_vector_kernel(c32 *__restrict__ x, size_t len, c32 scale)
+{
+	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x)
+	{
+		const c32 a = x[i];
+		x[i] = make_float2(a.x * scale.x - a.y * scale.y, a.x * scale.y + a.y * scale.x);
+	}
+}
+
+extern "C" int trx_launch_scale_vector(float *d_x, size_t len, float sr, float si, hipStream_t stream)
+{
+	if (len == 0)
+		return 0;
+	size_t blocks = (len + 255) / 256;
+	if (blocks > 2048) blocks = 2048;
+	hipLaunchKernelGGL(scale_vector_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<c32 *>(d_x), len,
+			   make_float2(sr, si));
+	return hipGetLastError() == hipSuccess ? 0 : TRXHIP_EIO;
+}

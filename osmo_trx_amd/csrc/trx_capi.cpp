@@ -31,6 +31,9 @@ extern "C" int trx_launch_energy_detect(const float *d_x, size_t n_bursts, int b
 extern "C" int trx_launch_sch_detect(const float *d_iq, size_t buf_stride, trxhip_burst_result *d_results,
 				     const trx_tables *d_tab, size_t n_bufs, int len, int start, int toa_sub, float thresh,
 				     hipStream_t stream);
+extern "C" int trx_launch_delay_vector(const float *d_in, float *d_out, const float *d_delays, const trx_tables *d_tab,
+				       size_t n_vec, int len, hipStream_t stream);
+extern "C" int trx_launch_scale_vector(float *d_x, size_t len, float sr, float si, hipStream_t stream);
 extern "C" int trx_launch_vector_slicer(float *d_dst, const float *d_src, size_t len, hipStream_t stream);
 
 struct trxhip_ctx {
@@ -295,6 +298,29 @@ int trxhip_detect_sch_batch_cf32(trxhip_ctx *ctx, const float *d_iq, trxhip_burs
 	const int toa_sub = (state == TRXHIP_SCH_DETECT_BUFFER) ? 3 + 39 + 64 : head;      /* :1853-1858 */
 	return trx_launch_sch_detect(d_iq, buf_len, d_results, ctx->d_tables, n_bufs, len, start, toa_sub, threshold,
 				     static_cast<hipStream_t>(stream));
+}
+
+int trxhip_delay_vector_batch_cf32(trxhip_ctx *ctx, const float *d_in, float *d_out, const float *d_delays, size_t n_vec,
+				   int len, void *stream)
+{
+	if (!ctx || len < 0)
+		return TRXHIP_EINVAL;
+	if (n_vec == 0 || len == 0)
+		return TRXHIP_OK;
+	if (!d_in || !d_out || !d_delays || d_in == d_out)
+		return TRXHIP_EINVAL;
+	if (with_device(ctx))
+		return TRXHIP_EIO;
+	return trx_launch_delay_vector(d_in, d_out, d_delays, ctx->d_tables, n_vec, len, static_cast<hipStream_t>(stream));
+}
+
+int trxhip_scale_vector_cf32(trxhip_ctx *ctx, float *d_x, size_t len, float scale_re, float scale_im, void *stream)
+{
+	if (!ctx || (len && !d_x))
+		return TRXHIP_EINVAL;
+	if (with_device(ctx))
+		return TRXHIP_EIO;
+	return trx_launch_scale_vector(d_x, len, scale_re, scale_im, static_cast<hipStream_t>(stream));
 }
 
 int trxhip_vector_slicer(trxhip_ctx *ctx, float *d_dest, const float *d_src, size_t len, void *stream)

@@ -183,6 +183,39 @@ int detectAnyBurst(const signalVector &burst, unsigned tsc, float threshold, int
 	return res.rc;
 }
 
+signalVector *delayVector(const signalVector *in, signalVector *out, float delay)
+{
+	Scratch &t = tls;
+	if (!g_ctx || !in || !t.ensure(1, 2 * in->bytes() + 16, 1))
+		return NULL;
+	const size_t n = in->size();
+	signalVector *res = new signalVector(n);
+	/* scratch layout: [in][out]; the delay rides in d_ebp */
+	float *d_in = static_cast<float *>(t.d_iq), *d_out = d_in + 2 * n;
+	if (n && (!h2d(d_in, in->begin(), in->bytes(), t.stream) || !h2d(t.d_ebp, &delay, sizeof(float), t.stream) ||
+		  trxhip_delay_vector_batch_cf32(g_ctx, d_in, d_out, t.d_ebp, 1, (int)n, t.stream) != TRXHIP_OK ||
+		  !d2h(res->begin(), d_out, res->bytes(), t.stream) || hipStreamSynchronize(t.stream) != hipSuccess)) {
+		delete res;
+		return NULL;
+	}
+	if (!out)
+		return res;
+	*out = *res;                                               /* out->clone(*shift), :1094 */
+	delete res;
+	return out;
+}
+
+void scaleVector(signalVector &x, complex scale)
+{
+	Scratch &t = tls;
+	if (!g_ctx || !x.size() || !t.ensure(1, x.bytes(), 1))
+		return;
+	if (h2d(t.d_iq, x.begin(), x.bytes(), t.stream) &&
+	    trxhip_scale_vector_cf32(g_ctx, static_cast<float *>(t.d_iq), x.size(), scale.real(), scale.imag(), t.stream) == TRXHIP_OK &&
+	    d2h(x.begin(), t.d_iq, x.bytes(), t.stream))
+		hipStreamSynchronize(t.stream);
+}
+
 int detectSCHBurst(signalVector &burst, float thresh, int sps, sch_detect_type state, struct estim_burst_params *ebp)
 {
 	Scratch &t = tls;

@@ -48,6 +48,13 @@ float energyDetect(const signalVector &rxBurst, unsigned windowLength);
 int detectAnyBurst(const signalVector &burst, unsigned tsc, float threshold, int sps, CorrType type,
 		   unsigned max_toa, struct estim_burst_params *ebp);
 
+/** Fractional + integer delay (sigProcLib.h:97, sigProcLib.cpp:1046-1098).  out == NULL: returns a new vector the
+ *  caller deletes; otherwise `out` is resized to the result and returned.  NULL on a GPU error. */
+signalVector *delayVector(const signalVector *in, signalVector *out, float delay);
+
+/** In-place complex scaling (sigProcLib.h:94, sigProcLib.cpp:1188-1213) */
+void scaleVector(signalVector &x, complex scale);
+
 /** SCH synchronisation-burst search of the MS side (sigProcLib.h:139-148, sigProcLib.cpp:1805-1861)
  *  @return 1 if detected (ebp: toa, amp, ci), 0 if not (toa = amp = 0), -1 on error */
 enum class sch_detect_type {

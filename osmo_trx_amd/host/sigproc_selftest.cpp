@@ -2,6 +2,7 @@
 // (burst-gen.cpp:274-290 for the captured burst; Transceiver.cpp:768-803 for the detect -> demod -> slice
 // sequence).  Reads inputs prepared by tests/test_gpu_host_shim.py, writes results as plain text/binary.
 //   sigproc_selftest capture <cfile> <out.txt>
+//   sigproc_selftest delay <cfile> <delay> <scale_re> <scale_im> <out.cf32>
 //   sigproc_selftest sch <cfile> <0 full | 1 narrow | 2 buffer> <out.txt>
 //   sigproc_selftest batch <iq.s16> <params.bin> <n> <sps> <burst_len> <out_results.bin> <out_soft.bin>
 #include <cstdio>
@@ -56,6 +57,21 @@ int main(int argc, char **argv)
 			fprintf(o, "sliced0 %.9g %.9g %.9g\n", sliced[0], sliced[73], sliced[147]);
 		}
 		fprintf(o, "energy %.9g\n", energyDetect(sv, 80));
+		fclose(o);
+		sigProcLibDestroy();
+		return 0;
+	}
+
+	if (!strcmp(argv[1], "delay") && argc == 7) {
+		/* delayVector(burst, NULL, d) then scaleVector(*delay, s): the pair demodCommon() and ms_rx_lower.cpp:243-245 use */
+		std::vector<char> raw = slurp(argv[2]);
+		size_t n = raw.size() / sizeof(complex);
+		signalVector sv(reinterpret_cast<complex *>(raw.data()), 0, n);
+		std::unique_ptr<signalVector> d(delayVector(&sv, NULL, (float)atof(argv[3])));
+		if (!d) return 4;
+		scaleVector(*d, complex((float)atof(argv[4]), (float)atof(argv[5])));
+		FILE *o = fopen(argv[6], "wb");
+		fwrite(d->begin(), 1, d->bytes(), o);
 		fclose(o);
 		sigProcLibDestroy();
 		return 0;

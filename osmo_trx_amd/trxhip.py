@@ -55,6 +55,8 @@ SYMBOLS = {
     "trxhip_detect_demod_batch_cf32": (_I, [_VP, _VP, _VP, _VP, _VP, _SZ, _I, _I, _F, _F, _I, _I, _VP]),
     "trxhip_demod_batch_cf32": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _SZ, _I, _I, _I, _I, _VP]),
     "trxhip_energy_detect_batch_cf32": (_I, [_VP, _VP, _SZ, _I, C.c_uint, _VP, _VP]),
+    "trxhip_delay_vector_batch_cf32": (_I, [_VP, _VP, _VP, _VP, _SZ, _I, _VP]),
+    "trxhip_scale_vector_cf32": (_I, [_VP, _VP, _SZ, C.c_float, C.c_float, _VP]),
     "trxhip_detect_sch_batch_cf32": (_I, [_VP, _VP, _VP, _SZ, _SZ, _I, _I, C.c_float, _VP]),
     "trxhip_vector_slicer": (_I, [_VP, _VP, _VP, _SZ, _VP]),
     "trxhip_pack_trxd_batch": (_I, [_VP, _VP, _VP, _I, _VP, _SZ, _F, _VP]),
@@ -209,6 +211,23 @@ class TrxHip:
                                             self._stream(stream))
         _check(rc, "trxhip_demod_batch_cf32")
         return results, soft
+
+    def delay_vector(self, x_cf32, delays, stream=None):
+        """delayVector(): x complex64[n, len], delays float32[n] (samples).  Returns a new tensor."""
+        torch = self.torch
+        n, length = x_cf32.shape
+        out = torch.empty_like(x_cf32)
+        _check(self.L.trxhip_delay_vector_batch_cf32(self.h, self._dev(x_cf32), self._dev(out),
+                                                     self._dev(delays, torch.float32), n, length, self._stream(stream)),
+               "trxhip_delay_vector_batch_cf32")
+        return out
+
+    def scale_vector(self, x_cf32, scale, stream=None):
+        """scaleVector(): in place x *= scale (complex)."""
+        scale = complex(scale)
+        _check(self.L.trxhip_scale_vector_cf32(self.h, self._dev(x_cf32), x_cf32.numel(), scale.real, scale.imag,
+                                               self._stream(stream)), "trxhip_scale_vector_cf32")
+        return x_cf32
 
     def detect_sch(self, iq_cf32, state=0, sps=4, threshold=4.0, stream=None):
         """detectSCHBurst() for complex64[n_bufs, buf_len] buffers; state = SCH_DETECT_FULL / _NARROW / _BUFFER.

@@ -321,3 +321,22 @@ def test_streaming_front_end_any_chunking(trx, p, q, block_len):
         assert np.array_equal(whole[k].cpu().numpy().view(np.float32), ref.view(np.float32)), k
     L.orc_resampler_free(r)
     fe.close()
+
+
+def test_delay_vector_batch_bit_exact(trx):
+    """trxhip_delay_vector_batch_cf32 == delayVector() (sigProcLib.cpp:1046-1098) per vector, every filter phase."""
+    import torch
+    rng = np.random.default_rng(31)
+    n, length = 130, 625
+    x = (rng.standard_normal((n, length)) + 1j * rng.standard_normal((n, length))).astype(np.complex64) * 500
+    delays = np.concatenate([np.arange(64) / 64.0 + 0.003, -np.arange(64) / 64.0 - 2.0, [0.0, 630.0]]).astype(np.float32)
+    got = trx.delay_vector(torch.from_numpy(x).to("cuda:0"), torch.from_numpy(delays).to("cuda:0")).cpu().numpy()
+    for v in range(n):
+        ref = np.zeros(length, dtype=np.complex64)
+        xv = np.ascontiguousarray(x[v])
+        O.lib().orc_delay_vector(xv.ctypes.data, length, float(delays[v]), ref.ctypes.data)
+        assert np.array_equal(got[v].view(np.float32), ref.view(np.float32)), (v, delays[v])
+    y = trx.scale_vector(torch.from_numpy(x).to("cuda:0"), 0.25 - 2.0j).cpu().numpy()
+    re = x.real * np.float32(0.25) - x.imag * np.float32(-2.0)
+    im = x.real * np.float32(-2.0) + x.imag * np.float32(0.25)
+    assert np.array_equal(y.real, re) and np.array_equal(y.imag, im)

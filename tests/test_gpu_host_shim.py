@@ -131,3 +131,21 @@ def test_sch_through_sigproclib_api(exe, tmp_path):
             soft = O.demod_any_burst(y[:625], 4, 4, e)
             assert kv["bits"] == "".join("1" if v > 0 else "0" for v in soft[:148])
             assert kv["bits"] == "".join("0" if b else "1" for b in bits)      # polarity: see tests/test_oracle.py
+
+
+def test_delay_and_scale_vector_api(exe, tmp_path):
+    """delayVector() + scaleVector() of the shim vs the oracle, fractional / integer / negative delays."""
+    rng = np.random.default_rng(22)
+    x = (rng.standard_normal(625) + 1j * rng.standard_normal(625)).astype(np.complex64) * 1000
+    (tmp_path / "x.cfile").write_bytes(x.tobytes())
+    sc = np.complex64(0.3 - 0.8j)
+    for d in (0.0, 0.005, 2.37, -3.6, 17.999, -0.5, 700.0):
+        out = tmp_path / "d.cf32"
+        subprocess.check_call([exe, "delay", str(tmp_path / "x.cfile"), repr(d), repr(float(sc.real)), repr(float(sc.imag)),
+                               str(out)])
+        got = np.fromfile(out, dtype=np.complex64)
+        ref = np.zeros(625, dtype=np.complex64)
+        O.lib().orc_delay_vector(x.ctypes.data, 625, d, ref.ctypes.data)
+        re = ref.real * sc.real - ref.imag * sc.imag                 # Complex.h:74 operand order, fp32
+        im = ref.real * sc.imag + ref.imag * sc.real
+        assert np.array_equal(got.real, re.astype(np.float32)) and np.array_equal(got.imag, im.astype(np.float32)), d
