@@ -13,6 +13,10 @@
 #define TRX_PAD 20                 // zero samples kept on both sides of a burst in LDS
 #define TRX_DEC_LEN 208            // decimated burst: 156 samples + zero tail up to start+len (<= 199)
 #define TRX_CORR_MAX 128           // head + tail <= 16 + TRXHIP_MAX_TOA
+// narrow per-wave buffers of the 4-SPS production kernel (16 waves per CU must fit 160 KB of LDS): windows up to
+// max_toa = 64 (the reference's defaults are 63 / 30) are stored whole, wider ones take detect_burst()'s windowed path
+#define TRX_DEC_NARROW 160         // 156 samples + 4 zeros
+#define TRX_CORR_NARROW 80
 #define TRX_CZ_PAD 12              // zero samples either side of the correlation (interpolatePoint reach)
 #define TRX_CZ_LEN (TRX_CZ_PAD + TRX_CORR_MAX + TRX_CZ_PAD)
 #define TRX_SINCV_LDS (TRX_SINCV_LEN + 32)   // + zero tail: q = 4096 is addressed when the fraction is 0
@@ -94,32 +98,45 @@ __device__ __forceinline__ float dpp(float v)
 #define DPP_BCAST15     0x142
 #define DPP_BCAST31     0x143
 
-// wave-wide max / sum in 6 DPP-fed VALU ops; result taken from lane 63
+// wave-wide max / sum in 6 DPP VALU ops; result taken from lane 63.  Written as asm: from the update_dpp builtin
+// the compiler emits v_mov_b32 + v_mov_b32_dpp + (canonicalising v_max) + op per step (~4x the instructions).
+// A DPP source written by the previous VALU op needs two wait states on gfx9 (s_nop 1), which the compiler's
+// hazard recogniser does not insert inside an asm block.
+#define TRX_DPP_STEP(op, ctrl) "s_nop 1\n\t" op " %0, %0, %0 " ctrl "\n\t"
 __device__ __forceinline__ float wave_max(float v)
 {
-	v = fmaxf(v, dpp<DPP_QUAD_XOR1, 0xf>(v));
-	v = fmaxf(v, dpp<DPP_QUAD_XOR2, 0xf>(v));
-	v = fmaxf(v, dpp<DPP_HALF_MIRROR, 0xf>(v));
-	v = fmaxf(v, dpp<DPP_ROW_MIRROR, 0xf>(v));
-	v = fmaxf(v, dpp<DPP_BCAST15, 0xa>(v));
-	v = fmaxf(v, dpp<DPP_BCAST31, 0xc>(v));
+	asm volatile(TRX_DPP_STEP("v_max_f32_dpp", "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+		     TRX_DPP_STEP("v_max_f32_dpp", "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+		     TRX_DPP_STEP("v_max_f32_dpp", "row_half_mirror row_mask:0xf bank_mask:0xf")
+		     TRX_DPP_STEP("v_max_f32_dpp", "row_mirror row_mask:0xf bank_mask:0xf")
+		     TRX_DPP_STEP("v_max_f32_dpp", "row_bcast:15 row_mask:0xa bank_mask:0xf")
+		     TRX_DPP_STEP("v_max_f32_dpp", "row_bcast:31 row_mask:0xc bank_mask:0xf")
+		     : "+v"(v));
 	return lane_val(v, 63);
 }
 
 __device__ __forceinline__ float wave_sum(float v)
 {
-	v += dpp<DPP_QUAD_XOR1, 0xf>(v);
-	v += dpp<DPP_QUAD_XOR2, 0xf>(v);
-	v += dpp<DPP_HALF_MIRROR, 0xf>(v);
-	v += dpp<DPP_ROW_MIRROR, 0xf>(v);
-	{
-		// rows 1,3 += row 0,2 totals; rows 2,3 += (rows 0+1) total.  Masked-out rows must add 0.
-		const float t = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_BCAST15, 0xa, 0xf, false));
-		v += t;
-		const float u = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_BCAST31, 0xc, 0xf, false));
-		v += u;
-	}
+	// rows 1,3 += row 0,2 totals; rows 2,3 += (rows 0+1) total: masked-out rows are not written
+	asm volatile(TRX_DPP_STEP("v_add_f32_dpp", "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+		     TRX_DPP_STEP("v_add_f32_dpp", "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+		     TRX_DPP_STEP("v_add_f32_dpp", "row_half_mirror row_mask:0xf bank_mask:0xf")
+		     TRX_DPP_STEP("v_add_f32_dpp", "row_mirror row_mask:0xf bank_mask:0xf")
+		     TRX_DPP_STEP("v_add_f32_dpp", "row_bcast:15 row_mask:0xa bank_mask:0xf")
+		     TRX_DPP_STEP("v_add_f32_dpp", "row_bcast:31 row_mask:0xc bank_mask:0xf")
+		     : "+v"(v));
 	return lane_val(v, 63);
+}
+
+// sum over each row of 16 lanes (every lane of the row gets the total)
+__device__ __forceinline__ float row_sum(float v)
+{
+	asm volatile(TRX_DPP_STEP("v_add_f32_dpp", "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+		     TRX_DPP_STEP("v_add_f32_dpp", "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+		     TRX_DPP_STEP("v_add_f32_dpp", "row_half_mirror row_mask:0xf bank_mask:0xf")
+		     TRX_DPP_STEP("v_add_f32_dpp", "row_mirror row_mask:0xf bank_mask:0xf")
+		     : "+v"(v));
+	return v;
 }
 
 // Complex.h:113 norm2(): i*i + r*r
@@ -268,11 +285,10 @@ __device__ __forceinline__ void peak_detect_spec(const c32 *cz, int max_idx, con
 // computeCI, amp and toa.  One wave; `bidx` is the wave-uniform index of the first strict maximum of |corr|^2.
 //   cz     : correlation with TRX_CZ_PAD zeros either side; only cz[bidx-12 .. bidx+12] is read, so a caller
 //            with a long correlation (SCH buffer search) may pass a 25-sample window, biased so that it is
-//            indexed by the absolute position (WINDOWED: the ":1105" zeroing of cz[len-1] is then range-checked)
+//            indexed by the absolute position (the ":1105" zeroing of cz[len-1] is range-checked for that)
 //   sig    : what was correlated (computeCI reads N samples of it), sig_len its length
 //   hdr    : {gain.re, gain.im, ginv.re, ginv.im, ci_den, toa, n, 1/ci_den}
 // ------------------------------------------------------------------------------------------------
-template <bool WINDOWED>
 __device__ __forceinline__ int detect_tail(const c32 *sig, int sig_len, c32 *cz, const float *hdr, int N, float thresh,
 					    int start, int len, int bidx, const float *sincv, const PeakConst &pc, int lane,
 					    float *toa_out, c32 *amp_out, float *ci_out, int slice DIAG_ARG)
@@ -319,7 +335,7 @@ __device__ __forceinline__ int detect_tail(const c32 *sig, int sig_len, c32 *cz,
 	int toa512;
 	c32 xcorr;
 	// interpolatePoint() never reads the last correlation sample (:1105, :1109): zero it in the padded copy
-	if (lane == 0 && (!WINDOWED || len - 1 - bidx <= TRX_CZ_PAD))
+	if (lane == 0 && len - 1 - bidx <= TRX_CZ_PAD)       // (farther from the peak nothing reads it)
 		cz[len - 1] = make_float2(0.0f, 0.0f);
 	wave_sync();
 	if (ABL(1)) { toa512 = bidx * 512; xcorr = amp0; }
@@ -364,41 +380,66 @@ __device__ __forceinline__ int detect_tail(const c32 *sig, int sig_len, c32 *cz,
 //   taps  : LDS, wave-uniform -> broadcast reads; hdr: {gain.re, gain.im, ginv.re, ginv.im, ci_den, toa}
 // Returns rc (1 / 0); on 1 fills toa (symbols, before "- head"), amp, ci.  Wave-uniform.
 // ------------------------------------------------------------------------------------------------
-template <bool PADDED>
+//   NARROW: sig[] and cz[] are the TRX_DEC_NARROW / TRX_CORR_NARROW buffers: a window that does not fit them
+//           (max_toa > 64) is correlated without storing it and only the 25 values around the peak are
+//           recomputed for the tail, exactly as the SCH buffer search does (trx_sch.hip)
+template <bool PADDED, bool NARROW>
 __device__ __forceinline__ int detect_burst(const c32 *sig, int sig_len, c32 *cz, const c32 *taps, const float *hdr,
 					     int N, float thresh, int start, int len, const float *sincv, const PeakConst &pc, int lane,
 					     float *toa_out, c32 *amp_out, float *ci_out, int slice DIAG_ARG)
 {
+	const bool wide = NARROW && (len > TRX_CORR_NARROW || start + len > TRX_DEC_NARROW);
+	// corr[i] with range-checked reads, taps in order (cold: wide windows only)
+	auto corr_at = [&](int i) {
+		float yr = 0.0f, yi = 0.0f;
+		const int base = i + start - (N - 1);
+		for (int k = 0; k < N; k++) {
+			const int j = base + k;
+			const c32 x = (j >= 0 && j < sig_len) ? sig[j] : make_float2(0.0f, 0.0f);
+			const c32 h = taps[k];
+			yr += x.x * h.x - x.y * h.y;
+			yi += x.x * h.y + x.y * h.x;
+		}
+		return make_float2(yr, yi);
+	};
+
 	// ---- correlate: corr[i] = sum_k SIG(i + start - (N-1) + k) * seq[k]   (:1674, convolve_base.c:72-85)
 	// N is 16 (TSC/EDGE) or 40 (RACH): tap loop unrolled by 8 so the LDS reads pipeline
 	float best = 0.0f;                               // fastPeakDetect state, fused into the same pass
 	int bidx = -1;
-	for (int i = lane; i < len; i += WAVE) {
-		float yr = 0.0f, yi = 0.0f;
-		const int base = i + start - (N - 1);
-		for (int k0 = 0; k0 < N; k0 += 8) {
-			c32 x[8];
-#pragma unroll
-			for (int u = 0; u < 8; u++) {
-				const int j = base + k0 + u;
-				if (PADDED) x[u] = sig[j];
-				else x[u] = (j >= 0 && j < sig_len) ? sig[j] : make_float2(0.0f, 0.0f);
-			}
-#pragma unroll
-			for (int u = 0; u < 8; u++) {
-				const c32 h = taps[k0 + u];
-				yr += x[u].x * h.x - x[u].y * h.y;
-				yi += x[u].x * h.y + x[u].y * h.x;
-			}
+	if (wide) {
+		for (int i = lane; i < len; i += WAVE) {
+			const float v = norm2(corr_at(i));
+			if (v > best) { best = v; bidx = i; }
 		}
-		const c32 y = make_float2(yr, yi);
-		cz[i] = y;
-		// fastPeakDetect (:1120-1139): first strict maximum of |corr|^2 (per lane: i ascending)
-		const float v = norm2(y);
-		if (v > best) { best = v; bidx = i; }
+	} else {
+		for (int i = lane; i < len; i += WAVE) {
+			float yr = 0.0f, yi = 0.0f;
+			const int base = i + start - (N - 1);
+			for (int k0 = 0; k0 < N; k0 += 8) {
+				c32 x[8];
+#pragma unroll
+				for (int u = 0; u < 8; u++) {
+					const int j = base + k0 + u;
+					if (PADDED) x[u] = sig[j];
+					else x[u] = (j >= 0 && j < sig_len) ? sig[j] : make_float2(0.0f, 0.0f);
+				}
+#pragma unroll
+				for (int u = 0; u < 8; u++) {
+					const c32 h = taps[k0 + u];
+					yr += x[u].x * h.x - x[u].y * h.y;
+					yi += x[u].x * h.y + x[u].y * h.x;
+				}
+			}
+			const c32 y = make_float2(yr, yi);
+			cz[i] = y;
+			// fastPeakDetect (:1120-1139): first strict maximum of |corr|^2 (per lane: i ascending)
+			const float v = norm2(y);
+			if (v > best) { best = v; bidx = i; }
+		}
+		if (lane < TRX_CZ_PAD)
+			cz[len + lane] = make_float2(0.0f, 0.0f);    // right zero pad (len varies per burst)
 	}
-	if (lane < TRX_CZ_PAD)
-		cz[len + lane] = make_float2(0.0f, 0.0f);    // right zero pad (len varies per burst)
 
 	DIAG_MARK(3);
 	// arg-max across lanes: wave max (DPP), then the lowest index holding it (ballot + scalar ff1)
@@ -410,7 +451,23 @@ __device__ __forceinline__ int detect_burst(const c32 *sig, int sig_len, c32 *cz
 		const unsigned long long hit_lo = __ballot(best == m && bidx == lane);
 		bidx = hit_lo ? (__ffsll((unsigned long long)hit_lo) - 1) : (64 + __ffsll((unsigned long long)hit) - 1);
 	}
-	return detect_tail<false>(sig, sig_len, cz, hdr, N, thresh, start, len, bidx, sincv, pc, lane, toa_out, amp_out, ci_out, slice DIAG_PASS);
+	c32 *czp = cz;
+	if (wide) {
+		c32 *win = cz - TRX_CZ_PAD;                      // 2 * TRX_CZ_PAD + 1 entries: positions bidx - 12 .. bidx + 12
+		if (lane < 2 * TRX_CZ_PAD + 1) {
+			const int g = bidx - TRX_CZ_PAD + lane;
+			win[lane] = (g >= 0 && g < len) ? corr_at(g) : make_float2(0.0f, 0.0f);
+		}
+		czp = win - (bidx - TRX_CZ_PAD);
+	}
+	const int r = detect_tail(sig, sig_len, czp, hdr, N, thresh, start, len, bidx, sincv, pc, lane, toa_out, amp_out, ci_out,
+				  slice DIAG_PASS);
+	if (wide) {
+		wave_sync();
+		if (lane < TRX_CZ_PAD)
+			cz[lane - TRX_CZ_PAD] = make_float2(0.0f, 0.0f);     // the window covered cz's left zero pad: restore it
+	}
+	return r;
 }
 
 
@@ -424,7 +481,7 @@ __device__ __forceinline__ int detect_burst(const c32 *sig, int sig_len, c32 *cz
 // ------------------------------------------------------------------------------------------------
 struct DetectOut { float toa; c32 amp; float ci; int tsc; };
 
-template <bool PADDED, typename DecimateFn>
+template <bool PADDED, bool NARROW, typename DecimateFn>
 __device__ __forceinline__ int detect_any_burst(int type, int tsc, int max_toa, int clip, DecimateFn decimate,
 						 const c32 *sig, int sig_len, c32 *cz, const c32 *lseq, const float *lhdr,
 						 float thresh, const float *sincv, const PeakConst &pkc, int lane, int slice,
@@ -465,7 +522,7 @@ __device__ __forceinline__ int detect_any_burst(int type, int tsc, int max_toa, 
 		}
 		DIAG_MARK(2);
 		float t; c32 a; float cc;
-		const int hit = detect_burst<PADDED>(sig, sig_len, cz, taps, hdr, N, thresh, start, len, sincv, pkc, lane, &t, &a, &cc, slice DIAG_PASS);
+		const int hit = detect_burst<PADDED, NARROW>(sig, sig_len, cz, taps, hdr, N, thresh, start, len, sincv, pkc, lane, &t, &a, &cc, slice DIAG_PASS);
 		wave_sync();
 		if (hit) {
 			out->toa = t - (float)head;                      // :1768

@@ -22,7 +22,8 @@
 #define PH_M0  12                  // position of m = 0 inside a phase array (48 samples of zero pad in front)
 #define K4_XS  (4 * PH_A)
 #define K4_EDGE 8
-#define K4_SLICE (K4_XS + TRX_DEC_LEN + TRX_CZ_LEN + K4_EDGE)
+#define K4_CZ_LEN (TRX_CZ_PAD + TRX_CORR_NARROW + TRX_CZ_PAD)
+#define K4_SLICE (K4_XS + TRX_DEC_NARROW + K4_CZ_LEN + K4_EDGE)
 #define K4_DROWS (TRX_DELAY_FILTS + 1)                         // + identity row (no fractional filter)
 #define K4_TABLES_FLOATS (TRX_SINCV_LDS + K4_DROWS * TRX_DELAY_HLEN + 2 * 160 + 16 + 2 * LSEQ_TAPS + 8 * LSEQ_NHDR + K4_DROWS * 36)
 #define K4_TABLES_BYTES (K4_TABLES_FLOATS * 4)
@@ -60,23 +61,14 @@ __device__ __forceinline__ PhBase ph_bases(const c32 *P, int ph0, int m0)
 	return b;
 }
 
-// 16-lane (one DPP row) sum, result in every lane of the row
-__device__ __forceinline__ float row_sum(float v)
-{
-	v += dpp<DPP_QUAD_XOR1, 0xf>(v);
-	v += dpp<DPP_QUAD_XOR2, 0xf>(v);
-	v += dpp<DPP_HALF_MIRROR, 0xf>(v);
-	v += dpp<DPP_ROW_MIRROR, 0xf>(v);
-	return v;
-}
-
-// waves per workgroup (one workgroup per CU).  The fused kernel would fit 14 (124 VGPRs, 36 KB of tables + 8.7 KB
-// of LDS per wave) but measures no faster than 12: the kernel is VALU-throughput bound (~85 % busy), not latency bound.
-#define K4_WPB_FUSED 12
+// waves per workgroup (one workgroup per CU).  Fused: 16 = 4 per SIMD (<= 128 VGPRs; 36 KB of tables + 16 x 7.75 KB
+// slices = 159.2 KB of the 160 KB LDS, which is why the per-wave buffers are the NARROW ones).  Measured 12 -> 16
+// waves: 378 -> 420 Mbursts/s; the kernel is latency bound per wave (profiles/).  Exact: 168 VGPRs.
+#define K4_WPB_FUSED 16
 #define K4_WPB_EXACT 12
 
 template <bool CF32, bool EXACT>
-__global__ void __launch_bounds__((EXACT ? K4_WPB_EXACT : K4_WPB_FUSED) * WAVE, 3)
+__global__ void __launch_bounds__((EXACT ? K4_WPB_EXACT : K4_WPB_FUSED) * WAVE)
 burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__restrict__ params,
 		   trxhip_burst_result *__restrict__ results, float *__restrict__ soft,
 		   const trx_tables *__restrict__ tab, const float4 *__restrict__ ebp_in,
@@ -85,7 +77,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 	constexpr int NLD = 10;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const int lane = threadIdx.x & (WAVE - 1);
-	const int wave = threadIdx.x >> 6;
+	const int wave = uni((int)(threadIdx.x >> 6));                  // wave-uniform: burst index and its addresses live in SGPRs
 	const int waves_per_block = blockDim.x >> 6;
 
 	// ---- LDS carve: [tables][per-wave slices]
@@ -99,8 +91,8 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 	c32 *wbase = reinterpret_cast<c32 *>(smem + K4_TABLES_BYTES) + (size_t)wave * K4_SLICE;
 	c32 *const P = wbase;                                          // polyphase burst: P[r*PH_A + PH_M0 + m] = x[4m + r]
 	c32 *const dec = wbase + K4_XS;                                // 1-SPS (decimated) burst, zero tail
-	c32 *const cz = dec + TRX_DEC_LEN + TRX_CZ_PAD;                // zero-padded correlation
-	c32 *const edge = dec + TRX_DEC_LEN + TRX_CZ_LEN;              // [8] exactly recomputed edge outputs (fused demod)
+	c32 *const cz = dec + TRX_DEC_NARROW + TRX_CZ_PAD;             // zero-padded correlation
+	c32 *const edge = dec + TRX_DEC_NARROW + K4_CZ_LEN;            // [8] exactly recomputed edge outputs (fused demod)
 
 	// ---- one-time staging (workgroup-wide) of every table; zero this wave's slice (pads stay zero)
 	for (int i = threadIdx.x; i < TRX_SINCV_LDS; i += blockDim.x)
@@ -237,7 +229,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 					wave_sync();
 				};
 				DetectOut d;
-				rc = detect_any_burst<true>(type, tsc, max_toa, clip, decimate, dec, 156, cz, lseq, lhdr, thresh, sincv, pkc,
+				rc = detect_any_burst<true, true>(type, tsc, max_toa, clip, decimate, dec, 156, cz, lseq, lhdr, thresh, sincv, pkc,
 							    lane, slice, &d DIAG_PASS);
 				if (rc > 0) { toa = d.toa; amp = d.amp; ci = d.ci; out_tsc = d.tsc; }
 			}

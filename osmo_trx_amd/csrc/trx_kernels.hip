@@ -43,7 +43,7 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const int lane = threadIdx.x & (WAVE - 1);
-	const int wave = threadIdx.x >> 6;
+	const int wave = uni((int)(threadIdx.x >> 6));                  // wave-uniform: burst index and its addresses live in SGPRs
 	const int waves_per_block = blockDim.x >> 6;
 
 	// ---- LDS carve: [tables][per-wave slices]
@@ -209,11 +209,11 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 						}
 						wave_sync();
 					};
-					rc = detect_any_burst<true>(type, tsc, max_toa, clip, decimate, dec, 156, cz, lseq, lhdr, thresh, sincv,
+					rc = detect_any_burst<true, false>(type, tsc, max_toa, clip, decimate, dec, 156, cz, lseq, lhdr, thresh, sincv,
 								    pkc, lane, slice, &d DIAG_PASS);
 				} else {
 					auto nothing = [](int, int) {};
-					rc = detect_any_burst<false>(type, tsc, max_toa, clip, nothing, xs, L, cz, lseq, lhdr, thresh, sincv,
+					rc = detect_any_burst<false, false>(type, tsc, max_toa, clip, nothing, xs, L, cz, lseq, lhdr, thresh, sincv,
 								     pkc, lane, slice, &d DIAG_PASS);
 				}
 				if (rc > 0) { toa = d.toa; amp = d.amp; ci = d.ci; out_tsc = d.tsc; }

@@ -119,7 +119,7 @@ sch_detect_kernel(const c32 *__restrict__ iq, size_t buf_stride, trxhip_burst_re
 #ifdef TRX_DIAG
 		unsigned long long diag_acc[24] = {0}, diag_prev = 0;
 #endif
-		rc = detect_tail<true>(dec, len, win - (bidx - TRX_CZ_PAD), hdr, SCH_N, thresh, start, len, bidx, sincv, pkc, lane,
+		rc = detect_tail(dec, len, win - (bidx - TRX_CZ_PAD), hdr, SCH_N, thresh, start, len, bidx, sincv, pkc, lane,
 				       &toa, &amp, &ci, 0 DIAG_PASS);
 	}
 	if (lane < 8) {

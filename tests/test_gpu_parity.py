@@ -82,6 +82,31 @@ def test_normal_bursts_wide_window_raw_soft(trx):
     check_parity(f_res, f_soft, o_res, o_soft, soft_atol=FUSED_SOFT_ATOL)
 
 
+def test_window_widths_around_the_narrow_buffer_limit(trx):
+    """The 4-SPS kernel keeps correlation windows up to max_toa = 64 whole in LDS and switches to a windowed
+    evaluation beyond (TRX_CORR_NARROW / TRX_DEC_NARROW, trx_device.h).  Per-burst max_toa on both sides of the
+    limit, narrow and wide bursts interleaved in one batch (a wide burst must leave the buffers clean for the next),
+    NB and RACH, up to the API limit 112: all bit-exact."""
+    from osmo_trx_amd import synth
+    n = 1536
+    widths = np.array([3, 64, 65, 73, 74, 63, 90, 112, 30, 101, 102, 5], dtype=np.uint16)
+    iq, params, _ = synth.make_normal_bursts(n, "cpu", 4, seed=23, max_toa=63, delay_sym=(-1.0, 60.0))
+    params["max_toa"] = widths[np.arange(n) % len(widths)]
+    o_res, o_soft = O.pull_batch(iq.numpy(), 4, params)
+    for exact in (True, False):
+        g_res, g_soft = run_gpu(trx, iq, params, 4, exact=exact)
+        check_parity(g_res, g_soft, o_res, o_soft, soft_atol=0.0 if exact else FUSED_SOFT_ATOL)
+    assert (o_res["rc"] > 0).sum() > 900
+    wide = params["max_toa"] > 64
+    assert ((o_res["rc"] > 0) & wide).sum() > 300 and ((o_res["rc"] > 0) & ~wide).sum() > 300
+    iq, params, _ = synth.make_access_bursts(n, "cpu", ext=True, seed=24)
+    params["max_toa"] = widths[np.arange(n) % len(widths)]
+    o_res, o_soft = O.pull_batch(iq.numpy(), 4, params)
+    g_res, g_soft = run_gpu(trx, iq, params, 4)
+    check_parity(g_res, g_soft, o_res, o_soft)
+    assert ((o_res["rc"] > 0) & wide).sum() > 100
+
+
 @pytest.mark.parametrize("ext", [False, True])
 def test_access_bursts(trx, ext):
     """BASELINE.json configs[2]: RACH correlation sweep, max_toa 63; EXT_RACH tries TS0/1/2, first hit wins."""
