@@ -219,7 +219,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 						float yr = 0.0f, yi = 0.0f;
 #pragma unroll
 						for (int k = 0; k < 16; k++) {
-							const c32 x = pd[((k + 1) & 3) * PH_A + ((k + 1) >> 2)];
+							const c32 x = lds_c32(pd + ((k + 1) & 3) * PH_A + ((k + 1) >> 2));
 							const float g = gdec[k];
 							yr += x.x * g;
 							yi += x.y * g;
@@ -331,7 +331,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 							float yr = 0.0f, yi = 0.0f;
 #pragma unroll
 							for (int k = 0; k < 16; k++) {
-								const c32 x = pd[((k + 1) & 3) * PH_A + ((k + 1) >> 2)];
+								const c32 x = lds_c32(pd + ((k + 1) & 3) * PH_A + ((k + 1) >> 2));
 								const float g = gdec[k];
 								yr += x.x * g;
 								yi += x.y * g;
@@ -377,7 +377,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 						c32 x[10];
 #pragma unroll
 						for (int q = 0; q < 10; q++)
-							x[q] = pb.p[(k0 + q) & 3][(k0 + q) >> 2];
+							x[q] = lds_c32(pb.p[(k0 + q) & 3] + ((k0 + q) >> 2));
 #pragma unroll
 						for (int q = 0; q < 10; q += 2) {
 							acc0 = __builtin_elementwise_fma((v2f){ x[q].x, x[q].y }, (v2f){ hh[k0 + q], hh[k0 + q] }, acc0);
@@ -424,7 +424,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 							for (int q = 0; q < 4; q++)
 #pragma unroll
 								for (int r = 0; r < NR; r++)
-									x[r][q] = pbr[r].p[(u0 + q) & 3][(u0 + q) >> 2];   // tap 35: coefficient 0, sample in range
+									x[r][q] = lds_c32(pbr[r].p[(u0 + q) & 3] + ((u0 + q) >> 2));   // tap 35: coefficient 0, sample in range
 #pragma unroll
 							for (int q = 0; q < 4; q++) {
 								const v2f hv = { cf[q], cf[q] };
