@@ -415,24 +415,34 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 						acc[r] = (v2f){ 0.0f, 0.0f };
 					}
 					if (!ABL(5)) {
+						// software pipeline: the LDS reads run D taps ahead of the FMAs that consume them (ring of
+						// D + 1 taps x 3 rounds); one sched_barrier per tap keeps that order and the register
+						// footprint.  Tap 35 is a zero pad (coefficient 0, sample in range).
+						constexpr int D = 4;
+						c32 ring[D + 1][NR];
+						float4 cq[2];
+						cq[0] = c4[0];
 #pragma unroll
-						for (int u0 = 0; u0 < 36; u0 += 4) {                    // chunks of 4 taps (tap 35 is a zero pad)
-							const float4 ca = c4[u0 / 4];
-							const float cf[4] = { ca.x, ca.y, ca.z, ca.w };
-							c32 x[NR][4];
+						for (int t = 0; t < D; t++)
 #pragma unroll
-							for (int q = 0; q < 4; q++)
+							for (int r = 0; r < NR; r++)
+								ring[t][r] = lds_c32(pbr[r].p[t & 3] + (t >> 2));
+#pragma unroll
+						for (int u = 0; u < 36; u++) {
+							if ((u & 3) == 0 && u + 4 < 36)
+								cq[((u >> 2) + 1) & 1] = c4[(u >> 2) + 1];
+							if (u + D < 36) {
 #pragma unroll
 								for (int r = 0; r < NR; r++)
-									x[r][q] = lds_c32(pbr[r].p[(u0 + q) & 3] + ((u0 + q) >> 2));   // tap 35: coefficient 0, sample in range
+									ring[(u + D) % (D + 1)][r] = lds_c32(pbr[r].p[(u + D) & 3] + ((u + D) >> 2));
+							}
+							const float4 ca = cq[(u >> 2) & 1];
+							const float cfa[4] = { ca.x, ca.y, ca.z, ca.w };
+							const v2f hv = { cfa[u & 3], cfa[u & 3] };
 #pragma unroll
-							for (int q = 0; q < 4; q++) {
-								const v2f hv = { cf[q], cf[q] };
-#pragma unroll
-								for (int r = 0; r < NR; r++) {
-									const v2f xv = { x[r][q].x, x[r][q].y };
-									acc[r] = __builtin_elementwise_fma(xv, hv, acc[r]);
-								}
+							for (int r = 0; r < NR; r++) {
+								const v2f xv = { ring[u % (D + 1)][r].x, ring[u % (D + 1)][r].y };
+								acc[r] = __builtin_elementwise_fma(xv, hv, acc[r]);
 							}
 							__builtin_amdgcn_sched_barrier(0);
 						}
@@ -451,8 +461,18 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 							if (i < nwrite) {
 								const bool full = (i >= i_full_lo) && (i <= i_full_hi);
 								c32 d = full ? cmul(make_float2(acc[r].x, acc[r].y), scale) : make_float2(0.0f, 0.0f);
-								if (need_lo && (unsigned)(i - i0l) < 4u) d = edge[i - i0l];
-								if (need_hi && (unsigned)(i - i0h) < 4u) d = edge[4 + i - i0h];
+								// the exactly recomputed edge outputs: wave-uniform test whether this round holds any of
+								// them, then an unconditional (clamped) LDS read and a select -- no divergent branch
+								if (need_lo && i0l < (r + 1) * WAVE && i0l + 4 > r * WAVE) {
+									const int e = i - i0l;
+									const c32 ev = edge[e < 0 ? 0 : (e > 3 ? 3 : e)];
+									d = ((unsigned)e < 4u) ? ev : d;
+								}
+								if (need_hi && i0h < (r + 1) * WAVE && i0h + 4 > r * WAVE) {
+									const int e = i - i0h;
+									const c32 ev = edge[4 + (e < 0 ? 0 : (e > 3 ? 3 : e))];
+									d = ((unsigned)e < 4u) ? ev : d;
+								}
 								if (is_edge) {
 									dec[i] = d;
 									continue;
