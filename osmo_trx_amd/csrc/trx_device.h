@@ -372,9 +372,20 @@ __device__ __forceinline__ int detect_tail(const c32 *sig, int sig_len, c32 *cz,
 		if (ps >= 0 && ps + N <= sig_len && !ABL(7)) {
 			// S = sum_i |sig[ps+i]|^2 in index order: lane i squares one sample, the sum walks the lanes
 			const float pw = norm2(sig[ps + (lane < N ? lane : 0)]);
-			float S = 0.0f;
-			for (int i = 0; i < N; i++)
-				S += lane_val(pw, i);
+			// serial scan along the lanes: after step s lane k holds pw[k-s] + ... + pw[k] added left to right, so
+			// lane N-1 ends with the reference's S (one DPP add per term instead of a readlane + add)
+			float acc = pw;
+#define TRX_SCAN_STEP asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(pw))
+			if (N == 16) {                                   // normal bursts: straight-line
+#pragma unroll
+				for (int i = 1; i < 16; i++)
+					TRX_SCAN_STEP;
+			} else {
+				for (int i = 1; i < N; i++)
+					TRX_SCAN_STEP;
+			}
+#undef TRX_SCAN_STEP
+			float S = lane_val(acc, N - 1);
 			// C/I is an analogue report (tolerance 2e-5 dB in the tests): reciprocal-multiplies and the
 			// hardware log2 instead of three IEEE divisions and a software log
 			S *= (N == 16) ? 0.0625f : (N == 64) ? 0.015625f : 0.025f;   // S /= N  (N is 16, 40 or 64)
