@@ -455,34 +455,34 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 						asm volatile("" : "+v"(acc[r]));
 #pragma unroll
 					for (int r = 0; r < NR; r++) {
+						// straight-line per round: every lane computes its value (reads clamped into range), one
+						// predicated store at the end
 						const int i = lane + r * WAVE;
-						if (i < (is_edge ? 156 : soft_stride)) {
-							float sv = 0.0f;
-							if (i < nwrite) {
-								const bool full = (i >= i_full_lo) && (i <= i_full_hi);
-								c32 d = full ? cmul(make_float2(acc[r].x, acc[r].y), scale) : make_float2(0.0f, 0.0f);
-								// the exactly recomputed edge outputs: wave-uniform test whether this round holds any of
-								// them, then an unconditional (clamped) LDS read and a select -- no divergent branch
-								if (need_lo && i0l < (r + 1) * WAVE && i0l + 4 > r * WAVE) {
-									const int e = i - i0l;
-									const c32 ev = edge[e < 0 ? 0 : (e > 3 ? 3 : e)];
-									d = ((unsigned)e < 4u) ? ev : d;
-								}
-								if (need_hi && i0h < (r + 1) * WAVE && i0h + 4 > r * WAVE) {
-									const int e = i - i0h;
-									const c32 ev = edge[4 + (e < 0 ? 0 : (e > 3 ? 3 : e))];
-									d = ((unsigned)e < 4u) ? ev : d;
-								}
-								if (is_edge) {
-									dec[i] = d;
-									continue;
-								}
-								const c32 rr = rrot[i];
-								sv = rr.x * d.x - rr.y * d.y;                   // real(rot * x)  (:2066-2068)
-								if (slice & 1)
-									sv = __builtin_amdgcn_fmed3f(0.5f * (sv + 1.0f), 0.0f, 1.0f);
-							}
-							so[i] = sv;
+						const bool full = (i >= i_full_lo) && (i <= i_full_hi);
+						c32 d = full ? cmul(make_float2(acc[r].x, acc[r].y), scale) : make_float2(0.0f, 0.0f);
+						// the exactly recomputed edge outputs: wave-uniform test whether this round holds any of
+						// them, then an unconditional (clamped) LDS read and a select -- no divergent branch
+						if (need_lo && i0l < (r + 1) * WAVE && i0l + 4 > r * WAVE) {
+							const int e = i - i0l;
+							const c32 ev = edge[e < 0 ? 0 : (e > 3 ? 3 : e)];
+							d = ((unsigned)e < 4u) ? ev : d;
+						}
+						if (need_hi && i0h < (r + 1) * WAVE && i0h + 4 > r * WAVE) {
+							const int e = i - i0h;
+							const c32 ev = edge[4 + (e < 0 ? 0 : (e > 3 ? 3 : e))];
+							d = ((unsigned)e < 4u) ? ev : d;
+						}
+						if (is_edge) {                                          // wave-uniform
+							if (i < nwrite)
+								dec[i] = d;
+						} else {
+							const c32 rr = rrot[i < 159 ? i : 159];
+							float sv = rr.x * d.x - rr.y * d.y;                     // real(rot * x)  (:2066-2068)
+							if (slice & 1)
+								sv = __builtin_amdgcn_fmed3f(0.5f * (sv + 1.0f), 0.0f, 1.0f);
+							sv = (i < nwrite) ? sv : 0.0f;
+							if (i < soft_stride)
+								so[i] = sv;
 						}
 					}
 					if (!is_edge)
