@@ -441,7 +441,10 @@ __device__ __forceinline__ int detect_burst(const c32 *sig, int sig_len, c32 *cz
 		}
 	} else {
 		for (int i = lane; i < len; i += WAVE) {
-			float yr = 0.0f, yi = 0.0f;
+			// (yr, yi) += (xr*hr - xi*hi, xr*hi + xi*hr) as four packed ops per tap: two v_pk_mul, one v_pk_add with
+			// the low half negated, one accumulating v_pk_add -- the reference's roundings (convolve_base.c:28-40),
+			// spelled out because the vectoriser otherwise spends 6-7 instructions per tap on it
+			trx_v2f acc = { 0.0f, 0.0f };
 			const int base = i + start - (N - 1);
 			for (int k0 = 0; k0 < N; k0 += 8) {
 				c32 x[8];
@@ -453,12 +456,17 @@ __device__ __forceinline__ int detect_burst(const c32 *sig, int sig_len, c32 *cz
 				}
 #pragma unroll
 				for (int u = 0; u < 8; u++) {
-					const c32 h = taps[k0 + u];
-					yr += x[u].x * h.x - x[u].y * h.y;
-					yi += x[u].x * h.y + x[u].y * h.x;
+					// two taps per 16-byte broadcast read (sequence tables are 16-byte aligned in LDS)
+					const float4 h2 = reinterpret_cast<const float4 *>(taps + k0)[u >> 1];
+					const c32 h = (u & 1) ? make_float2(h2.z, h2.w) : make_float2(h2.x, h2.y);
+					const trx_v2f a = (trx_v2f){ x[u].x, x[u].x } * (trx_v2f){ h.x, h.y };
+					const trx_v2f b = (trx_v2f){ x[u].y, x[u].y } * (trx_v2f){ h.y, h.x };
+					trx_v2f t;                                   // (a.x - b.x, a.y + b.y): the compiler does not fold a
+					asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(t) : "v"(a), "v"(b));   // half negation
+					acc = acc + t;
 				}
 			}
-			const c32 y = make_float2(yr, yi);
+			const c32 y = make_float2(acc.x, acc.y);
 			cz[i] = y;
 			// fastPeakDetect (:1120-1139): first strict maximum of |corr|^2 (per lane: i ascending)
 			const float v = norm2(y);
