@@ -150,6 +150,19 @@ __device__ __forceinline__ c32 lds_c32(const c32 *p)
 	return make_float2(v.x, v.y);
 }
 
+// acc += x * h for a complex x and a real tap h that is element HI of a 64-bit register pair (taps arrive from LDS
+// in pairs / quads): one v_pk_fma_f32 with the tap selected by op_sel.  The compiler only knows how to broadcast
+// the low element and spends a v_mov on every odd tap.
+template <int HI>
+__device__ __forceinline__ trx_v2f pk_fma_tap(trx_v2f x, trx_v2f hpair, trx_v2f acc)
+{
+	if (HI)
+		asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(x), "v"(hpair));
+	else
+		asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(x), "v"(hpair));
+	return acc;
+}
+
 // Complex.h:113 norm2(): i*i + r*r
 __device__ __forceinline__ float norm2(c32 v) { return v.y * v.y + v.x * v.x; }
 // Complex.h:74 operator*(Complex)
@@ -168,17 +181,22 @@ __device__ __forceinline__ c32 cmul(c32 a, c32 b) { return make_float2(a.x * b.x
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ c32 interp_taps(const c32 *c, const float *sa, const float *sb)
 {
+	// pin tap 0's LDS address in a register: all 16 reads then use non-negative immediate offsets (otherwise the
+	// compiler rebases on the peak and spends a VALU subtract per tap on the negative side)
+	typedef const volatile trx_v2f __attribute__((address_space(3))) *lds_ptr;
+	lds_ptr cp = (lds_ptr)c;
+	asm("" : "+v"(cp));
 	c32 p = make_float2(0.0f, 0.0f);
 #pragma unroll
 	for (int u = 0; u < 8; u++) {                    // i = fl-7 .. fl   (k = 7 .. 0)
-		const c32 v = lds_c32(c + u);
+		const trx_v2f v = cp[u];
 		const float w = sa[512 * (7 - u)];
 		p.x += v.x * w;
 		p.y += v.y * w;
 	}
 #pragma unroll
 	for (int u = 0; u < 8; u++) {                    // i = fl+1 .. fl+8 (k = 0 .. 7)
-		const c32 v = lds_c32(c + 8 + u);
+		const trx_v2f v = cp[8 + u];
 		const float w = sb[512 * u];
 		p.x += v.x * w;
 		p.y += v.y * w;

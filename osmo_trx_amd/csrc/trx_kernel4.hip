@@ -54,10 +54,14 @@ __device__ __forceinline__ int cdiv(int a, int b) { return -fdiv(-a, b); }
 struct PhBase { const c32 *p[4]; };
 __device__ __forceinline__ PhBase ph_bases(const c32 *P, int ph0, int m0)
 {
+	// p[k] = P + ((ph0 + k) & 3) * PH_A + PH_M0 + m0 + ((ph0 + k) >> 2), incrementally: one multiply-add for p[0],
+	// then + k * PH_A, and one row back / one sample on where the phase wraps
 	PhBase b;
+	const c32 *p0 = P + (ph0 * PH_A + PH_M0 + m0);
+	b.p[0] = p0;
 #pragma unroll
-	for (int k = 0; k < 4; k++)
-		b.p[k] = P + ((ph0 + k) & 3) * PH_A + PH_M0 + m0 + ((ph0 + k) >> 2);
+	for (int k = 1; k < 4; k++)
+		b.p[k] = p0 + (k * PH_A + ((ph0 + k) >> 2) * (1 - 4 * PH_A));
 	return b;
 }
 
@@ -252,7 +256,9 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 				const float ian = __builtin_amdgcn_rcpf(an);
 				ainv = make_float2(amp.x * ian, -amp.y * ian);
 			}
-			const c32 scale = cmul(make_float2(1.0f, 0.0f), ainv);
+			// (complex) 1.0 * amp.inv(): the exact variant multiplies it out as the reference does (Complex.h:74-75);
+			// the fused one (tolerance 1e-5) takes ainv as is
+			const c32 scale = EXACT ? cmul(make_float2(1.0f, 0.0f), ainv) : ainv;
 			const bool is_edge = (rc == TRXHIP_EDGE);                     // 8-PSK: all 156 symbols go through LDS to edge_post()
 			nbits = is_edge ? 444 : 148;
 			idle = 0;
@@ -380,8 +386,10 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 							x[q] = lds_c32(pb.p[(k0 + q) & 3] + ((k0 + q) >> 2));
 #pragma unroll
 						for (int q = 0; q < 10; q += 2) {
-							acc0 = __builtin_elementwise_fma((v2f){ x[q].x, x[q].y }, (v2f){ hh[k0 + q], hh[k0 + q] }, acc0);
-							acc1 = __builtin_elementwise_fma((v2f){ x[q + 1].x, x[q + 1].y }, (v2f){ hh[k0 + q + 1], hh[k0 + q + 1] }, acc1);
+							// taps k0+q (even) and k0+q+1 (odd) share a register pair
+							const v2f hp = { hh[k0 + q], hh[k0 + q + 1] };
+							acc0 = pk_fma_tap<0>((v2f){ x[q].x, x[q].y }, hp, acc0);
+							acc1 = pk_fma_tap<1>((v2f){ x[q + 1].x, x[q + 1].y }, hp, acc1);
 						}
 						__builtin_amdgcn_sched_barrier(0);
 					}
@@ -437,12 +445,11 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 									ring[(u + D) % (D + 1)][r] = lds_c32(pbr[r].p[(u + D) & 3] + ((u + D) >> 2));
 							}
 							const float4 ca = cq[(u >> 2) & 1];
-							const float cfa[4] = { ca.x, ca.y, ca.z, ca.w };
-							const v2f hv = { cfa[u & 3], cfa[u & 3] };
+							const v2f hp = (u & 2) ? (v2f){ ca.z, ca.w } : (v2f){ ca.x, ca.y };
 #pragma unroll
 							for (int r = 0; r < NR; r++) {
 								const v2f xv = { ring[u % (D + 1)][r].x, ring[u % (D + 1)][r].y };
-								acc[r] = __builtin_elementwise_fma(xv, hv, acc[r]);
+								acc[r] = (u & 1) ? pk_fma_tap<1>(xv, hp, acc[r]) : pk_fma_tap<0>(xv, hp, acc[r]);
 							}
 							__builtin_amdgcn_sched_barrier(0);
 						}
