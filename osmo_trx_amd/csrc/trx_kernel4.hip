@@ -270,16 +270,17 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 			const int n_hi = (L - 1 + w < 623) ? L - 1 + w : 623;
 
 			float hh[TRX_DELAY_HLEN];                                      // delay filter taps (LDS broadcast reads)
-			{
+			auto load_hh = [&]() {
 				const float4 *hf4 = reinterpret_cast<const float4 *>(dfilt + fidx * TRX_DELAY_HLEN);
 #pragma unroll
 				for (int q = 0; q < TRX_DELAY_HLEN / 4; q++) {
 					const float4 h4 = hf4[q];
 					hh[4 * q + 0] = h4.x; hh[4 * q + 1] = h4.y; hh[4 * q + 2] = h4.z; hh[4 * q + 3] = h4.w;
 				}
-			}
+			};
 
 			if (EXACT) {
+				load_hh();
 				// ================= EXACT: two FIR stages in the reference's operand order =================
 				constexpr int R = 12;                                       // outputs per lane: 12*l .. 12*l+11 (52 lanes)
 				const int c0 = -w - 9;                                      // sample of tap 0 of output n: n + c0
@@ -366,124 +367,106 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 				const bool need_lo = (n_hi >= n_lo) && (i0l < i_full_lo) && (i0l < nwrite);
 				const bool need_hi = (n_hi >= n_lo) && (i0h <= fdiv(n_hi + 15, 4)) && (i0h < nwrite);
 
-				// exact masked two-stage sum for 4 consecutive outputs i0..i0+3: lane = 16*e + t computes
-				// g[t] * fshift[n - w] for n = 4(i0+e) - 15 + t if that sample exists, one DPP row sums over t
-				auto edge_round = [&](int i0, int slot) {
-					const int e = lane >> 4, t = lane & 15;
-					const int n = 4 * (i0 + e) - 15 + t;
-					const bool ok = (n >= n_lo) && (n <= n_hi);
-					const int s0 = n - w - 9;
-					int m0 = s0 >> 2;
-					if (m0 < -9) m0 = -9;
-					if (m0 > 158) m0 = 158;
-					const PhBase pb = ph_bases(P, s0 & 3, m0);
-					v2f acc0 = { 0.0f, 0.0f }, acc1 = { 0.0f, 0.0f };     // two chains: even / odd taps
-#pragma unroll
-					for (int k0 = 0; k0 < TRX_DELAY_HLEN; k0 += 10) {
-						c32 x[10];
-#pragma unroll
-						for (int q = 0; q < 10; q++)
-							x[q] = lds_c32(pb.p[(k0 + q) & 3] + ((k0 + q) >> 2));
-#pragma unroll
-						for (int q = 0; q < 10; q += 2) {
-							// taps k0+q (even) and k0+q+1 (odd) share a register pair
-							const v2f hp = { hh[k0 + q], hh[k0 + q + 1] };
-							acc0 = pk_fma_tap<0>((v2f){ x[q].x, x[q].y }, hp, acc0);
-							acc1 = pk_fma_tap<1>((v2f){ x[q + 1].x, x[q + 1].y }, hp, acc1);
-						}
-						__builtin_amdgcn_sched_barrier(0);
-					}
-					const v2f acc = acc0 + acc1;
-					const float g = ok ? gdec[t] : 0.0f;
-					const float sr = row_sum(acc.x * g), si = row_sum(acc.y * g);
-					if (t == 0)
-						edge[slot + e] = cmul(make_float2(sr, si), scale);
-				};
-				DIAG_MARK(8);
-				if (need_lo && !ABL(6)) edge_round(i0l, 0);
-				if (need_hi && !ABL(6)) edge_round(i0h, 4);
-
-				DIAG_MARK(9);
-				const float4 *c4 = reinterpret_cast<const float4 *>(comp + fidx * 36);   // 35 taps, LDS broadcast reads
-				const int c = -24 - w;
-				const int i_min = cdiv(-36 - c, 4), i_max = fdiv(L + 1 - c, 4);
-				wave_sync();
 				if (so || is_edge) {
-					// three output rounds (i = lane, lane+64, lane+128) advance together: three independent FMA
-					// chains per lane hide the LDS and FMA latency, and the 35 taps are fetched once
-					constexpr int NR = 3;
-					PhBase pbr[NR];
-					v2f acc[NR];
-#pragma unroll
-					for (int r = 0; r < NR; r++) {
-						int ic = lane + r * WAVE;
-						if (ic < i_min) ic = i_min;
-						if (ic > i_max) ic = i_max;
-						pbr[r] = ph_bases(P, c & 3, ic + (c >> 2));
-						acc[r] = (v2f){ 0.0f, 0.0f };
-					}
+					// ---- main filter.  Lane l owns the three ADJACENT outputs 3l, 3l+1, 3l+2 (52 lanes): their 35-tap
+					// windows overlap in 27 samples, so the lane reads 44 samples from LDS instead of 3 x 36 (sample
+					// v = u + 4j serves tap u of output j); stride-3 lanes stay bank-conflict-free.  Taps outer, a ring
+					// of 16 samples loaded D ahead of use; one sched_barrier per tap keeps order and register footprint.
+					const float4 *c4 = reinterpret_cast<const float4 *>(comp + fidx * 36);   // 35 taps (+ zero pad), broadcast reads
+					const int c = -24 - w;
+					const int i_min = cdiv(-36 - c, 4), i_max = fdiv(L + 1 - c, 4);
+					// lanes holding a full output never need the clamp (i_min + 6 <= i_full_lo, i_full_hi + 6 <= i_max):
+					// it only keeps the reads of lanes whose outputs are discarded inside the padded arrays
+					int ic = 3 * lane;
+					if (ic < i_min) ic = i_min;
+					if (ic > i_max - 2) ic = i_max - 2;
+					const PhBase pb = ph_bases(P, c & 3, ic + (c >> 2));
+					v2f acc[3] = { { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f } };
 					if (!ABL(5)) {
-						// software pipeline: the LDS reads run D taps ahead of the FMAs that consume them (ring of
-						// D + 1 taps x 3 rounds); one sched_barrier per tap keeps that order and the register
-						// footprint.  Tap 35 is a zero pad (coefficient 0, sample in range).
-						constexpr int D = 4;
-						c32 ring[D + 1][NR];
+						constexpr int D = 4, NV = 36 + 8;                       // samples v = 0 .. 43
+						c32 xw[16];
 						float4 cq[2];
 						cq[0] = c4[0];
 #pragma unroll
-						for (int t = 0; t < D; t++)
-#pragma unroll
-							for (int r = 0; r < NR; r++)
-								ring[t][r] = lds_c32(pbr[r].p[t & 3] + (t >> 2));
+						for (int v = 0; v < 8 + D; v++)
+							xw[v] = lds_c32(pb.p[v & 3] + (v >> 2));
 #pragma unroll
 						for (int u = 0; u < 36; u++) {
 							if ((u & 3) == 0 && u + 4 < 36)
 								cq[((u >> 2) + 1) & 1] = c4[(u >> 2) + 1];
-							if (u + D < 36) {
-#pragma unroll
-								for (int r = 0; r < NR; r++)
-									ring[(u + D) % (D + 1)][r] = lds_c32(pbr[r].p[(u + D) & 3] + ((u + D) >> 2));
-							}
+							if (u + 8 + D < NV)
+								xw[(u + 8 + D) & 15] = lds_c32(pb.p[(u + 8 + D) & 3] + ((u + 8 + D) >> 2));
 							const float4 ca = cq[(u >> 2) & 1];
 							const v2f hp = (u & 2) ? (v2f){ ca.z, ca.w } : (v2f){ ca.x, ca.y };
 #pragma unroll
-							for (int r = 0; r < NR; r++) {
-								const v2f xv = { ring[u % (D + 1)][r].x, ring[u % (D + 1)][r].y };
-								acc[r] = (u & 1) ? pk_fma_tap<1>(xv, hp, acc[r]) : pk_fma_tap<0>(xv, hp, acc[r]);
+							for (int j = 0; j < 3; j++) {
+								const v2f xv = { xw[(u + 4 * j) & 15].x, xw[(u + 4 * j) & 15].y };
+								acc[j] = (u & 1) ? pk_fma_tap<1>(xv, hp, acc[j]) : pk_fma_tap<0>(xv, hp, acc[j]);
 							}
 							__builtin_amdgcn_sched_barrier(0);
 						}
 					}
 					DIAG_MARK(10);
-					// pin the three sums here: without it LLVM sinks all 105 FMAs below the per-output predicates
-					// and keeps every LDS operand alive (170 spilled VGPRs)
+					// the 1-SPS symbols go through dec[] (free once detection is done; the 8-PSK tail wants them there
+					// anyway): FIR lanes write theirs, the edge rounds overwrite the few partial ones, then every lane
+					// reads back lane + 64 r for a coalesced store.  dec[156..159] stay zero for the next detection.
 #pragma unroll
-					for (int r = 0; r < NR; r++)
-						asm volatile("" : "+v"(acc[r]));
-#pragma unroll
-					for (int r = 0; r < NR; r++) {
-						// straight-line per round: every lane computes its value (reads clamped into range), one
-						// predicated store at the end
-						const int i = lane + r * WAVE;
+					for (int j = 0; j < 3; j++) {
+						const int i = 3 * lane + j;
 						const bool full = (i >= i_full_lo) && (i <= i_full_hi);
-						c32 d = full ? cmul(make_float2(acc[r].x, acc[r].y), scale) : make_float2(0.0f, 0.0f);
-						// the exactly recomputed edge outputs: wave-uniform test whether this round holds any of
-						// them, then an unconditional (clamped) LDS read and a select -- no divergent branch
-						if (need_lo && i0l < (r + 1) * WAVE && i0l + 4 > r * WAVE) {
-							const int e = i - i0l;
-							const c32 ev = edge[e < 0 ? 0 : (e > 3 ? 3 : e)];
-							d = ((unsigned)e < 4u) ? ev : d;
+						const c32 d = full ? cmul(make_float2(acc[j].x, acc[j].y), scale) : make_float2(0.0f, 0.0f);
+						if (i < 156)
+							dec[i] = d;
+					}
+
+					// exact masked two-stage sum for 4 consecutive outputs i0..i0+3: lane = 16*e + t computes
+					// g[t] * fshift[n - w] for n = 4(i0+e) - 15 + t if that sample exists, one DPP row sums over t
+					auto edge_round = [&](int i0) {
+						const int e = lane >> 4, t = lane & 15;
+						const int n = 4 * (i0 + e) - 15 + t;
+						const bool ok = (n >= n_lo) && (n <= n_hi);
+						const int s0 = n - w - 9;
+						int m0 = s0 >> 2;
+						if (m0 < -9) m0 = -9;
+						if (m0 > 158) m0 = 158;
+						const PhBase pe = ph_bases(P, s0 & 3, m0);
+						v2f acc0 = { 0.0f, 0.0f }, acc1 = { 0.0f, 0.0f };     // two chains: even / odd taps
+#pragma unroll
+						for (int k0 = 0; k0 < TRX_DELAY_HLEN; k0 += 10) {
+							c32 x[10];
+#pragma unroll
+							for (int q = 0; q < 10; q++)
+								x[q] = lds_c32(pe.p[(k0 + q) & 3] + ((k0 + q) >> 2));
+#pragma unroll
+							for (int q = 0; q < 10; q += 2) {
+								// taps k0+q (even) and k0+q+1 (odd) share a register pair
+								const v2f hp = { hh[k0 + q], hh[k0 + q + 1] };
+								acc0 = pk_fma_tap<0>((v2f){ x[q].x, x[q].y }, hp, acc0);
+								acc1 = pk_fma_tap<1>((v2f){ x[q + 1].x, x[q + 1].y }, hp, acc1);
+							}
+							__builtin_amdgcn_sched_barrier(0);
 						}
-						if (need_hi && i0h < (r + 1) * WAVE && i0h + 4 > r * WAVE) {
-							const int e = i - i0h;
-							const c32 ev = edge[4 + (e < 0 ? 0 : (e > 3 ? 3 : e))];
-							d = ((unsigned)e < 4u) ? ev : d;
-						}
-						if (is_edge) {                                          // wave-uniform
-							if (i < nwrite)
-								dec[i] = d;
-						} else {
-							const c32 rr = rrot[i < 159 ? i : 159];
+						const v2f accs = acc0 + acc1;
+						const float g = ok ? gdec[t] : 0.0f;
+						const float sr = row_sum(accs.x * g), si = row_sum(accs.y * g);
+						if (t == 0 && (unsigned)(i0 + e) < 156u)
+							dec[i0 + e] = cmul(make_float2(sr, si), scale);
+					};
+					DIAG_MARK(8);
+					if (need_lo || need_hi)
+						load_hh();                                          // only now: 20 registers the main filter does not carry
+					if (need_lo && !ABL(6)) edge_round(i0l);
+					if (need_hi && !ABL(6)) edge_round(i0h);
+					DIAG_MARK(9);
+					wave_sync();
+
+					if (!is_edge) {
+#pragma unroll
+						for (int r = 0; r < 3; r++) {
+							const int i = lane + r * WAVE;
+							const int ii = i < 159 ? i : 159;
+							const c32 d = dec[ii];
+							const c32 rr = rrot[ii];
 							float sv = rr.x * d.x - rr.y * d.y;                     // real(rot * x)  (:2066-2068)
 							if (slice & 1)
 								sv = __builtin_amdgcn_fmed3f(0.5f * (sv + 1.0f), 0.0f, 1.0f);
@@ -491,10 +474,9 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 							if (i < soft_stride)
 								so[i] = sv;
 						}
-					}
-					if (!is_edge)
-						for (int i = lane + NR * WAVE; i < soft_stride; i += WAVE) // soft_stride > 192: zero tail
+						for (int i = lane + 3 * WAVE; i < soft_stride; i += WAVE) // soft_stride > 192: zero tail
 							so[i] = 0.0f;
+					}
 				}
 				if (is_edge) {
 					wave_sync();
