@@ -222,7 +222,7 @@ struct PeakConst {
 	int flA;        // round A: floor((offset of this lane's position) / 512)
 	int loA, hiA;   // round A: sinc LUT bases (the fraction depends on the lane only: E is a multiple of 512)
 	int offB;       // round B: position offset of this lane (node early/late, or one of the 16 final positions)
-	int pad;
+	int ratio_off;  // computePeakRatio: offset of this lane's term, lane & 7 -> -2, +2, -3, +3, -4, +4, -5, +5
 };
 __device__ __forceinline__ int node_offset(int n, int inc0);
 __device__ __forceinline__ PeakConst peak_const(int lane)
@@ -233,7 +233,7 @@ __device__ __forceinline__ PeakConst peak_const(int lane)
 	pc.loA = sinc_base_lo(offA & 511);
 	pc.hiA = sinc_base_hi(offA & 511);
 	pc.offB = (lane < 32) ? node_offset(lane >> 1, 8) + ((lane & 1) ? 1024 : 0) : (2 * (lane & 15) - 15) + 512;
-	pc.pad = 0;
+	pc.ratio_off = ((lane & 1) ? 1 : -1) * (2 + ((lane & 7) >> 1));
 	return pc;
 }
 
@@ -337,14 +337,18 @@ __device__ __forceinline__ int detect_tail(const c32 *sig, int sig_len, c32 *cz,
 	// ---- computePeakRatio (:1541-1571): terms in the reference's order; out-of-range terms read the
 	// zero pads (adding +0 is exact), their count is arithmetic
 	{
-		float avg = 0.0f;
+		// lane k (mod 8) squares the k-th term of the reference's loop (peak-2, peak+2, peak-3, ... peak+5; out-of-range
+		// ones read the zero pads), a serial DPP scan adds them left to right: lane 7 holds the reference's avg
+		float acc = norm2(cz[bidx + pc.ratio_off]);
+		const float pwr = acc;
+#pragma unroll
+		for (int i = 1; i < 8; i++)
+			asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(pwr));
+		const float avg = lane_val(acc, 7);
 		int num = 0;
 #pragma unroll
-		for (int i = 2; i <= 5; i++) {
-			avg += norm2(cz[bidx - i]);
-			avg += norm2(cz[bidx + i]);              // bidx + i >= len reads zeros (pad = 12 > 5)
+		for (int i = 2; i <= 5; i++)
 			num += (bidx - i >= 0) + (bidx + i < len);
-		}
 		if (num < 5)
 			return 0;
 		// The gate "|amp| / (sqrtf(avg/num) + 1e-5) < thresh" is a decision, so it must round as the reference
