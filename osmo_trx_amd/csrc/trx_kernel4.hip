@@ -11,11 +11,16 @@
 //       EXACT (TRXHIP_FLAG_EXACT_DEMOD): delayVector -> scaleVector -> downsampleBurst as the reference
 //         does it, two FIR stages in the reference's operand order: soft bits bit-identical to generic C.
 //       FUSED (default): delay(20 taps) o decimate(16 taps) is ONE 35-tap filter evaluated only at the 148/156
-//         symbol instants (5.5 k MACs instead of 15 k), with FMA.  The reference truncates the intermediate
+//         symbol instants (5.5 k MACs instead of 15 k), with FMA; a lane owns three adjacent symbols so that their
+//         windows share LDS reads, and the symbols go through the (by then free) decimation buffer for a
+//         coalesced store.  The reference truncates the intermediate
 //         signal (zero outside [0, L) after the delay, zero history in front of the decimator): the <= 8
 //         outputs whose decimator window straddles those edges are recomputed with the exact masked two-stage
 //         sum, so the result differs from the reference only by rounding (<= 2e-6 of full scale; bar 1e-4).
 //     Detection (rc, TOA, amp, C/I) is shared and bit-exact in both modes.
+//   * occupancy: 16 waves per CU (4 per SIMD) for the fused kernel -- per-wave LDS is cut to 7.75 KB (NARROW
+//     buffers, trx_device.h) and the kernel kept under 128 VGPRs; measured, the kernel is bound by VALU + LDS
+//     issue (profiles/), so every reduction below is an instruction-count reduction.
 #include "trx_device.h"
 
 #define PH_A   180                 // entries per phase array (= 4 mod 16: conflict-free loader writes)
