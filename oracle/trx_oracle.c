@@ -1304,3 +1304,212 @@ int orc_channelizer_rotate(orc_channelizer *c, const orc_cf *in, int len, orc_cf
 	}
 	return 0;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Viterbi alternative of pullRadioVector (cfg->use_va): demodAnyBurst_va(), Transceiver.cpp:620-645,
+ * on top of Transceiver52M/grgsm_vitac/{grgsm_vitac.cpp, viterbi_detector.cc} (gr-gsm's MLSE receiver,
+ * 4 samples per symbol, 5-symbol channel, 16 states).  std::complex<float> arithmetic is spelled out:
+ * operator* = (ar*br - ai*bi, ar*bi + ai*br); division by (len, 0) = component-wise division (libgcc
+ * __divsc3 with a zero imaginary divisor); abs() = cabsf; std::pow(float, int) = pow in double.
+ * ---------------------------------------------------------------------------------------- */
+#define VA_OSR 4
+#define VA_CIR 5                                  /* CHAN_IMP_RESP_LENGTH, constants.h */
+#define VA_BURST 148                              /* BURST_SIZE */
+#define VA_AB_BURST (8 + 41 + 36 + 3)             /* grgsm_vitac.cpp:104 */
+#define VA_TRAIN_BEGINNING 5
+#define VA_TRAIN_POS (3 + 58 + 5)                 /* TRAIN_POS */
+
+static orc_cf va_norm_seq[8][26];                 /* d_norm_training_seq (TSC 0..7) */
+static orc_cf va_acc_seq[41];                     /* d_acc_training_seq */
+static int va_ready;
+
+/* grgsm_vitac.cpp:122-145 gmsk_mapper, then conj (:57-79) */
+static void va_gmsk_map(const char *bits, int n, orc_cf start, orc_cf *out)
+{
+	const orc_cf j = cf(0.0f, 1.0f);
+	out[0] = start;
+	int prev = 2 * (bits[0] - '0') - 1;
+	for (int i = 1; i < n; i++) {
+		int cur = 2 * (bits[i] - '0') - 1;
+		int enc = cur * prev;
+		out[i] = cmul(cmul(j, cf((float)enc, 0.0f)), out[i - 1]);
+		prev = cur;
+	}
+	for (int i = 0; i < n; i++)
+		out[i] = cf(out[i].re, -out[i].im);
+}
+
+static void va_init(void)
+{
+	if (va_ready) return;
+	va_gmsk_map(RACH_BITS[0], 41, cf(0.0f, -1.0f), va_acc_seq);            /* ACCESS_BITS, constants.h:91-95 */
+	for (int t = 0; t < 8; t++)
+		va_gmsk_map(TSC_BITS[t], 26, TSC_BITS[t][0] == '0' ? cf(1.0f, 0.0f) : cf(-1.0f, 0.0f), va_norm_seq[t]);
+	va_ready = 1;
+}
+
+/* grgsm_vitac.cpp:147-155 correlate_sequence; x = 0 outside [0, n) */
+static orc_cf va_correlate(const orc_cf *seq, int len, const orc_cf *x, int n, int pos)
+{
+	orc_cf r = cf(0.0f, 0.0f);
+	for (int ii = 0; ii < len; ii++) {
+		int j = pos + ii * VA_OSR;
+		orc_cf t = cmul(seq[ii], (j >= 0 && j < n) ? x[j] : cf(0.0f, 0.0f));
+		r.re += t.re;
+		r.im += t.im;
+	}
+	return cf(r.re / (float)len, -r.im / (float)len);
+}
+
+/* grgsm_vitac.cpp:183-232 get_chan_imp_resp: returns the first sample of the impulse response */
+static int va_chan_imp_resp(const orc_cf *x, int n, orc_cf *cir, int start_pos, int stop_pos,
+			    const orc_cf *tseq, int tseqlen)
+{
+	const int nw = stop_pos - start_pos, wl = VA_CIR * VA_OSR;
+	orc_cf corr[256];
+	float power[256], energy[256];
+	for (int ii = 0; ii < nw; ii++) {
+		corr[ii] = va_correlate(tseq, tseqlen, x, n, start_pos + ii);
+		power[ii] = (float)pow((double)hypotf(corr[ii].re, corr[ii].im), 2.0);   /* abs(): cabsf = hypotf */
+	}
+	float ws = 0;
+	int ne = 0;
+	for (int i = 0; i < wl; i++)
+		ws += power[i];
+	energy[ne++] = ws;
+	for (int i = wl; i < nw; i++) {
+		ws += power[i] - power[i - wl];
+		energy[ne++] = ws;
+	}
+	int best = 0;                                  /* std::max_element: first largest */
+	for (int i = 1; i < ne; i++)
+		if (energy[best] < energy[i]) best = i;
+	for (int ii = 0; ii < wl; ii++)
+		cir[ii] = corr[best + ii];
+	return start_pos + best;
+}
+
+/* viterbi_detector.cc:62-392.  Regular structure of its 32 hand-written add-compare-select statements:
+ * new state s comes from old states p = s>>1 and p+8; on imaginary steps candidate 1 is
+ * old[p] +- in -+ inc[IA[p]], candidate 2 old[p+8] +- in +- inc[IB[p]] (upper signs for even s); on real steps
+ * old[p] -+ in -+ inc[7-p], old[p+8] -+ in +- inc[p].  Evaluated left to right as written there. */
+static const int VA_IA[8] = { 2, 3, 0, 1, 6, 7, 4, 5 }, VA_IB[8] = { 5, 4, 7, 6, 1, 0, 3, 2 };
+
+void orc_va_viterbi(const orc_cf *in, unsigned n, const orc_cf *rhh, unsigned start_state,
+		    const unsigned *stop_states, unsigned nstops, float *out)
+{
+	float inc[8], pm1[16], pm2[16], *oldm = pm1, *newm = pm2;
+	float *trans = malloc((size_t)n * 16 * sizeof(float));
+	int real_imag = 0;
+	for (int i = 0; i < 16; i++) pm1[i] = (-10e30);
+	if (start_state < 16) pm1[start_state] = 0;   /* the reference writes out of bounds for larger values */
+	for (int m = 0; m < 8; m++) {
+		float v = (m & 1) ? rhh[1].im : -rhh[1].im;
+		v = (m & 2) ? v + rhh[2].re : v - rhh[2].re;
+		v = (m & 4) ? v + rhh[3].im : v - rhh[3].im;
+		inc[m] = v + rhh[4].re;
+	}
+	for (unsigned k = 0; k < n; k++) {
+		real_imag = !(k & 1);                      /* even samples: imaginary part */
+		float sym = real_imag ? in[k].im : in[k].re;
+		for (int s = 0; s < 16; s++) {
+			int p = s >> 1, odd = s & 1;
+			float c1, c2;
+			if (real_imag) {
+				if (!odd) { c1 = oldm[p] + sym - inc[VA_IA[p]]; c2 = oldm[p + 8] + sym + inc[VA_IB[p]]; }
+				else      { c1 = oldm[p] - sym + inc[VA_IA[p]]; c2 = oldm[p + 8] - sym - inc[VA_IB[p]]; }
+			} else {
+				if (!odd) { c1 = oldm[p] - sym - inc[7 - p]; c2 = oldm[p + 8] - sym + inc[p]; }
+				else      { c1 = oldm[p] + sym + inc[7 - p]; c2 = oldm[p + 8] + sym - inc[p]; }
+			}
+			float d = c2 - c1;
+			newm[s] = (d < 0) ? c1 : c2;
+			trans[k * 16 + s] = d;
+		}
+		float *t = oldm; oldm = newm; newm = t;
+	}
+	unsigned best = stop_states[0];
+	float bm = oldm[best];
+	for (unsigned i = 1; i < nstops; i++)
+		if (oldm[stop_states[i]] > bm) { bm = oldm[stop_states[i]]; best = stop_states[i]; }
+	unsigned state = best;
+	int out_bit = 0;
+	for (unsigned k = n; k-- > 0;) {
+		float tv = trans[k * 16 + state];
+		int decision = tv > 0;
+		out[k] = (decision != out_bit) ? -tv : tv;
+		int parity = ((state >> 1) ^ state) & 1;   /* parity_table: 0 1 1 0 0 1 1 0 ... */
+		out_bit = out_bit ^ real_imag ^ parity;
+		state = (state >> 1) + (decision ? 8 : 0); /* prev_table */
+		real_imag = !real_imag;
+	}
+	free(trans);
+}
+
+/* grgsm_vitac.cpp:82-108 detect_burst_generic: x = 0 outside [0, n) */
+static void va_detect_burst(const orc_cf *x, int n, const orc_cf *cir, int burst_start, int burst_size,
+			    unsigned start_state, float *out)
+{
+	const int fl = VA_CIR * VA_OSR;
+	orc_cf rt[VA_CIR * VA_OSR], rhh[VA_CIR], *filt = malloc((size_t)burst_size * sizeof(orc_cf));
+	for (int k = fl - 1; k >= 0; k--) {            /* autocorrelation :158-166 */
+		rt[k] = cf(0.0f, 0.0f);
+		for (int i = k; i < fl; i++) {
+			orc_cf t = cmul(cir[i], cf(cir[i - k].re, -cir[i - k].im));
+			rt[k].re += t.re;
+			rt[k].im += t.im;
+		}
+	}
+	for (int ii = 0; ii < VA_CIR; ii++)
+		rhh[ii] = cf(rt[ii * VA_OSR].re, -rt[ii * VA_OSR].im);
+	for (int m = 0; m < burst_size; m++) {         /* mafi :168-181 */
+		int a = m * VA_OSR;
+		filt[m] = cf(0.0f, 0.0f);
+		for (int ii = 0; ii < fl; ii++) {
+			if (a + ii >= burst_size * VA_OSR) break;
+			int j = burst_start + a + ii;
+			orc_cf t = cmul((j >= 0 && j < n) ? x[j] : cf(0.0f, 0.0f), cir[ii]);
+			filt[m].re += t.re;
+			filt[m].im += t.im;
+		}
+	}
+	const unsigned stops[2] = { 4, 12 };
+	orc_va_viterbi(filt, (unsigned)burst_size, rhh, start_state, stops, 2, out);
+	free(filt);
+}
+
+/* Transceiver.cpp:782-784 + :620-645: scaleVector(burst, scale) then demodAnyBurst_va().  soft: 156 values,
+ * +-127 for the demodulated bits (148 normal / 88 access), 0 for the rest (the reference leaves bits 88..147 of an
+ * access burst uninitialised).  Samples outside the burst read as 0 (the reference reads up to 2 samples past its
+ * 625-sample vector for the latest burst position).  Returns the burst start (samples), -1 on a bad argument. */
+int orc_demod_any_burst_va(const orc_cf *burst, int n, int type, int tsc, int max_toa, float scale, float *soft)
+{
+	va_init();
+	if (tsc < 0 || tsc > 7) return -1;
+	orc_cf *x = malloc((size_t)n * sizeof(orc_cf)), cir[VA_CIR * VA_OSR];
+	for (int i = 0; i < n; i++)
+		x[i] = cmul(burst[i], cf(scale, 0.0f));    /* scaleVector :1198-1205 */
+	float out[VA_BURST];
+	int nb, start;
+	if (type == ORC_TSC) {
+		const int center = VA_TRAIN_POS;           /* get_norm_chan_imp_resp :263-272 */
+		start = va_chan_imp_resp(x, n, cir, (center - 5) * VA_OSR + 1, (center + 5 + VA_CIR) * VA_OSR,
+					 &va_norm_seq[tsc][VA_TRAIN_BEGINNING], 26 - 2 * VA_TRAIN_BEGINNING) - center * VA_OSR;
+		if (start < 0) start = 0;
+		nb = VA_BURST;
+		va_detect_burst(x, n, cir, start, nb, 3, out);
+	} else {
+		const int center = 8 + 5;                  /* get_access_imp_resp(..., max_delay = 0) :244-253 */
+		start = va_chan_imp_resp(x, n, cir, (center - 5) * VA_OSR + 1, (center + 5 + VA_CIR + 0) * VA_OSR,
+					 &va_acc_seq[VA_TRAIN_BEGINNING], 41 - 2 * VA_TRAIN_BEGINNING) - center * VA_OSR;
+		if (start < 0) start = 0;
+		nb = VA_AB_BURST;
+		va_detect_burst(x, n, cir, start, nb, (unsigned)max_toa, out);   /* rach_max_toa lands in start_state (:633) */
+	}
+	for (int i = 0; i < 156; i++)
+		soft[i] = 0.0f;
+	for (int i = 0; i < nb; i++)
+		soft[i] = (float)((out[i] > 0 ? -127 : 127) * -1);   /* sbit "pre flip" (:107) and "* -1" (:638) */
+	free(x);
+	return start;
+}

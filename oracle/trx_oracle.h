@@ -140,6 +140,11 @@ void orc_pull_batch(const int16_t *iq, size_t n_bursts, int burst_len, int sps,
 		    const orc_burst_params *params, float threshold, double full_scale,
 		    orc_burst_result *res, float *soft, int soft_stride, int slice);
 
+/* Viterbi alternative (cfg->use_va): Transceiver.cpp:620-645, :782-784 over grgsm_vitac/ */
+int   orc_demod_any_burst_va(const orc_cf *burst, int n, int type, int tsc, int max_toa, float scale, float *soft);
+void  orc_va_viterbi(const orc_cf *in, unsigned n, const orc_cf *rhh, unsigned start_state,
+		     const unsigned *stop_states, unsigned nstops, float *out);
+
 /* TRXD packing, proto_trxd.c:36-66: returns toa_int (1/256 sym), ci centi-bel, soft uint8 */
 int     orc_trxd_toa256(double toa);
 int16_t orc_trxd_ci_cb(float ci);

@@ -7,6 +7,7 @@ Produces DATA fixtures only (inputs + expected outputs), never reference source 
   nb_chunk_tsc7.cfile, demodbits_tsc7.s8
                         -- the reference's captured 4-SPS TSC-7 burst and its known-good bits
                            (utils/va-test/, used by burst-gen.cpp:256-290)
+  ref_va_vectors.npz    -- outputs of the reference's own viterbi_detector() (oracle/_ref/libref_va.so)
   ref_arch_vectors.npz  -- outputs of the reference's own arch kernels and Resampler class,
                            compiled unmodified into oracle/_ref (oracle/Makefile), on seeded inputs:
                            convolve_real/convolve_complex (generic + SSE builds), convert_short_float,
@@ -18,6 +19,7 @@ import os
 import re
 import shutil
 import subprocess
+import sys
 
 import numpy as np
 
@@ -60,8 +62,40 @@ def aligned(n_floats, align=16):
     return raw[off:off + n_floats]
 
 
+def make_va_vectors():
+    """ref_va_vectors.npz -- the reference's own viterbi_detector() (grgsm_vitac/viterbi_detector.cc compiled
+    unmodified into oracle/_ref/libref_va.so) on seeded matched-filter outputs: normal (148) and access (88) lengths,
+    start states 3 / other, both stop states reachable."""
+    L = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_va.so"))
+    L.ref_viterbi_detector.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_uint, C.c_void_p, C.c_uint, C.c_void_p]
+    rng = np.random.default_rng(0x5A17)
+    out = {}
+    stops = np.array([4, 12], dtype=np.uint32)
+    cases = []
+    for k in range(48):
+        n = 148 if k % 3 else 88
+        bits = rng.integers(0, 2, n) * 2 - 1
+        # something Viterbi-like: +-1 symbols alternating imag / real plus ISI-ish noise, random scale
+        x = np.zeros(n, dtype=np.complex64)
+        x.real = np.where(np.arange(n) % 2 == 1, bits, 0) + rng.normal(0, 0.4, n)
+        x.imag = np.where(np.arange(n) % 2 == 0, bits, 0) + rng.normal(0, 0.4, n)
+        x *= np.float32(10 ** rng.uniform(-3, 1))
+        rhh = (rng.normal(0, 0.3, 5) + 1j * rng.normal(0, 0.3, 5)).astype(np.complex64)
+        rhh[0] = 1.0
+        start = 3 if k % 4 else int(rng.integers(0, 16))
+        y = np.zeros(n, dtype=np.float32)
+        L.ref_viterbi_detector(x.ctypes.data, n, rhh.ctypes.data, start, stops.ctypes.data, 2, y.ctypes.data)
+        out[f"in_{k}"], out[f"rhh_{k}"], out[f"out_{k}"] = x.view(np.float32), rhh.view(np.float32), y
+        cases.append((n, start))
+    out["cases"] = np.array(cases, dtype=np.int32)
+    np.savez_compressed(os.path.join(HERE, "ref_va_vectors.npz"), **out)
+
+
 def main():
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"], stdout=subprocess.DEVNULL)
+    make_va_vectors()
+    if len(sys.argv) > 1 and sys.argv[1] == "va":
+        return
 
     g = parse_golden_header(os.path.join(REF, "tests/Transceiver52M/convolve_test_golden.h"))
     assert len(g) == 12, sorted(g)

@@ -85,6 +85,9 @@ def lib():
                                        C.POINTER(Ebp)]
     L.orc_detect_sch_burst.restype = C.c_int
     L.orc_detect_sch_burst.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.POINTER(Ebp)]
+    L.orc_demod_any_burst_va.restype = C.c_int
+    L.orc_demod_any_burst_va.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]
+    L.orc_va_viterbi.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_uint, C.c_void_p, C.c_uint, C.c_void_p]
     L.orc_demod_any_burst.restype = C.c_int
     L.orc_demod_any_burst.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(Ebp), C.c_void_p]
     L.orc_modulate_burst.restype = C.c_int
@@ -164,6 +167,26 @@ def detect_sch_burst(burst, threshold, sps, state):
     e = Ebp()
     rc = lib().orc_detect_sch_burst(_ptr(b), len(b), threshold, sps, state, C.byref(e))
     return rc, e
+
+
+VA_SCALE = np.float32(1.0 / float((1 << 14) - 1))      # Transceiver.cpp:783
+
+
+def demod_any_burst_va(burst, ctype, tsc, max_toa, scale=VA_SCALE):
+    """scaleVector + demodAnyBurst_va (Transceiver.cpp:782-784, :620-645).  Returns (burst_start, soft[156])."""
+    b = np.ascontiguousarray(burst, dtype=np.complex64)
+    soft = np.zeros(156, dtype=np.float32)
+    st = lib().orc_demod_any_burst_va(_ptr(b), len(b), ctype, tsc, max_toa, float(scale), _ptr(soft))
+    return st, soft
+
+
+def va_viterbi(x, rhh, start_state, stops=(4, 12)):
+    x = np.ascontiguousarray(x, dtype=np.complex64)
+    r = np.ascontiguousarray(rhh, dtype=np.complex64)
+    s = np.array(stops, dtype=np.uint32)
+    out = np.zeros(len(x), dtype=np.float32)
+    lib().orc_va_viterbi(_ptr(x), len(x), _ptr(r), start_state, _ptr(s), len(s), _ptr(out))
+    return out
 
 
 def demod_any_burst(burst, ctype, sps, ebp):

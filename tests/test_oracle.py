@@ -229,3 +229,76 @@ def test_sch_detect_states():
     assert rc == 1 and rc_f == 1
     # BUFFER subtracts 3+39+64 = 106 where FULL subtracts head = 105 (:1853-1858): one symbol apart by construction
     assert abs((e.toa - 5000) - (e_f.toa - 1.0)) < 0.02
+
+
+# ---- Viterbi alternative (cfg->use_va): Transceiver.cpp:620-645 over grgsm_vitac/ --------------------------------
+def test_va_viterbi_matches_compiled_reference(golden_dir):
+    """orc_va_viterbi() (table-driven restatement) == the reference's viterbi_detector() compiled unmodified
+    (oracle/_ref/libref_va.so, vectors in ref_va_vectors.npz), bit for bit, incl. the soft magnitudes."""
+    v = np.load(os.path.join(golden_dir, "ref_va_vectors.npz"))
+    for k, (n, start) in enumerate(v["cases"]):
+        out = O.va_viterbi(v[f"in_{k}"].view(np.complex64), v[f"rhh_{k}"].view(np.complex64), int(start))
+        assert len(out) == n
+        assert np.array_equal(out.view(np.uint32), v[f"out_{k}"].view(np.uint32)), k
+
+
+def _va_burst(rng, tsc, delay_samples, snr_db=25.0, amp=8000.0):
+    """625-sample 4-SPS normal burst as the VA path sees it.  Its buffer starts 20 samples (5 symbols) before the one
+    the detector looks at (Transceiver.cpp:760-762, osmo-trx.cpp:97), so a burst placed `delay_samples` in shows up
+    there with TOA = delay/4 - 0.4 symbols; get_norm_chan_imp_resp() tracks starts of 0 .. 20 samples."""
+    from osmo_trx_amd.synth import TSC_BITS
+    tsc_bits = np.array([int(c) for c in TSC_BITS[tsc]], dtype=np.uint8)
+    bits = rng.integers(0, 2, 148, dtype=np.uint8)
+    bits[:3] = 0
+    bits[-3:] = 0
+    bits[61:87] = tsc_bits
+    x = O.modulate_burst(bits, 8, 4)
+    y = np.zeros(625, dtype=np.complex64)
+    off = delay_samples
+    m = min(len(x), 625 - off)
+    y[off:off + m] = x[:m] * np.complex64(amp * np.exp(1j * rng.uniform(0, 2 * np.pi)))
+    sigma = amp * 10 ** (-snr_db / 20) / np.sqrt(2)
+    y += ((rng.normal(size=625) + 1j * rng.normal(size=625)) * sigma).astype(np.complex64)
+    return y, bits
+
+
+def test_va_demodulates_normal_bursts():
+    """End to end: the MLSE receiver returns the transmitted bits of a clean Laurent-GMSK burst for every TSC and a
+    range of delays; output format of demodAnyBurst_va (+-127, 8 trailing zeros)."""
+    rng = np.random.default_rng(31)
+    errs = 0
+    for k in range(32):
+        tsc = k % 8
+        d = int(rng.integers(0, 19))
+        y, bits = _va_burst(rng, tsc, d)
+        start, soft = O.demod_any_burst_va(y, O.TSC, tsc, 3)
+        assert abs(start - (d + 1)) <= 6                           # 5-symbol energy window: coarse by design
+        assert set(np.unique(soft[:148])) <= {-127.0, 127.0} and not soft[148:].any()
+        hard = (soft[:148] > 0).astype(np.uint8)
+        errs += int((hard != bits).sum())
+    assert errs <= 8, errs                                     # 32 x 148 bits at 25 dB SNR
+
+
+def test_va_access_burst_and_quirks():
+    """RACH branch: get_access_imp_resp() + 88-bit detect_burst_ab(); rach_max_toa lands in the Viterbi start state
+    (Transceiver.cpp:633): values >= 16 select no start state here (the reference stores out of bounds).  Bits 88..147
+    of the output are zero here (uninitialised in the reference)."""
+    rng = np.random.default_rng(33)
+    ab = np.array([int(c) for c in "01001011011111111001100110101010001111000"], dtype=np.uint8)
+    errs = 0
+    for k in range(16):
+        bits = np.concatenate([np.array([0, 0, 1, 1, 1, 0, 1, 0], np.uint8), ab, rng.integers(0, 2, 36, dtype=np.uint8),
+                               np.zeros(3, np.uint8)])
+        x = O.modulate_burst(bits, 8, 4)
+        off = int(rng.integers(2, 20))                             # tracked starts: 0 .. 20 samples = offsets 4 .. 24 here
+        y = np.zeros(625, dtype=np.complex64)
+        m = min(len(x), 625 - off)
+        y[off:off + m] = x[:m] * np.complex64(5000.0 * np.exp(1j * rng.uniform(0, 6.28)))
+        y += ((rng.normal(size=625) + 1j * rng.normal(size=625)) * 100).astype(np.complex64)
+        for max_toa in (3, 63):
+            start, soft = O.demod_any_burst_va(y, O.RACH, 0, max_toa)
+            assert set(np.unique(soft[:88])) <= {-127.0, 127.0} and not soft[88:].any()
+            if max_toa == 3:
+                errs += int(((soft[:88] > 0).astype(np.uint8) != bits).sum())
+    assert errs <= 8, errs
+    assert O.demod_any_burst_va(y, O.TSC, 9, 3)[0] == -1          # tsc > 7
