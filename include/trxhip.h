@@ -170,6 +170,19 @@ int trxhip_delay_vector_batch_cf32(trxhip_ctx *ctx, const float *d_in_cf32, floa
  * complex64 samples. */
 int trxhip_scale_vector_cf32(trxhip_ctx *ctx, float *d_x_cf32, size_t len, float scale_re, float scale_im, void *stream);
 
+/* The Viterbi alternative of pullRadioVector (cfg->use_va): scaleVector(burst, scale) + demodAnyBurst_va()
+ * (Transceiver.cpp:782-784 with scale = 1/16383, :620-645) over gr-gsm's 4-samples-per-symbol MLSE receiver in
+ * Transceiver52M/grgsm_vitac/ (get_norm_chan_imp_resp / get_access_imp_resp, detect_burst_nb / _ab, viterbi_detector).
+ * d_iq_cf32: n_bursts x burst_len complex64, the burst as that path sees it (it starts 20 samples before the one the
+ * detector looks at, Transceiver.cpp:760-762); d_params[b].type TSC selects the normal-burst branch, anything else
+ * the access-burst branch (whose Viterbi start state is max_toa, as in the reference; >= 16 selects none); tsc 0..7.
+ * d_soft[b][0..soft_stride): +-127 for the 148 (normal) / 88 (access) demodulated bits, 0 behind them; with
+ * TRXHIP_FLAG_SLICE through vectorSlicer() (0 / 1).  d_starts (may be NULL): estimated burst start in samples.
+ * Samples outside the burst read as 0.  soft_stride >= 148. */
+int trxhip_demod_va_batch_cf32(trxhip_ctx *ctx, const float *d_iq_cf32, const trxhip_burst_params *d_params,
+			       float *d_soft, int32_t *d_starts, size_t n_bursts, int burst_len, float scale,
+			       int soft_stride, int flags, void *stream);
+
 /* energyDetect() on its own (sigProcLib.h:105, sigProcLib.cpp:1573-1585): mean |x|^2 of `window` samples at
  * stride 4 from sample 0 of each burst (complex64); d_energy: n_bursts floats. */
 int trxhip_energy_detect_batch_cf32(trxhip_ctx *ctx, const float *d_iq_cf32, size_t n_bursts, int burst_len,

@@ -21,7 +21,7 @@ LIB = os.path.join(LIBDIR, "libtrxhip.so")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-result"]
 
-LIB_SOURCES = ["trx_kernel4.hip", "trx_kernels.hip", "trx_aux_kernels.hip", "trx_sch.hip", "trx_capi.cpp", "trx_tables.cpp"]
+LIB_SOURCES = ["trx_kernel4.hip", "trx_kernels.hip", "trx_aux_kernels.hip", "trx_sch.hip", "trx_va.hip", "trx_capi.cpp", "trx_tables.cpp"]
 
 
 def _stale(target, sources):

@@ -216,6 +216,28 @@ void scaleVector(signalVector &x, complex scale)
 		hipStreamSynchronize(t.stream);
 }
 
+SoftVector *demodAnyBurst_va(const signalVector &burst, CorrType type, int sps, int rach_max_toa, int tsc)
+{
+	Scratch &t = tls;
+	(void)sps;                                                 /* the reference ignores it too: the receiver is 4 SPS */
+	if (!g_ctx || tsc < 0 || tsc > 7 || !burst.size() || !t.ensure(1, burst.bytes(), 156))
+		return NULL;
+	trxhip_burst_params prm;
+	memset(&prm, 0, sizeof(prm));
+	prm.type = (uint8_t)type;
+	prm.tsc = (uint8_t)tsc;
+	prm.max_toa = (uint16_t)(rach_max_toa < 0 ? 0 : rach_max_toa > 65535 ? 65535 : rach_max_toa);
+	SoftVector *bits = new SoftVector(148 + 8);
+	if (!h2d(t.d_iq, burst.begin(), burst.bytes(), t.stream) || !h2d(t.d_prm, &prm, sizeof(prm), t.stream) ||
+	    trxhip_demod_va_batch_cf32(g_ctx, static_cast<const float *>(t.d_iq), t.d_prm, t.d_soft, NULL, 1, (int)burst.size(),
+				       1.0f, 156, 0, t.stream) != TRXHIP_OK ||
+	    !d2h(bits->begin(), t.d_soft, 156 * sizeof(float), t.stream) || hipStreamSynchronize(t.stream) != hipSuccess) {
+		delete bits;
+		return NULL;
+	}
+	return bits;
+}
+
 int detectSCHBurst(signalVector &burst, float thresh, int sps, sch_detect_type state, struct estim_burst_params *ebp)
 {
 	Scratch &t = tls;

@@ -69,6 +69,11 @@ int detectSCHBurst(signalVector &rxBurst, float detectThreshold, int sps, sch_de
  *  Returns a new SoftVector the caller deletes (Transceiver.cpp:805), or NULL. */
 SoftVector *demodAnyBurst(const signalVector &burst, CorrType type, int sps, struct estim_burst_params *ebp);
 
+/** The Viterbi alternative of pullRadioVector (cfg->use_va): demodAnyBurst_va(), a file-static of the reference's
+ *  Transceiver.cpp (:620-645) over grgsm_vitac/.  `burst` is the already scaled vector (Transceiver.cpp:783).
+ *  Returns a new SoftVector of 156 values (+-127, trailing zeros) the caller deletes, or NULL. */
+SoftVector *demodAnyBurst_va(const signalVector &burst, CorrType type, int sps, int rach_max_toa, int tsc);
+
 /* ---- batched form of the pullRadioVector() DSP core (Transceiver.cpp:724-803) ---- */
 struct BurstRequest {
 	const int16_t *iq;     /* burst_len x (I,Q) as delivered by RadioDevice::readSamples */

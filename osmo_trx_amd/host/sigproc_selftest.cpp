@@ -3,6 +3,7 @@
 // sequence).  Reads inputs prepared by tests/test_gpu_host_shim.py, writes results as plain text/binary.
 //   sigproc_selftest capture <cfile> <out.txt>
 //   sigproc_selftest delay <cfile> <delay> <scale_re> <scale_im> <out.cf32>
+//   sigproc_selftest va <cfile> <tsc> <out.f32>
 //   sigproc_selftest sch <cfile> <0 full | 1 narrow | 2 buffer> <out.txt>
 //   sigproc_selftest batch <iq.s16> <params.bin> <n> <sps> <burst_len> <out_results.bin> <out_soft.bin>
 #include <cstdio>
@@ -72,6 +73,21 @@ int main(int argc, char **argv)
 		scaleVector(*d, complex((float)atof(argv[4]), (float)atof(argv[5])));
 		FILE *o = fopen(argv[6], "wb");
 		fwrite(d->begin(), 1, d->bytes(), o);
+		fclose(o);
+		sigProcLibDestroy();
+		return 0;
+	}
+
+	if (!strcmp(argv[1], "va") && argc == 5) {
+		/* Transceiver.cpp:782-784: scaleVector(*burst, 1/16383) then demodAnyBurst_va(*burst, TSC, 4, max_toa, tsc) */
+		std::vector<char> raw = slurp(argv[2]);
+		size_t n = raw.size() / sizeof(complex);
+		signalVector sv(reinterpret_cast<complex *>(raw.data()), 0, n);
+		scaleVector(sv, complex((float)(1. / (float)((1 << 14) - 1)), 0));
+		std::unique_ptr<SoftVector> bits(demodAnyBurst_va(sv, TSC, 4, 3, atoi(argv[3])));
+		if (!bits) return 4;
+		FILE *o = fopen(argv[4], "wb");
+		fwrite(bits->begin(), 1, bits->bytes(), o);
 		fclose(o);
 		sigProcLibDestroy();
 		return 0;

@@ -57,6 +57,7 @@ SYMBOLS = {
     "trxhip_energy_detect_batch_cf32": (_I, [_VP, _VP, _SZ, _I, C.c_uint, _VP, _VP]),
     "trxhip_delay_vector_batch_cf32": (_I, [_VP, _VP, _VP, _VP, _SZ, _I, _VP]),
     "trxhip_scale_vector_cf32": (_I, [_VP, _VP, _SZ, C.c_float, C.c_float, _VP]),
+    "trxhip_demod_va_batch_cf32": (_I, [_VP, _VP, _VP, _VP, _VP, _SZ, _I, C.c_float, _I, _I, _VP]),
     "trxhip_detect_sch_batch_cf32": (_I, [_VP, _VP, _VP, _SZ, _SZ, _I, _I, C.c_float, _VP]),
     "trxhip_vector_slicer": (_I, [_VP, _VP, _VP, _SZ, _VP]),
     "trxhip_pack_trxd_batch": (_I, [_VP, _VP, _VP, _I, _VP, _SZ, _F, _VP]),
@@ -228,6 +229,19 @@ class TrxHip:
         _check(self.L.trxhip_scale_vector_cf32(self.h, self._dev(x_cf32), x_cf32.numel(), scale.real, scale.imag,
                                                self._stream(stream)), "trxhip_scale_vector_cf32")
         return x_cf32
+
+    def demod_va(self, iq_cf32, params, scale=1.0 / 16383.0, soft_stride=156, slice_bits=False, stream=None):
+        """Viterbi alternative (cfg->use_va): scaleVector + demodAnyBurst_va.  iq complex64[n, L], params uint8[n, 8].
+        Returns (soft float32[n, soft_stride], starts int32[n])."""
+        torch = self.torch
+        n, burst_len = iq_cf32.shape
+        soft = torch.empty((n, soft_stride), dtype=torch.float32, device=iq_cf32.device)
+        starts = torch.empty(n, dtype=torch.int32, device=iq_cf32.device)
+        _check(self.L.trxhip_demod_va_batch_cf32(self.h, self._dev(iq_cf32), self._dev(params), self._dev(soft),
+                                                 self._dev(starts), n, burst_len, scale, soft_stride,
+                                                 FLAG_SLICE if slice_bits else 0, self._stream(stream)),
+               "trxhip_demod_va_batch_cf32")
+        return soft, starts
 
     def detect_sch(self, iq_cf32, state=0, sps=4, threshold=4.0, stream=None):
         """detectSCHBurst() for complex64[n_bufs, buf_len] buffers; state = SCH_DETECT_FULL / _NARROW / _BUFFER.

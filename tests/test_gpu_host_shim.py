@@ -149,3 +149,18 @@ def test_delay_and_scale_vector_api(exe, tmp_path):
         re = ref.real * sc.real - ref.imag * sc.imag                 # Complex.h:74 operand order, fp32
         im = ref.real * sc.imag + ref.imag * sc.real
         assert np.array_equal(got.real, re.astype(np.float32)) and np.array_equal(got.imag, im.astype(np.float32)), d
+
+
+def test_va_through_shim(exe, tmp_path):
+    """scaleVector() + demodAnyBurst_va() of the shim (Transceiver.cpp:782-784) vs the oracle."""
+    from test_oracle import _va_burst
+    rng = np.random.default_rng(23)
+    for tsc in (0, 5):
+        y, bits = _va_burst(rng, tsc, 7, snr_db=20.0)
+        (tmp_path / "va.cfile").write_bytes(y.tobytes())
+        out = tmp_path / "va.f32"
+        subprocess.check_call([exe, "va", str(tmp_path / "va.cfile"), str(tsc), str(out)])
+        got = np.fromfile(out, dtype=np.float32)
+        _, ref = O.demod_any_burst_va(y, O.TSC, tsc, 3)
+        assert len(got) == 156 and np.array_equal(got, ref)
+        assert int(((got[:148] > 0).astype(np.uint8) != bits).sum()) <= 2

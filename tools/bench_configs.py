@@ -33,3 +33,16 @@ iq, p, _ = synth.make_access_bursts(n, "cuda:0"); run("configs[2] RACH, max_toa 
 iq, p, _ = synth.make_access_bursts(n, "cuda:0", ext=True); run("configs[2] EXT_RACH (TS0/1/2), max_toa 63", iq, p)
 iq, p = synth.make_mixed_bursts(n, "cuda:0"); run("configs[4] 7:1 NB:RACH mix (per GPU)", iq, p)
 iq, p, _ = synth.make_edge_bursts(n, "cuda:0"); run("EDGE 8-PSK (444 soft bits)", iq, p, stride=444)
+
+# Viterbi alternative (cfg->use_va): its own kernel, one wave per burst
+iq, p, _ = synth.make_normal_bursts(n, "cuda:0", 4)
+x = torch.view_as_complex(iq.to(torch.float32).contiguous())
+dp = trx.params_tensor(p)
+f = lambda: trx.demod_va(x, dp)
+f(); torch.cuda.synchronize()
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+a.record()
+for _ in range(3): f()
+b.record(); torch.cuda.synchronize()
+ms = a.elapsed_time(b) / 3
+print(f"{'Viterbi alternative (use_va), NB, demod only':44s} {ms:7.3f} ms  {n / ms / 1e3:7.1f} Mbursts/s")
