@@ -10,12 +10,14 @@
 //     serial (59 steps on wave-uniform LDS reads) -- it decides the burst position
 //   * matched filter: one output symbol per lane and round, 20 complex taps in order
 //   * add-compare-select: lane = state (16 lanes), predecessors s>>1 and (s>>1)+8 fetched with a 16-wide shuffle,
-//     the 32 hand-written ACS statements of the reference reduced to their sign/increment pattern; decisions and
-//     path-metric differences go to a [148][16] LDS table, traceback is the reference's serial walk
+//     the 32 hand-written ACS statements of the reference reduced to their sign/increment pattern; of every
+//     path-metric difference only (d > 0, d != 0) matter for the +-127 output, so a step's table row is one ballot
+//     word; the traceback is the reference's serial walk on the scalar unit
 // Operand order follows the reference statement by statement (-ffp-contract=off): the +-127 outputs are bit-exact.
 #include "trx_device.h"
 
 #define VA_WPB 4
+#define VA_SLICE_BYTES(xs_len) ((size_t)((xs_len) + 64 + VA_FL + VA_NB + 32 + 8) * sizeof(c32) + (size_t)(64 + 192) * sizeof(float))
 #define VA_OSR 4
 #define VA_CIR 5
 #define VA_FL (VA_CIR * VA_OSR)
@@ -39,8 +41,8 @@ va_demod_kernel(const c32 *__restrict__ iq, const trxhip_burst_params *__restric
 	const int lane = threadIdx.x & (WAVE - 1);
 	const int wave = uni((int)(threadIdx.x >> 6));
 	const int xs_len = (L + 1) & ~1;
-	// per-wave slice: xs[L] | corr[64] | cir[20] | filt[148] | seq[32] | rhh[8] : c32;  power[64] | out[148] | trans[148*16] : float
-	const size_t slice_bytes = (size_t)(xs_len + 64 + VA_FL + VA_NB + 32 + 8) * sizeof(c32) + (size_t)(64 + VA_NB + 4 + VA_NB * 16) * sizeof(float);
+	// per-wave slice: xs[L] | corr[64] | cir[20] | filt[148] | seq[32] | rhh[8] : c32;  power[64] : float | tr[192] : u32
+	const size_t slice_bytes = VA_SLICE_BYTES(xs_len);
 	char *base = smem + (size_t)wave * slice_bytes;
 	c32 *xs = reinterpret_cast<c32 *>(base);
 	c32 *corr = xs + xs_len;
@@ -49,8 +51,7 @@ va_demod_kernel(const c32 *__restrict__ iq, const trxhip_burst_params *__restric
 	c32 *seq = filt + VA_NB;
 	c32 *rhh = seq + 32;
 	float *power = reinterpret_cast<float *>(rhh + 8);
-	float *outv = power + 64;
-	float *trans = outv + VA_NB + 4;
+	unsigned *tr = reinterpret_cast<unsigned *>(power + 64);   // decision words, one per step (entries >= 148 unused)
 
 	const unsigned b = blockIdx.x * VA_WPB + wave;
 	if (b >= n_bursts)
@@ -177,6 +178,8 @@ va_demod_kernel(const c32 *__restrict__ iq, const trxhip_burst_params *__restric
 	float pm = (-10e30);
 	if ((unsigned)s == start_state)
 		pm = 0.0f;
+	// Only two bits of every path-metric difference survive into the +-127 output: d > 0 (the decision) and d != 0
+	// (an output of +-0 is "not > 0").  Per step the 16 states' bits are one ballot word: tr[k] = nz << 16 | pos.
 	for (int k = 0; k < nbits; k++) {
 		const bool imag = !(k & 1);
 		const c32 f = filt[k];
@@ -191,34 +194,44 @@ va_demod_kernel(const c32 *__restrict__ iq, const trxhip_burst_params *__restric
 		const float c2 = (o2 + ss) + (odd ? -l2 : l2);
 		const float d = c2 - c1;
 		pm = (d < 0) ? c1 : c2;
-		if (lane < 16)
-			trans[k * 16 + s] = d;
+		const unsigned pos = (unsigned)__ballot(d > 0) & 0xffffu, nz = (unsigned)__ballot(d != 0) & 0xffffu;
+		if (lane == 0)
+			tr[k] = (nz << 16) | pos;
 	}
 	wave_sync();
+	unsigned long long ones[3] = { 0ull, 0ull, 0ull };             // bit k of word k >> 6: output k is > 0
 	{
-		// best of the stop states {4, 12}; traceback with differential decoding
+		// best of the stop states {4, 12}; traceback with differential decoding (viterbi_detector.cc:340-392).
+		// out[k] = +-d with the sign flipped when decision != out_bit, so out[k] > 0 <=> out_bit && d != 0.
 		const float m4 = __shfl(pm, 4, 16), m12 = __shfl(pm, 12, 16);
-		unsigned state = (m12 > m4) ? 12u : 4u;
-		state = (unsigned)uni((int)state);
-		int out_bit = 0, real_imag = (nbits & 1) ? 1 : 0;          // type of the last step processed
-		for (int k = nbits - 1; k >= 0; k--) {
-			const float tv = trans[k * 16 + state];
-			const int decision = tv > 0;
-			if (lane == 0)
-				outv[k] = (decision != out_bit) ? -tv : tv;
-			const int parity = ((state >> 1) ^ state) & 1;
-			out_bit = out_bit ^ real_imag ^ parity;
-			state = (state >> 1) + (decision ? 8u : 0u);
-			real_imag = !real_imag;
+		unsigned state = (unsigned)uni((m12 > m4) ? 12 : 4);
+		unsigned out_bit = 0u, real_imag = (nbits & 1) ? 1u : 0u;  // type of the last step processed
+		// the words are read back once, lane l holding steps l, l + 64, l + 128; the serial walk is scalar
+		const unsigned wv[3] = { tr[lane], tr[lane + 64], (lane + 128 < VA_NB) ? tr[lane + 128] : 0u };
+#pragma unroll
+		for (int blk = 2; blk >= 0; blk--) {
+			unsigned long long acc = 0ull;
+			const int hi = (nbits - 1 < blk * 64 + 63) ? nbits - 1 - blk * 64 : 63;
+			for (int kk = hi; kk >= 0; kk--) {
+				const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)wv[blk], kk);
+				const unsigned decision = (w >> state) & 1u, nonzero = (w >> (16 + state)) & 1u;
+				acc |= (unsigned long long)(out_bit & nonzero) << kk;
+				const unsigned parity = ((state >> 1) ^ state) & 1u;
+				out_bit = out_bit ^ real_imag ^ parity;
+				state = (state >> 1) + (decision << 3);
+				real_imag ^= 1u;
+			}
+			ones[blk] = acc;
 		}
 	}
-	wave_sync();
 
 	// ---- "pre flip" (:107), "* -1" (Transceiver.cpp:638), zeros behind the burst (:640-641); optional vectorSlicer
 	for (int i = lane; i < soft_stride; i += WAVE) {
 		float v = 0.0f;
-		if (i < nbits)
-			v = (outv[i] > 0) ? 127.0f : -127.0f;
+		if (i < nbits) {
+			const unsigned long long m = (i < 64) ? ones[0] : (i < 128) ? ones[1] : ones[2];
+			v = ((m >> (i & 63)) & 1ull) ? 127.0f : -127.0f;
+		}
 		if (slice & 1)
 			v = (i < 148) ? __builtin_amdgcn_fmed3f(0.5f * (v + 1.0f), 0.0f, 1.0f) : 0.0f;
 		so[i] = v;
@@ -230,7 +243,7 @@ va_demod_kernel(const c32 *__restrict__ iq, const trxhip_burst_params *__restric
 extern "C" size_t trx_va_lds_bytes(int L)
 {
 	const int xs_len = (L + 1) & ~1;
-	return VA_WPB * ((size_t)(xs_len + 64 + VA_FL + VA_NB + 32 + 8) * sizeof(c32) + (size_t)(64 + VA_NB + 4 + VA_NB * 16) * sizeof(float));
+	return VA_WPB * VA_SLICE_BYTES(xs_len);
 }
 
 extern "C" int trx_launch_va_demod(const float *d_iq, const trxhip_burst_params *d_params, float *d_soft, int32_t *d_starts,
