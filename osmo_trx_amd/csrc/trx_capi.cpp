@@ -121,7 +121,7 @@ int trxhip_create_from_tables(trxhip_ctx **out, int device, const void *h_blob, 
 		return TRXHIP_ENOMEM;
 	}
 	if (hipMemcpy(ctx->d_tables, h_blob, sizeof(trx_tables), hipMemcpyHostToDevice) != hipSuccess) {
-		hipFree(ctx->d_tables);
+		(void)hipFree(ctx->d_tables);
 		delete ctx;
 		return TRXHIP_EIO;
 	}
@@ -148,7 +148,7 @@ void trxhip_destroy(trxhip_ctx *ctx)
 	if (!ctx)
 		return;
 	if (hipSetDevice(ctx->device) == hipSuccess && ctx->d_tables)
-		hipFree(ctx->d_tables);
+		(void)hipFree(ctx->d_tables);
 	delete ctx;
 }
 
@@ -420,10 +420,10 @@ void trxhip_rx_frontend_destroy(trxhip_rx_frontend *f)
 	if (!f)
 		return;
 	if (with_device(f->ctx) == 0) {
-		if (f->d_parts) hipFree(f->d_parts);
-		if (f->d_wide_hist) hipFree(f->d_wide_hist);
-		if (f->d_chan_hist) hipFree(f->d_chan_hist);
-		if (f->d_chan) hipFree(f->d_chan);
+		if (f->d_parts) (void)hipFree(f->d_parts);
+		if (f->d_wide_hist) (void)hipFree(f->d_wide_hist);
+		if (f->d_chan_hist) (void)hipFree(f->d_chan_hist);
+		if (f->d_chan) (void)hipFree(f->d_chan);
 	}
 	delete f;
 }
@@ -451,7 +451,7 @@ int trxhip_rx_frontend_pull(trxhip_rx_frontend *f, const int16_t *d_wide, size_t
 	if (out_stride < n_total / f->q * f->p)
 		return TRXHIP_EINVAL;
 	if (n_total > f->cap) {
-		if (f->d_chan) hipFree(f->d_chan);
+		if (f->d_chan) (void)hipFree(f->d_chan);
 		f->d_chan = nullptr;
 		if (hipMalloc((void **)&f->d_chan, 4 * n_total * 8) != hipSuccess) { f->cap = 0; return TRXHIP_ENOMEM; }
 		f->cap = n_total;

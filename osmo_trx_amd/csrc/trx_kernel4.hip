@@ -18,7 +18,7 @@
 //         outputs whose decimator window straddles those edges are recomputed with the exact masked two-stage
 //         sum, so the result differs from the reference only by rounding (<= 2e-6 of full scale; bar 1e-4).
 //     Detection (rc, TOA, amp, C/I) is shared and bit-exact in both modes.
-//   * occupancy: 16 waves per CU (4 per SIMD) for the fused kernel -- per-wave LDS is cut to 7.75 KB (NARROW
+//   * occupancy: 16 waves per CU (4 per SIMD) for the fused kernel -- per-wave LDS is cut to 7.7 KB (NARROW
 //     buffers, trx_device.h) and the kernel kept under 128 VGPRs; measured, the kernel is bound by VALU + LDS
 //     issue (profiles/), so every reduction below is an instruction-count reduction.
 #include "trx_device.h"
@@ -26,9 +26,8 @@
 #define PH_A   180                 // entries per phase array (= 4 mod 16: conflict-free loader writes)
 #define PH_M0  12                  // position of m = 0 inside a phase array (48 samples of zero pad in front)
 #define K4_XS  (4 * PH_A)
-#define K4_EDGE 8
 #define K4_CZ_LEN (TRX_CZ_PAD + TRX_CORR_NARROW + TRX_CZ_PAD)
-#define K4_SLICE (K4_XS + TRX_DEC_NARROW + K4_CZ_LEN + K4_EDGE)
+#define K4_SLICE (K4_XS + TRX_DEC_NARROW + K4_CZ_LEN)
 #define K4_DROWS (TRX_DELAY_FILTS + 1)                         // + identity row (no fractional filter)
 #define K4_TABLES_FLOATS (TRX_SINCV_LDS + K4_DROWS * TRX_DELAY_HLEN + 2 * 160 + 16 + 2 * LSEQ_TAPS + 8 * LSEQ_NHDR + K4_DROWS * 36)
 #define K4_TABLES_BYTES (K4_TABLES_FLOATS * 4)
@@ -70,8 +69,8 @@ __device__ __forceinline__ PhBase ph_bases(const c32 *P, int ph0, int m0)
 	return b;
 }
 
-// waves per workgroup (one workgroup per CU).  Fused: 16 = 4 per SIMD (<= 128 VGPRs; 36 KB of tables + 16 x 7.75 KB
-// slices = 159.2 KB of the 160 KB LDS, which is why the per-wave buffers are the NARROW ones).  Measured 12 -> 16
+// waves per workgroup (one workgroup per CU).  Fused: 16 = 4 per SIMD (<= 128 VGPRs; 36 KB of tables + 16 x 7.7 KB
+// slices = 158.2 KB of the 160 KB LDS, which is why the per-wave buffers are the NARROW ones).  Measured 12 -> 16
 // waves: 378 -> 420 Mbursts/s; the kernel is latency bound per wave (profiles/).  Exact: 168 VGPRs.
 #define K4_WPB_FUSED 16
 #define K4_WPB_EXACT 12
@@ -101,7 +100,6 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 	c32 *const P = wbase;                                          // polyphase burst: P[r*PH_A + PH_M0 + m] = x[4m + r]
 	c32 *const dec = wbase + K4_XS;                                // 1-SPS (decimated) burst, zero tail
 	c32 *const cz = dec + TRX_DEC_NARROW + TRX_CZ_PAD;             // zero-padded correlation
-	c32 *const edge = dec + TRX_DEC_NARROW + K4_CZ_LEN;            // [8] exactly recomputed edge outputs (fused demod)
 
 	// ---- one-time staging (workgroup-wide) of every table; zero this wave's slice (pads stay zero)
 	for (int i = threadIdx.x; i < TRX_SINCV_LDS; i += blockDim.x)
