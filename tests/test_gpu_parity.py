@@ -334,3 +334,27 @@ def test_no_soft_output_pointer(trx):
     res2, soft2 = trx.detect_demod(d_iq, d_p, sps=4, want_soft=False)
     torch.cuda.synchronize()
     assert soft2 is None and torch.equal(res, res2)
+
+
+def test_capturable_in_a_hip_graph(trx):
+    """The batched entry point makes no synchronising call: it can be captured into a HIP graph on a side stream and
+    replayed (tools/bench_latency.py measures when that pays)."""
+    import torch
+    from osmo_trx_amd import synth
+    iq, params, _ = synth.make_normal_bursts(256, "cuda:0", 4, seed=77)
+    dp = trx.params_tensor(params)
+    res = torch.empty((256, 32), dtype=torch.uint8, device="cuda:0")
+    soft = torch.empty((256, 148), dtype=torch.float32, device="cuda:0")
+    trx.detect_demod(iq, dp, results=res, soft=soft)
+    torch.cuda.synchronize()
+    ref_res, ref_soft = res.clone(), soft.clone()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            trx.detect_demod(iq, dp, results=res, soft=soft)
+    res.zero_()
+    soft.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(res, ref_res) and torch.equal(soft, ref_soft)
