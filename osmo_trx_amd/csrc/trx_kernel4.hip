@@ -245,11 +245,24 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 		// ---- demodAnyBurst -> demodGmskBurst (:2055-2072) ----
 		if (rc > 0 && !ABL(0)) {
 			// demodCommon (:2030-2048): delayVector(burst, -toa*sps) -> scaleVector(1/amp) -> downsampleBurst
-			const float delay = -toa * 4.0f;
-			const int w = uni((int)floorf(delay));                         // integer shift: y[n] = fshift[n - w]; wave-uniform -> SALU
-			const float frac = delay - (float)w;
-			const bool use_filt = ((double)fabsf(frac) > 1e-2) && !ABL(4);  // :1056
-			const int fidx = uni(use_filt ? (int)floorf(frac * (float)TRX_DELAY_FILTS) : TRX_DELAY_FILTS);   // :1057; row 64 = identity
+			// delay = -toa * 4 samples: whole = floor(delay), frac = delay - whole, filter floorf(frac * 64) if frac > 0.01
+			// (:1049-1057).  A detected TOA is a multiple of 1/512 symbol (bisection step, table toa, integer head), so
+			// delay = -K/128 with K = toa * 512 exactly and the split is integer arithmetic on the scalar unit:
+			// whole = -K >> 7, frac = (-K & 127) / 128 > 0.01 <=> (-K & 127) >= 2, index = (-K & 127) >> 1.
+			// A caller-supplied TOA (demodulation only) can be anything: that path keeps the float sequence.
+			int w, fidx;                                                   // integer shift y[n] = fshift[n - w]; filter row (64 = identity)
+			if (ebp_in) {
+				const float delay = -toa * 4.0f;
+				w = uni((int)floorf(delay));
+				const float frac = delay - (float)w;
+				const bool use_filt = ((double)fabsf(frac) > 1e-2) && !ABL(4);
+				fidx = uni(use_filt ? (int)floorf(frac * (float)TRX_DELAY_FILTS) : TRX_DELAY_FILTS);
+			} else {
+				const int nk = -uni((int)(toa * 512.0f));
+				w = nk >> 7;
+				const int fr = nk & 127;
+				fidx = (fr >= 2 && !ABL(4)) ? (fr >> 1) : TRX_DELAY_FILTS;
+			}
 			// (complex) 1.0 / amp = (1,0) * amp.inv()   (Complex.h:75,144-150)
 			const float an = norm2(amp);
 			c32 ainv;
