@@ -24,3 +24,18 @@ for name, (iq, params) in (("normal, max_toa 3", synth.make_normal_bursts(n_nb, 
     f_res, f_soft = run_gpu(trx, iq, params, 4, exact=False)
     check_parity(f_res, f_soft, o_res, o_soft, soft_atol=FUSED_SOFT_ATOL)
     print(f"{name:22s} {len(params):8d} bursts, {int((o_res['rc'] > 0).sum()):8d} detected: bit-exact (exact) / <= {FUSED_SOFT_ATOL:g} (fused)  [{time.time() - t0:.0f} s]", flush=True)
+
+# EDGE 8-PSK (444 soft bits) and the generic kernel (1 SPS, 156/157-sample bursts)
+iq, params, _ = synth.make_edge_bursts(1 << 16, "cpu", seed=0xCA15)
+o_res, o_soft = O.pull_batch(iq.numpy(), 4, params, soft_stride=444, slice_bits=False)
+g_res, g_soft = run_gpu(trx, iq, params, 4, soft_stride=444, slice_bits=False, exact=True)
+check_parity(g_res, g_soft, o_res, o_soft)
+f_res, f_soft = run_gpu(trx, iq, params, 4, soft_stride=444, slice_bits=False, exact=False)
+check_parity(f_res, f_soft, o_res, o_soft, soft_atol=5e-5)
+print(f"{'EDGE 8-PSK':22s} {len(params):8d} bursts, {int((o_res['rc'] > 0).sum()):8d} detected: bit-exact (exact) / <= 5e-05 (fused)", flush=True)
+for bl in (156, 157):
+    iq, params, _ = synth.make_normal_bursts(1 << 16, "cpu", 1, seed=0xCA16 + bl, burst_len=bl, delay_sym=(0, 3))
+    o_res, o_soft = O.pull_batch(iq.numpy(), 1, params)
+    g_res, g_soft = run_gpu(trx, iq, params, 1)
+    check_parity(g_res, g_soft, o_res, o_soft)
+    print(f"{'1 SPS, ' + str(bl) + ' samples':22s} {len(params):8d} bursts, {int((o_res['rc'] > 0).sum()):8d} detected: bit-exact", flush=True)
