@@ -128,6 +128,24 @@ __device__ __forceinline__ float wave_sum(float v)
 	return lane_val(v, 63);
 }
 
+// wave max of `m` and wave sum of `s` in one go: the two DPP chains are interleaved, so each fills one of the two
+// wait states the other needs and a single s_nop 0 per pair replaces two s_nop 1
+__device__ __forceinline__ void wave_max_and_sum(float &m, float &s)
+{
+#define TRX_DPP_PAIR(ctrl) "s_nop 0\n\tv_max_f32_dpp %0, %0, %0 " ctrl "\n\tv_add_f32_dpp %1, %1, %1 " ctrl "\n\t"
+	asm volatile("s_nop 1\n\t"
+		     TRX_DPP_PAIR("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+		     TRX_DPP_PAIR("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+		     TRX_DPP_PAIR("row_half_mirror row_mask:0xf bank_mask:0xf")
+		     TRX_DPP_PAIR("row_mirror row_mask:0xf bank_mask:0xf")
+		     TRX_DPP_PAIR("row_bcast:15 row_mask:0xa bank_mask:0xf")
+		     TRX_DPP_PAIR("row_bcast:31 row_mask:0xc bank_mask:0xf")
+		     : "+v"(m), "+v"(s));
+#undef TRX_DPP_PAIR
+	m = lane_val(m, 63);
+	s = lane_val(s, 63);
+}
+
 // sum over each row of 16 lanes (every lane of the row gets the total)
 __device__ __forceinline__ float row_sum(float v)
 {

@@ -203,9 +203,9 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 		DIAG_MARK(15);
 
 		if (type != TRXHIP_OFF) {                                   // Transceiver.cpp:704-707
-			amax = wave_max(amax);                                  // maxAmplitude(), :1711-1722
+			wave_max_and_sum(amax, epart);                          // maxAmplitude(), :1711-1722; energyDetect partial sums
 			clip = amax > TRX_CLIP_THRESH;
-			energy = wave_sum(epart) * 0.0125f;                     // energyDetect(burst, 20*sps): / 80
+			energy = epart * 0.0125f;                               // energyDetect(burst, 20*sps): / 80
 			if (!ABL(2))
 				rssi = fs_db - 3.01029996f * __log2f(energy);       // 20*log10(fs/sqrt(e)), Transceiver.cpp:741,751
 			wave_sync();
