@@ -178,10 +178,13 @@ int trxhip_scale_vector_cf32(trxhip_ctx *ctx, float *d_x_cf32, size_t len, float
  * the access-burst branch (whose Viterbi start state is max_toa, as in the reference; >= 16 selects none); tsc 0..7.
  * d_soft[b][0..soft_stride): +-127 for the 148 (normal) / 88 (access) demodulated bits, 0 behind them; with
  * TRXHIP_FLAG_SLICE through vectorSlicer() (0 / 1).  d_starts (may be NULL): estimated burst start in samples.
- * Samples outside the burst read as 0.  soft_stride >= 148. */
+ * Samples outside the burst read as 0.  soft_stride >= 148.
+ * d_detected (may be NULL): the result records of a preceding detection launch on the same batch; burst b is then
+ * demodulated only if d_detected[b].rc > 0, with that rc as the CorrType (Transceiver.cpp:769-784); the others get
+ * zeros and start -1.  This chains detection and the Viterbi demodulator on one stream without a host round trip. */
 int trxhip_demod_va_batch_cf32(trxhip_ctx *ctx, const float *d_iq_cf32, const trxhip_burst_params *d_params,
-			       float *d_soft, int32_t *d_starts, size_t n_bursts, int burst_len, float scale,
-			       int soft_stride, int flags, void *stream);
+			       const trxhip_burst_result *d_detected, float *d_soft, int32_t *d_starts, size_t n_bursts,
+			       int burst_len, float scale, int soft_stride, int flags, void *stream);
 
 /* energyDetect() on its own (sigProcLib.h:105, sigProcLib.cpp:1573-1585): mean |x|^2 of `window` samples at
  * stride 4 from sample 0 of each burst (complex64); d_energy: n_bursts floats. */

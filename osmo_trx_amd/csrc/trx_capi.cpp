@@ -34,7 +34,8 @@ extern "C" int trx_launch_sch_detect(const float *d_iq, size_t buf_stride, trxhi
 extern "C" int trx_launch_delay_vector(const float *d_in, float *d_out, const float *d_delays, const trx_tables *d_tab,
 				       size_t n_vec, int len, hipStream_t stream);
 extern "C" int trx_launch_scale_vector(float *d_x, size_t len, float sr, float si, hipStream_t stream);
-extern "C" int trx_launch_va_demod(const float *d_iq, const trxhip_burst_params *d_params, float *d_soft, int32_t *d_starts,
+extern "C" int trx_launch_va_demod(const float *d_iq, const trxhip_burst_params *d_params,
+				   const trxhip_burst_result *d_detected, float *d_soft, int32_t *d_starts,
 				   size_t n_bursts, int L, float scale, int soft_stride, int flags, hipStream_t stream);
 extern "C" int trx_launch_vector_slicer(float *d_dst, const float *d_src, size_t len, hipStream_t stream);
 
@@ -325,9 +326,9 @@ int trxhip_scale_vector_cf32(trxhip_ctx *ctx, float *d_x, size_t len, float scal
 	return trx_launch_scale_vector(d_x, len, scale_re, scale_im, static_cast<hipStream_t>(stream));
 }
 
-int trxhip_demod_va_batch_cf32(trxhip_ctx *ctx, const float *d_iq, const trxhip_burst_params *d_params, float *d_soft,
-			       int32_t *d_starts, size_t n_bursts, int burst_len, float scale, int soft_stride, int flags,
-			       void *stream)
+int trxhip_demod_va_batch_cf32(trxhip_ctx *ctx, const float *d_iq, const trxhip_burst_params *d_params,
+			       const trxhip_burst_result *d_detected, float *d_soft, int32_t *d_starts, size_t n_bursts,
+			       int burst_len, float scale, int soft_stride, int flags, void *stream)
 {
 	if (!ctx || burst_len < 1 || burst_len > TRXHIP_MAX_BURST_LEN || soft_stride < 148)
 		return TRXHIP_EINVAL;
@@ -337,7 +338,7 @@ int trxhip_demod_va_batch_cf32(trxhip_ctx *ctx, const float *d_iq, const trxhip_
 		return TRXHIP_EINVAL;
 	if (with_device(ctx))
 		return TRXHIP_EIO;
-	return trx_launch_va_demod(d_iq, d_params, d_soft, d_starts, n_bursts, burst_len, scale, soft_stride, flags,
+	return trx_launch_va_demod(d_iq, d_params, d_detected, d_soft, d_starts, n_bursts, burst_len, scale, soft_stride, flags,
 				   static_cast<hipStream_t>(stream));
 }
 

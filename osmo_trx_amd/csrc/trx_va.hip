@@ -34,7 +34,8 @@ __constant__ char va_acc_str[42] = "01001011011111111001100110101010001111000";
 __device__ __forceinline__ c32 va_cmul(c32 a, c32 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 
 __global__ void __launch_bounds__(VA_WPB * WAVE)
-va_demod_kernel(const c32 *__restrict__ iq, const trxhip_burst_params *__restrict__ params, float *__restrict__ soft,
+va_demod_kernel(const c32 *__restrict__ iq, const trxhip_burst_params *__restrict__ params,
+		const trxhip_burst_result *__restrict__ detected, float *__restrict__ soft,
 		int32_t *__restrict__ starts, unsigned n_bursts, int L, float scale, int soft_stride, int slice)
 {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -57,9 +58,16 @@ va_demod_kernel(const c32 *__restrict__ iq, const trxhip_burst_params *__restric
 	if (b >= n_bursts)
 		return;
 	const unsigned prm = reinterpret_cast<const uint32_t *>(params)[2 * (size_t)b];
-	const int type = prm & 0xff, tsc = (prm >> 8) & 0xff, max_toa = prm >> 16;
+	int type = prm & 0xff;
+	const int tsc = (prm >> 8) & 0xff, max_toa = prm >> 16;
 	float *so = soft + (size_t)b * soft_stride;
-	if (tsc > 7) {                                                 // train_seq has 8 entries (+ dummy): reject
+	bool skip = false;
+	if (detected) {                                                // chained behind detection: rc is the CorrType (Transceiver.cpp:784)
+		const int rc = uni(detected[b].rc);
+		skip = rc <= 0;
+		type = rc;
+	}
+	if (tsc > 7 || skip) {                                                 // train_seq has 8 entries (+ dummy): reject
 		for (int i = lane; i < soft_stride; i += WAVE) so[i] = 0.0f;
 		if (starts && lane == 0) starts[b] = -1;
 		return;
@@ -246,7 +254,8 @@ extern "C" size_t trx_va_lds_bytes(int L)
 	return VA_WPB * VA_SLICE_BYTES(xs_len);
 }
 
-extern "C" int trx_launch_va_demod(const float *d_iq, const trxhip_burst_params *d_params, float *d_soft, int32_t *d_starts,
+extern "C" int trx_launch_va_demod(const float *d_iq, const trxhip_burst_params *d_params,
+				   const trxhip_burst_result *d_detected, float *d_soft, int32_t *d_starts,
 				   size_t n_bursts, int L, float scale, int soft_stride, int flags, hipStream_t stream)
 {
 	if (n_bursts == 0)
@@ -258,6 +267,7 @@ extern "C" int trx_launch_va_demod(const float *d_iq, const trxhip_burst_params 
 		return TRXHIP_EIO;
 	const size_t grid = (n_bursts + VA_WPB - 1) / VA_WPB;
 	hipLaunchKernelGGL(va_demod_kernel, dim3((unsigned)grid), dim3(VA_WPB * WAVE), lds, stream,
-			   reinterpret_cast<const c32 *>(d_iq), d_params, d_soft, d_starts, (unsigned)n_bursts, L, scale, soft_stride, flags);
+			   reinterpret_cast<const c32 *>(d_iq), d_params, d_detected, d_soft, d_starts, (unsigned)n_bursts, L, scale, soft_stride,
+			   flags);
 	return hipGetLastError() == hipSuccess ? 0 : TRXHIP_EIO;
 }

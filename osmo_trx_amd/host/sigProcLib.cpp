@@ -12,6 +12,7 @@
 #include <mutex>
 
 #include "sigProcLib.h"
+#include <cmath>
 #include "trxhip.h"
 
 namespace {
@@ -229,7 +230,7 @@ SoftVector *demodAnyBurst_va(const signalVector &burst, CorrType type, int sps, 
 	prm.max_toa = (uint16_t)(rach_max_toa < 0 ? 0 : rach_max_toa > 65535 ? 65535 : rach_max_toa);
 	SoftVector *bits = new SoftVector(148 + 8);
 	if (!h2d(t.d_iq, burst.begin(), burst.bytes(), t.stream) || !h2d(t.d_prm, &prm, sizeof(prm), t.stream) ||
-	    trxhip_demod_va_batch_cf32(g_ctx, static_cast<const float *>(t.d_iq), t.d_prm, t.d_soft, NULL, 1, (int)burst.size(),
+	    trxhip_demod_va_batch_cf32(g_ctx, static_cast<const float *>(t.d_iq), t.d_prm, NULL, t.d_soft, NULL, 1, (int)burst.size(),
 				       1.0f, 156, 0, t.stream) != TRXHIP_OK ||
 	    !d2h(bits->begin(), t.d_soft, 156 * sizeof(float), t.stream) || hipStreamSynchronize(t.stream) != hipSuccess) {
 		delete bits;
@@ -343,6 +344,74 @@ int pullRadioVectorBatch(const BurstRequest *req, size_t n, int sps, size_t burs
 			bi.ci = res[i].ci;
 			bi.nbits = 4u * res[i].nbits_div4;
 			memcpy(bi.rx_burst, &soft[i * stride], (bi.nbits < stride ? bi.nbits : stride) * sizeof(float));
+		}
+	}
+	return 0;
+}
+
+int pullRadioVectorBatchVA(const BurstRequest *req, size_t n, int sps, size_t burst_len, double rxFullScale,
+			   double rssi_offset, BurstIndication *out)
+{
+	const size_t stride = NORMAL_BURST_NBITS;
+	Scratch &t = tls;
+	if (!n)
+		return 0;
+	if (!g_ctx || !req || !out || burst_len <= 40)
+		return -EIO;
+	const size_t burst_bytes = burst_len * 2 * sizeof(int16_t);
+	/* scratch: [int16 bursts][int16 shifted copy][complex64 bursts]; the energies ride in d_ebp */
+	if (!t.ensure(n, 2 * n * burst_bytes + n * burst_len * 2 * sizeof(float), stride))
+		return -EIO;
+	int16_t *d_iq = static_cast<int16_t *>(t.d_iq), *d_shift = d_iq + n * burst_len * 2;
+	float *d_cf = reinterpret_cast<float *>(d_shift + n * burst_len * 2);
+
+	std::vector<int16_t> iq(n * burst_len * 2);
+	std::vector<trxhip_burst_params> prm(n);
+	for (size_t i = 0; i < n; i++) {
+		memcpy(&iq[i * burst_len * 2], req[i].iq, burst_bytes);
+		memset(&prm[i], 0, sizeof(prm[i]));
+		prm[i].type = (uint8_t)req[i].type;
+		prm[i].tsc = (uint8_t)req[i].tsc;
+		prm[i].max_toa = (uint16_t)req[i].max_toa;
+	}
+	std::vector<trxhip_burst_result> res(n);
+	std::vector<float> soft(n * stride), energy(n);
+	const size_t shift_bytes = (burst_len - 40) * 2 * sizeof(int16_t);
+	if (!h2d(d_iq, iq.data(), n * burst_bytes, t.stream) || !h2d(t.d_prm, prm.data(), n * sizeof(prm[0]), t.stream) ||
+	    /* shift_vec: samples 20 .. len-20 in front, zeros behind (Transceiver.cpp:679, :762) */
+	    hipMemsetAsync(d_shift, 0, n * burst_bytes, t.stream) != hipSuccess ||
+	    hipMemcpy2DAsync(d_shift, burst_bytes, d_iq + 40, burst_bytes, shift_bytes, n, hipMemcpyDeviceToDevice, t.stream) != hipSuccess)
+		return -EIO;
+	int rc = trxhip_detect_demod_batch(g_ctx, d_shift, t.d_prm, t.d_res, NULL, n, (int)burst_len, sps, BURST_THRESH,
+					   (float)rxFullScale, (int)stride, 0, t.stream);
+	if (rc == TRXHIP_OK)
+		rc = trxhip_convert_short_float(g_ctx, d_cf, d_iq, n * burst_len * 2, t.stream);
+	if (rc == TRXHIP_OK)                                       /* power of the unshifted burst (Transceiver.cpp:724-746) */
+		rc = trxhip_energy_detect_batch_cf32(g_ctx, d_cf, n, (int)burst_len, 20 * sps, t.d_ebp, t.stream);
+	if (rc == TRXHIP_OK)
+		rc = trxhip_demod_va_batch_cf32(g_ctx, d_cf, t.d_prm, t.d_res, t.d_soft, NULL, n, (int)burst_len,
+						(float)(1. / (float)((1 << 14) - 1)), (int)stride, TRXHIP_FLAG_SLICE, t.stream);
+	if (rc != TRXHIP_OK || !d2h(res.data(), t.d_res, n * sizeof(res[0]), t.stream) ||
+	    !d2h(soft.data(), t.d_soft, soft.size() * sizeof(float), t.stream) ||
+	    !d2h(energy.data(), t.d_ebp, n * sizeof(float), t.stream) || hipStreamSynchronize(t.stream) != hipSuccess)
+		return -EIO;
+
+	for (size_t i = 0; i < n; i++) {
+		BurstIndication &bi = out[i];
+		memset(&bi, 0, sizeof(bi));
+		bi.rc = res[i].rc;
+		bi.idle = res[i].idle != 0;
+		bi.energy = energy[i];
+		if (req[i].type == OFF)
+			bi.energy = 0.0f;                              /* no power level for a slot that is off (Transceiver.cpp:704-707) */
+		else                                               /* avg = sqrt(pow / chans); 20 log10(fullscale / avg) (:741, :751) */
+			bi.rssi = 20.0 * log10(rxFullScale / (double)sqrtf(energy[i])) + rssi_offset;
+		if (!bi.idle) {
+			bi.toa = res[i].toa;
+			bi.tsc = res[i].tsc;
+			bi.ci = res[i].ci;
+			bi.nbits = NORMAL_BURST_NBITS;                 /* rxBurst->size() = 156, not 444 (Transceiver.cpp:794-800) */
+			memcpy(bi.rx_burst, &soft[i * stride], NORMAL_BURST_NBITS * sizeof(float));
 		}
 	}
 	return 0;

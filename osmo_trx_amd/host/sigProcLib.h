@@ -96,4 +96,9 @@ struct BurstIndication {          /* the DSP-derived fields of struct trx_ul_bur
  *  Returns 0, or a negative errno-style code (-EIO on a GPU error). */
 int pullRadioVectorBatch(const BurstRequest *req, size_t n, int sps, size_t burst_len, double rxFullScale,
 			 double rssi_offset, BurstIndication *out, bool egprs = false);
+/** The same with cfg->use_va (Transceiver.cpp:760-768, :782-784): req[i].iq is the burst read 20 samples early
+ *  (osmo-trx.cpp:87-100); power / RSSI come from it, detection runs on the copy shifted by 20 samples, the soft bits
+ *  from scaleVector(1/16383) + demodAnyBurst_va() on the unshifted burst.  Three launches on one stream. */
+int pullRadioVectorBatchVA(const BurstRequest *req, size_t n, int sps, size_t burst_len, double rxFullScale,
+			   double rssi_offset, BurstIndication *out);
 #endif

@@ -3,6 +3,7 @@
 // sequence).  Reads inputs prepared by tests/test_gpu_host_shim.py, writes results as plain text/binary.
 //   sigproc_selftest capture <cfile> <out.txt>
 //   sigproc_selftest delay <cfile> <delay> <scale_re> <scale_im> <out.cf32>
+//   sigproc_selftest batchva <iq.s16> <params.bin> <n> <rec.bin> <soft.bin>
 //   sigproc_selftest va <cfile> <tsc> <out.f32>
 //   sigproc_selftest sch <cfile> <0 full | 1 narrow | 2 buffer> <out.txt>
 //   sigproc_selftest batch <iq.s16> <params.bin> <n> <sps> <burst_len> <out_results.bin> <out_soft.bin>
@@ -149,6 +150,31 @@ int main(int argc, char **argv)
 		return 0;
 	}
 	// multi <wide.s16> <n_blocks> <chans> <out_prefix>: RadioInterfaceMulti Rx in chunks of 1, 2, 3, ... blocks
+	if (!strcmp(argv[1], "batchva") && argc == 7) {
+		/* pullRadioVectorBatchVA: iq.s16 params.bin n out_rec.bin out_soft.bin; records {rc, toa, ci, rssi, idle, tsc, energy} */
+		std::vector<char> iq = slurp(argv[2]), pr = slurp(argv[3]);
+		size_t n = atol(argv[4]);
+		std::vector<BurstRequest> req(n);
+		for (size_t i = 0; i < n; i++) {
+			const unsigned char *p = reinterpret_cast<const unsigned char *>(pr.data()) + 8 * i;
+			req[i].iq = reinterpret_cast<const int16_t *>(iq.data()) + i * 625 * 2;
+			req[i].type = (CorrType)p[0];
+			req[i].tsc = p[1];
+			req[i].max_toa = p[2] | (p[3] << 8);
+		}
+		std::vector<BurstIndication> ind(n);
+		if (pullRadioVectorBatchVA(req.data(), n, 4, 625, 32767.0, 0.0, ind.data()) != 0) return 4;
+		FILE *fr = fopen(argv[5], "wb"), *fs = fopen(argv[6], "wb");
+		for (size_t i = 0; i < n; i++) {
+			float rec[7] = { (float)ind[i].rc, (float)ind[i].toa, ind[i].ci, (float)ind[i].rssi, (float)ind[i].idle, (float)ind[i].tsc, ind[i].energy };
+			fwrite(rec, sizeof(rec), 1, fr);
+			fwrite(ind[i].rx_burst, sizeof(float), 148, fs);
+		}
+		fclose(fr); fclose(fs);
+		sigProcLibDestroy();
+		return 0;
+	}
+
 	if (!strcmp(argv[1], "multi") && argc == 6) {
 		std::vector<char> raw = slurp(argv[2]);
 		size_t n_blocks = atol(argv[3]), chans = atol(argv[4]);

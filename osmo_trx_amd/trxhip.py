@@ -57,7 +57,7 @@ SYMBOLS = {
     "trxhip_energy_detect_batch_cf32": (_I, [_VP, _VP, _SZ, _I, C.c_uint, _VP, _VP]),
     "trxhip_delay_vector_batch_cf32": (_I, [_VP, _VP, _VP, _VP, _SZ, _I, _VP]),
     "trxhip_scale_vector_cf32": (_I, [_VP, _VP, _SZ, C.c_float, C.c_float, _VP]),
-    "trxhip_demod_va_batch_cf32": (_I, [_VP, _VP, _VP, _VP, _VP, _SZ, _I, C.c_float, _I, _I, _VP]),
+    "trxhip_demod_va_batch_cf32": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _SZ, _I, C.c_float, _I, _I, _VP]),
     "trxhip_detect_sch_batch_cf32": (_I, [_VP, _VP, _VP, _SZ, _SZ, _I, _I, C.c_float, _VP]),
     "trxhip_vector_slicer": (_I, [_VP, _VP, _VP, _SZ, _VP]),
     "trxhip_pack_trxd_batch": (_I, [_VP, _VP, _VP, _I, _VP, _SZ, _F, _VP]),
@@ -230,14 +230,16 @@ class TrxHip:
                                                self._stream(stream)), "trxhip_scale_vector_cf32")
         return x_cf32
 
-    def demod_va(self, iq_cf32, params, scale=1.0 / 16383.0, soft_stride=156, slice_bits=False, stream=None):
+    def demod_va(self, iq_cf32, params, scale=1.0 / 16383.0, soft_stride=156, slice_bits=False, detected=None, stream=None):
         """Viterbi alternative (cfg->use_va): scaleVector + demodAnyBurst_va.  iq complex64[n, L], params uint8[n, 8].
+        detected: uint8[n, 32] result records of a detection launch (only bursts with rc > 0 are demodulated).
         Returns (soft float32[n, soft_stride], starts int32[n])."""
         torch = self.torch
         n, burst_len = iq_cf32.shape
         soft = torch.empty((n, soft_stride), dtype=torch.float32, device=iq_cf32.device)
         starts = torch.empty(n, dtype=torch.int32, device=iq_cf32.device)
-        _check(self.L.trxhip_demod_va_batch_cf32(self.h, self._dev(iq_cf32), self._dev(params), self._dev(soft),
+        _check(self.L.trxhip_demod_va_batch_cf32(self.h, self._dev(iq_cf32), self._dev(params),
+                                                 self._dev(detected) if detected is not None else _VP(0), self._dev(soft),
                                                  self._dev(starts), n, burst_len, scale, soft_stride,
                                                  FLAG_SLICE if slice_bits else 0, self._stream(stream)),
                "trxhip_demod_va_batch_cf32")

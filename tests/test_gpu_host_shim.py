@@ -164,3 +164,48 @@ def test_va_through_shim(exe, tmp_path):
         _, ref = O.demod_any_burst_va(y, O.TSC, tsc, 3)
         assert len(got) == 156 and np.array_equal(got, ref)
         assert int(((got[:148] > 0).astype(np.uint8) != bits).sum()) <= 2
+
+
+def test_pull_radio_vector_batch_va(exe, tmp_path):
+    """pullRadioVectorBatchVA(): cfg->use_va flow of pullRadioVector (Transceiver.cpp:724-803) -- power from the burst
+    as read (20 samples early), detection on the shifted copy, soft bits from the Viterbi receiver -- against the same
+    composition of oracle calls."""
+    from osmo_trx_amd import synth
+    n = 192
+    # place the bursts where both views work: VA start 0..20 samples <-> detector TOA -0.4 .. 4.6 symbols
+    iq, params, _ = synth.make_normal_bursts(n, "cpu", 4, seed=91, max_toa=5, delay_sym=(-4.4, 0.2), p_clip=0.0)
+    params = synth.make_idle_off_mix(params)
+    (tmp_path / "iq.s16").write_bytes(iq.numpy().tobytes())
+    (tmp_path / "p.bin").write_bytes(params.tobytes())
+    subprocess.check_call([exe, "batchva", str(tmp_path / "iq.s16"), str(tmp_path / "p.bin"), str(n),
+                           str(tmp_path / "r.bin"), str(tmp_path / "s.bin")])
+    rec = np.fromfile(tmp_path / "r.bin", dtype=np.float32).reshape(n, 7)
+    soft = np.fromfile(tmp_path / "s.bin", dtype=np.float32).reshape(n, 148)
+    x = iq.numpy().astype(np.float32).view(np.complex64).reshape(n, 625)
+    ndet = 0
+    for i in range(n):
+        t, tsc, mt = int(params["type"][i]), int(params["tsc"][i]), int(params["max_toa"][i])
+        if t == O.OFF:
+            assert rec[i, 0] == 0 and rec[i, 4] == 1 and rec[i, 3] == 0
+            continue
+        xi = np.ascontiguousarray(x[i])
+        e = O.lib().orc_energy_detect(xi.ctypes.data, 625, 80)
+        assert abs(rec[i, 6] - e) <= 3e-6 * e
+        assert abs(rec[i, 3] - 20.0 * np.log10(32767.0 / np.sqrt(np.float32(e)))) <= 1e-4
+        if t == O.IDLE:
+            assert rec[i, 4] == 1
+            continue
+        sh = np.zeros(625, dtype=np.complex64)
+        sh[:585] = xi[20:605]
+        rc, ebp = O.detect_any_burst(sh, tsc, 4.0, 4, t, mt)
+        assert int(rec[i, 0]) == rc
+        if rc <= 0:
+            assert rec[i, 4] == 1
+            continue
+        ndet += 1
+        assert rec[i, 1] == np.float32(ebp.toa) and abs(rec[i, 2] - ebp.ci) <= 2e-5 and int(rec[i, 5]) == tsc
+        _, va = O.demod_any_burst_va(xi, rc, tsc, mt)
+        sl = np.zeros(148, dtype=np.float32)
+        O.lib().orc_vector_slicer(sl.ctypes.data, va.ctypes.data, 148)
+        assert np.array_equal(soft[i], sl), i
+    assert ndet > 80                                                  # (IDLE / OFF slots, noise-only bursts excluded)
