@@ -9,8 +9,9 @@
 //   * the sliding 20-sample energy window and its first maximum: the reference's serial float recurrence, kept
 //     serial (59 steps on wave-uniform LDS reads) -- it decides the burst position
 //   * matched filter: one output symbol per lane and round, 20 complex taps in order
-//   * add-compare-select: lane = state (16 lanes), predecessors s>>1 and (s>>1)+8 fetched with a 16-wide shuffle,
-//     the 32 hand-written ACS statements of the reference reduced to their sign/increment pattern; of every
+//   * add-compare-select as a butterfly on 16 lanes: the lane holding old state S produces new state rotl4(S) from
+//     its own metric and that of the lane holding S ^ 8, fetched with one DPP move (the state-to-lane map rotates
+//     with period 4); the 32 hand-written ACS statements of the reference reduced to their sign/increment pattern; of every
 //     path-metric difference only (d > 0, d != 0) matter for the +-127 output, so a step's table row is one ballot
 //     word; the traceback is the reference's serial walk on the scalar unit
 // Operand order follows the reference statement by statement (-ffp-contract=off): the +-127 outputs are bit-exact.
@@ -24,12 +25,15 @@
 #define VA_NB 148
 #define VA_AB 88
 
-// 3GPP TS 45.002 training sequence bits (constants.h:91-95, :131-141 in the reference's grgsm_vitac/)
-__constant__ char va_tsc_str[8][27] = {
-	"00100101110000100010010111", "00101101110111100010110111", "01000011101110100100001110", "01000111101101000100011110",
-	"00011010111001000001101011", "01001110101100000100111010", "10100111110110001010011111", "11101111000100101110111100",
-};
-__constant__ char va_acc_str[42] = "01001011011111111001100110101010001111000";
+// The training sequences after gmsk_mapper() and conj() (grgsm_vitac.cpp:57-79, :122-145) are walks over
+// {1, j, -1, -j}: out[i] = (+-j) * out[i-1] from the start point 1 / -1 (normal burst, first bit 0 / 1) or -j (access),
+// then conjugated.  Stored as 2-bit quarter-turn codes (0: 1, 1: j, 2: -1, 3: -j) of the elements the channel
+// estimate uses, i = 5 .. 20 of the 26 TSC bits and i = 5 .. 35 of the 41 access bits (TRAIN_BEGINNING = 5), element
+// k at bits 2k, 2k+1 -- computed from the 3GPP TS 45.002 bit strings by the same walk (tests compare with the oracle,
+// which maps the bits at run time).
+__constant__ unsigned int va_tsc_codes[8] = { 0x131319b9u, 0x9311b9b9u, 0x1913b3b3u, 0x191933b1u,
+					      0xbb191193u, 0x991b3391u, 0x139bb9b1u, 0x91933b31u };
+#define VA_ACC_CODES 0x464e4ccccc6c644ull
 
 __device__ __forceinline__ c32 va_cmul(c32 a, c32 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 
@@ -42,7 +46,7 @@ va_demod_kernel(const c32 *__restrict__ iq, const trxhip_burst_params *__restric
 	const int lane = threadIdx.x & (WAVE - 1);
 	const int wave = uni((int)(threadIdx.x >> 6));
 	const int xs_len = (L + 1) & ~1;
-	// per-wave slice: xs[L] | corr[64] | cir[20] | filt[148] | seq[32] | rhh[8] : c32;  power[64] : float | tr[192] : u32
+	// per-wave slice: xs[L] | corr[64] | cir[20] | filt[148] | seq[32] | rhh[8] : c32;  power[64] : float (+ 192 spare words)
 	const size_t slice_bytes = VA_SLICE_BYTES(xs_len);
 	char *base = smem + (size_t)wave * slice_bytes;
 	c32 *xs = reinterpret_cast<c32 *>(base);
@@ -52,7 +56,6 @@ va_demod_kernel(const c32 *__restrict__ iq, const trxhip_burst_params *__restric
 	c32 *seq = filt + VA_NB;
 	c32 *rhh = seq + 32;
 	float *power = reinterpret_cast<float *>(rhh + 8);
-	unsigned *tr = reinterpret_cast<unsigned *>(power + 64);   // decision words, one per step (entries >= 148 unused)
 
 	const unsigned b = blockIdx.x * VA_WPB + wave;
 	if (b >= n_bursts)
@@ -80,22 +83,12 @@ va_demod_kernel(const c32 *__restrict__ iq, const trxhip_burst_params *__restric
 	for (int i = lane; i < L; i += WAVE)
 		xs[i] = va_cmul(src[i], make_float2(scale, 0.0f));
 
-	// ---- training sequence, gmsk_mapper() + conj (grgsm_vitac.cpp:57-79, :122-145): a walk over {1, j, -1, -j}
+	// ---- training sequence: element `lane` from its quarter-turn code
 	const int tlen = nb ? 26 : 41, tseqlen = tlen - 10;
-	if (lane == 0) {
-		const char *bits = nb ? va_tsc_str[tsc] : va_acc_str;
-		int q = nb ? ((bits[0] == '0') ? 0 : 2) : 3;               // start point 1 / -1 (normal), -j (access)
-		int prev = 2 * (bits[0] - '0') - 1;
-		for (int i = 0; i < tlen; i++) {
-			if (i > 0) {
-				const int cur = 2 * (bits[i] - '0') - 1;
-				q = (q + ((cur * prev > 0) ? 1 : 3)) & 3;          // times j or -j
-				prev = cur;
-			}
-			const int qc = (4 - q) & 3;                            // conjugate
-			if (i >= 5 && i < 5 + 32)
-				seq[i - 5] = make_float2(qc == 0 ? 1.0f : qc == 2 ? -1.0f : 0.0f, qc == 1 ? 1.0f : qc == 3 ? -1.0f : 0.0f);
-		}
+	if (lane < 32) {
+		const unsigned long long codes = nb ? (unsigned long long)va_tsc_codes[tsc] : VA_ACC_CODES;
+		const int qc = (int)((codes >> (2 * lane)) & 3ull);
+		seq[lane] = make_float2(qc == 0 ? 1.0f : qc == 2 ? -1.0f : 0.0f, qc == 1 ? 1.0f : qc == 3 ? -1.0f : 0.0f);
 	}
 	wave_sync();
 
@@ -119,17 +112,23 @@ va_demod_kernel(const c32 *__restrict__ iq, const trxhip_burst_params *__restric
 		power[lane] = (float)((double)h * (double)h);              // std::pow(float, int)
 	}
 	wave_sync();
-	int best = 0;
+	// sliding 20-sample window energy (:199-214): ws = p[0] + ... + p[19], then ws += p[i] - p[i-20].  With q[i] = p[i]
+	// (i < 20) or p[i] - p[i-20], the window sums are the left-to-right prefix sums of q: a serial DPP scan along the
+	// lanes reproduces the reference's additions one for one (lane 19 + j ends with window j's energy).
+	int best;
 	{
-		float ws = 0.0f;
-		for (int i = 0; i < VA_FL; i++)
-			ws += power[i];
-		float beste = ws;
-		for (int i = VA_FL; i < nw; i++) {
-			ws += power[i] - power[i - VA_FL];
-			if (beste < ws) { beste = ws; best = i - (VA_FL - 1); }  // std::max_element: first largest
-		}
-		best = uni(best);
+		const float pw = (lane < nw) ? power[lane] : 0.0f;
+		const float pp = (lane >= VA_FL && lane < nw) ? power[lane - VA_FL] : 0.0f;
+		const float q = (lane < VA_FL) ? pw : pw - pp;
+		float acc = q;
+#pragma unroll
+		for (int i = 1; i < 59; i++)                               // nw = 59 for both burst types
+			asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(q));
+		const bool inwin = (lane >= VA_FL - 1) && (lane < nw);
+		const float e = inwin ? acc : -3.0e38f;
+		const float m = wave_max(e);
+		const unsigned long long hit = __ballot(inwin && e == m);  // std::max_element: the first largest
+		best = hit ? (int)__ffsll((unsigned long long)hit) - 1 - (VA_FL - 1) : 0;
 	}
 	if (lane < VA_FL)
 		cir[lane] = corr[best + lane];
@@ -164,8 +163,11 @@ va_demod_kernel(const c32 *__restrict__ iq, const trxhip_burst_params *__restric
 	}
 	wave_sync();
 
-	// ---- viterbi_detector (viterbi_detector.cc:62-392): lane & 15 = state
-	const int s = lane & 15, p = s >> 1, odd = s & 1;
+	// ---- viterbi_detector (viterbi_detector.cc:62-392), add-compare-select as a DPP butterfly.
+	// New state n comes from old states p = n >> 1 and p + 8, i.e. the pair (S, S ^ 8) feeds the pair rotl4(S),
+	// rotl4(S ^ 8).  So a lane holding old state S computes new state rotl4(S) from its own metric and the metric
+	// of the lane holding S ^ 8: lane l holds state rotl4^k(l) at step k (identity again every 4 steps) and its
+	// partner is lane l ^ (8 >> (k & 3)) -- one or two DPP moves instead of two ds_bpermute round trips per step.
 	float inc[8];
 #pragma unroll
 	for (int m = 0; m < 8; m++) {
@@ -174,55 +176,92 @@ va_demod_kernel(const c32 *__restrict__ iq, const trxhip_burst_params *__restric
 		v = (m & 4) ? v + rhh[3].y : v - rhh[3].y;
 		inc[m] = v + rhh[4].x;
 	}
-	float ia = 0.0f, ib = 0.0f, ra = 0.0f, rb = 0.0f;              // this state's reference levels
+	// per layout r = k & 3: the state this lane holds, and for the state n = rotl4(S) it produces (p = S & 7,
+	// odd = S >> 3) the signed reference levels and the sign of the input symbol:
+	//   imaginary step (r even): even n: o1 + sym - inc[p^2], o2 + sym + inc[p^5];  odd n: o1 - sym + inc[p^2], o2 - sym - inc[p^5]
+	//   real step      (r odd):  even n: o1 - sym - inc[7-p], o2 - sym + inc[p];    odd n: o1 + sym + inc[7-p], o2 + sym - inc[p]
+	float a1[4], a2[4];
+	unsigned sflip[4];                                             // sign-bit mask applied to the symbol
+	bool oddr[4];
 #pragma unroll
-	for (int m = 0; m < 8; m++) {
-		ia = (m == (p ^ 2)) ? inc[m] : ia;                         // imaginary steps: inc[{2,3,0,1,6,7,4,5}[p]]
-		ib = (m == (p ^ 5)) ? inc[m] : ib;                         //                  inc[{5,4,7,6,1,0,3,2}[p]]
-		ra = (m == 7 - p) ? inc[m] : ra;                           // real steps:      inc[7 - p], inc[p]
-		rb = (m == p) ? inc[m] : rb;
+	for (int r = 0; r < 4; r++) {
+		const int l4 = lane & 15;
+		const int S = ((l4 << r) | (l4 >> (4 - r))) & 15;          // rotl4^r(lane)
+		const int p = S & 7;
+		const bool odd = (S >> 3) != 0;
+		float l1 = 0.0f, l2 = 0.0f;
+#pragma unroll
+		for (int m = 0; m < 8; m++) {
+			l1 = (m == ((r & 1) ? 7 - p : (p ^ 2))) ? inc[m] : l1;
+			l2 = (m == ((r & 1) ? p : (p ^ 5))) ? inc[m] : l2;
+		}
+		a1[r] = odd ? l1 : -l1;
+		a2[r] = odd ? -l2 : l2;
+		const bool plus = (r & 1) ? odd : !odd;
+		sflip[r] = plus ? 0u : 0x80000000u;
+		oddr[r] = odd;
 	}
 	const unsigned start_state = nb ? 3u : (unsigned)max_toa;      // Transceiver.cpp:633: rach_max_toa as start state
 	float pm = (-10e30);
-	if ((unsigned)s == start_state)
+	if ((unsigned)(lane & 15) == start_state)
 		pm = 0.0f;
 	// Only two bits of every path-metric difference survive into the +-127 output: d > 0 (the decision) and d != 0
-	// (an output of +-0 is "not > 0").  Per step the 16 states' bits are one ballot word: tr[k] = nz << 16 | pos.
-	for (int k = 0; k < nbits; k++) {
-		const bool imag = !(k & 1);
-		const c32 f = filt[k];
-		const float sym = imag ? f.y : f.x;
-		const float o1 = __shfl(pm, p, 16), o2 = __shfl(pm, p + 8, 16);
-		// even state, imaginary step: o1 + sym - ia, o2 + sym + ib; odd: o1 - sym + ia, o2 - sym - ib
-		// even state, real step:      o1 - sym - ra, o2 - sym + rb; odd: o1 + sym + ra, o2 + sym - rb
-		const bool plus = imag ? !odd : odd;
-		const float ss = plus ? sym : -sym;
-		const float l1 = imag ? ia : ra, l2 = imag ? ib : rb;
-		const float c1 = (o1 + ss) + (odd ? l1 : -l1);
-		const float c2 = (o2 + ss) + (odd ? -l2 : l2);
-		const float d = c2 - c1;
-		pm = (d < 0) ? c1 : c2;
-		const unsigned pos = (unsigned)__ballot(d > 0) & 0xffffu, nz = (unsigned)__ballot(d != 0) & 0xffffu;
-		if (lane == 0)
-			tr[k] = (nz << 16) | pos;
+	// (an output of +-0 is "not > 0").  Per step the 16 lanes' bits are one ballot word, nz << 16 | pos,
+	// bit l = the new state rotl4^(k+1)(l).
+	// the matched-filter outputs are read once (lane l holds symbols l, l + 64, l + 128) and fetched per step with
+	// v_readlane; the decision words are collected in three registers (lane = step): no LDS traffic inside the trellis
+	c32 fr[3];
+	fr[0] = filt[lane];
+	fr[1] = (lane + 64 < nbits) ? filt[lane + 64] : make_float2(0.0f, 0.0f);
+	fr[2] = (lane + 128 < nbits) ? filt[lane + 128] : make_float2(0.0f, 0.0f);
+	unsigned wv[3] = { 0u, 0u, 0u };
+#pragma unroll
+	for (int blk = 0; blk < 3; blk++) {
+		const int kend = (nbits - blk * 64 < 64) ? nbits - blk * 64 : 64;
+		for (int k0 = 0; k0 < kend; k0 += 4) {                     // 148, 88 and 64 are multiples of 4
+#pragma unroll
+			for (int r = 0; r < 4; r++) {
+				const int kk = k0 + r;                             // step blk * 64 + kk
+				const float sym = __int_as_float(__builtin_amdgcn_readlane(__float_as_int((r & 1) ? fr[blk].x : fr[blk].y), kk));
+				const int pmi = __float_as_int(pm);
+				int other;
+				if (r == 0)      other = __builtin_amdgcn_update_dpp(pmi, pmi, 0x128, 0xf, 0xf, false);   // row_ror:8   (l ^ 8)
+				else if (r == 1) {                                                                           // l ^ 4
+					other = __builtin_amdgcn_update_dpp(pmi, pmi, 0x104, 0xf, 0x5, false);                   // row_shl:4 into banks 0, 2
+					other = __builtin_amdgcn_update_dpp(other, pmi, 0x114, 0xf, 0xa, false);                 // row_shr:4 into banks 1, 3
+				}
+				else if (r == 2) other = __builtin_amdgcn_update_dpp(pmi, pmi, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1] (l ^ 2)
+				else             other = __builtin_amdgcn_update_dpp(pmi, pmi, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2] (l ^ 1)
+				const float po = __int_as_float(other);
+				const float o1 = oddr[r] ? po : pm, o2 = oddr[r] ? pm : po;
+				const float ss = __int_as_float(__float_as_int(sym) ^ (int)sflip[r]);
+				const float c1 = (o1 + ss) + a1[r];
+				const float c2 = (o2 + ss) + a2[r];
+				const float d = c2 - c1;
+				pm = (d < 0) ? c1 : c2;
+				const unsigned word = (((unsigned)__ballot(d != 0) & 0xffffu) << 16) | ((unsigned)__ballot(d > 0) & 0xffffu);
+				wv[blk] = (lane == kk) ? word : wv[blk];           // (v_writelane cannot take two SGPRs on gfx9)
+			}
+		}
 	}
-	wave_sync();
 	unsigned long long ones[3] = { 0ull, 0ull, 0ull };             // bit k of word k >> 6: output k is > 0
 	{
 		// best of the stop states {4, 12}; traceback with differential decoding (viterbi_detector.cc:340-392).
 		// out[k] = +-d with the sign flipped when decision != out_bit, so out[k] > 0 <=> out_bit && d != 0.
-		const float m4 = __shfl(pm, 4, 16), m12 = __shfl(pm, 12, 16);
-		unsigned state = (unsigned)uni((m12 > m4) ? 12 : 4);
+		const float m4 = lane_val(pm, 4), m12 = lane_val(pm, 12);      // after a multiple of 4 steps lane l holds state l again
+		unsigned state = (m12 > m4) ? 12u : 4u;
 		unsigned out_bit = 0u, real_imag = (nbits & 1) ? 1u : 0u;  // type of the last step processed
-		// the words are read back once, lane l holding steps l, l + 64, l + 128; the serial walk is scalar
-		const unsigned wv[3] = { tr[lane], tr[lane + 64], (lane + 128 < VA_NB) ? tr[lane + 128] : 0u };
+		// lane l of wv[blk] holds the word of step blk * 64 + l; the serial walk is scalar
 #pragma unroll
 		for (int blk = 2; blk >= 0; blk--) {
 			unsigned long long acc = 0ull;
 			const int hi = (nbits - 1 < blk * 64 + 63) ? nbits - 1 - blk * 64 : 63;
 			for (int kk = hi; kk >= 0; kk--) {
 				const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)wv[blk], kk);
-				const unsigned decision = (w >> state) & 1u, nonzero = (w >> (16 + state)) & 1u;
+				// the bit of new state n at step k sits at lane rotr4^(k+1)(n); k = blk * 64 + kk and 64 = 0 mod 4
+				const unsigned rr = (unsigned)(kk + 1) & 3u;
+				const unsigned bit = ((state >> rr) | (state << (4u - rr))) & 15u;
+				const unsigned decision = (w >> bit) & 1u, nonzero = (w >> (16 + bit)) & 1u;
 				acc |= (unsigned long long)(out_bit & nonzero) << kk;
 				const unsigned parity = ((state >> 1) ^ state) & 1u;
 				out_bit = out_bit ^ real_imag ^ parity;
