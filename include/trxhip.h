@@ -69,6 +69,10 @@ enum trxhip_signal_error {
 
 /* Per-burst input: what pullRadioVector() knows before calling detectAnyBurst()
  * (expectedCorrType() Transceiver.cpp:513-601, mTSC, mMaxExpectedDelayAB/NB :757-758). 8 bytes. */
+#define TRXHIP_FLAG_IDLE_DUMMY   4  /* search IDLE slots for the dummy burst, as detectAnyBurst(IDLE) does (detectDummyBurst,
+                                     * sigProcLib.cpp:1863-1877, :1945-1947; rc = IDLE on a hit) instead of skipping them as
+                                     * pullRadioVector does (Transceiver.cpp:754-755) */
+
 typedef struct trxhip_burst_params {
 	uint8_t  type;      /* enum trxhip_corr_type expected for the slot */
 	uint8_t  tsc;       /* training sequence code 0..7 */

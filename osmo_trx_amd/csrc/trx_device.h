@@ -27,8 +27,9 @@
 #define LSEQ_TSC(s)   ((s) * 16)
 #define LSEQ_RACH(i)  (128 + (i) * 40)
 #define LSEQ_EDGE(s)  (248 + (s) * 16)
-#define LSEQ_TAPS     376
-#define LSEQ_NHDR     19
+#define LSEQ_DUMMY    376                 /* gDummySequence, 16 taps */
+#define LSEQ_TAPS     392
+#define LSEQ_NHDR     20
 #define TRX_TABLES_LDS_FLOATS (TRX_SINCV_LDS + TRX_DELAY_FILTS * TRX_DELAY_HLEN + 2 * 160 + 16 + 2 * LSEQ_TAPS + 8 * LSEQ_NHDR)
 #define TRX_TABLES_LDS_BYTES (TRX_TABLES_LDS_FLOATS * 4)
 
@@ -582,6 +583,8 @@ __device__ __forceinline__ int detect_any_burst(int type, int tsc, int max_toa, 
 		ncand = (type == TRXHIP_EDGE) ? 2 : 1;
 	} else if (type == TRXHIP_RACH || type == TRXHIP_EXT_RACH) {
 		ncand = (type == TRXHIP_EXT_RACH) ? 3 : 1;           // :1791
+	} else if (type == TRXHIP_IDLE && (slice & TRXHIP_FLAG_IDLE_DUMMY)) {
+		ncand = 1;                                           // detectDummyBurst (:1863-1877, :1945-1947)
 	}                                                        // other types: "Invalid correlation type", rc = 0 (:1949-1950)
 	if (ncand > 0 && max_toa > TRXHIP_MAX_TOA)
 		return -TRXHIP_SIGERR_UNSUPPORTED;                   // this implementation's window limit (trxhip.h)
@@ -594,10 +597,12 @@ __device__ __forceinline__ int detect_any_burst(int type, int tsc, int max_toa, 
 			slot = 8 + c; target = 48; head = 8; tail = 8 + max_toa; N = 40;       // :1788-1790
 		} else if (type == TRXHIP_EDGE && c == 0) {
 			slot = 11 + tsc; target = 82; head = 6; tail = 6 + max_toa; N = 16;    // :1915-1918
+		} else if (type == TRXHIP_IDLE) {
+			slot = 19; target = 82; head = 10; tail = 6 + max_toa; N = 16;         // :1869-1872
 		} else {
 			slot = tsc; target = 82; head = 10; tail = 6 + max_toa; N = 16;        // :1896-1899
 		}
-		const c32 *taps = lseq + ((slot < 8) ? LSEQ_TSC(slot) : (slot < 11) ? LSEQ_RACH(slot - 8) : LSEQ_EDGE(slot - 11));
+		const c32 *taps = lseq + ((slot < 8) ? LSEQ_TSC(slot) : (slot < 11) ? LSEQ_RACH(slot - 8) : (slot < 19) ? LSEQ_EDGE(slot - 11) : LSEQ_DUMMY);
 		const float *hdr = lhdr + 8 * slot;
 		const int start = target - head - 1;                 // :1752
 		const int len = head + tail;                         // :1753
@@ -617,6 +622,7 @@ __device__ __forceinline__ int detect_any_burst(int type, int tsc, int max_toa, 
 			out->amp = a;
 			out->ci = cc;
 			if (slot >= 8 && slot < 11) { out->tsc = slot - 8; return type; }    // :1797
+			if (slot == 19) { out->tsc = 0; return TRXHIP_IDLE; }                 // :1874, :1953-1954
 			out->tsc = tsc;
 			return (slot >= 11) ? TRXHIP_EDGE : TRXHIP_TSC;  // :1953-1954
 		}

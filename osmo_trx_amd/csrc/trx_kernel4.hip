@@ -94,7 +94,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 	c32 *rrot = reinterpret_cast<c32 *>(dfilt + K4_DROWS * TRX_DELAY_HLEN);   // [160] reverse rotation
 	float *gdec = reinterpret_cast<float *>(rrot + 160);           // [16] decimator taps
 	c32 *lseq = reinterpret_cast<c32 *>(gdec + 16);                // [376] training sequences
-	float *lhdr = reinterpret_cast<float *>(lseq + LSEQ_TAPS);     // [19][8] sequence headers
+	float *lhdr = reinterpret_cast<float *>(lseq + LSEQ_TAPS);     // [20][8] sequence headers
 	float *comp = lhdr + 8 * LSEQ_NHDR;                            // [65][36] composite delay-o-decimate filters
 	c32 *wbase = reinterpret_cast<c32 *>(smem + K4_TABLES_BYTES) + (size_t)wave * K4_SLICE;
 	c32 *const P = wbase;                                          // polyphase burst: P[r*PH_A + PH_M0 + m] = x[4m + r]
@@ -117,12 +117,13 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 		int s, k;
 		if (i < 128)      { s = TRX_SEQ_TSC0 + i / 16;          k = i % 16; }
 		else if (i < 248) { s = TRX_SEQ_RACH0 + (i - 128) / 40; k = (i - 128) % 40; }
-		else              { s = TRX_SEQ_EDGE0 + (i - 248) / 16; k = (i - 248) % 16; }
+		else if (i < 376) { s = TRX_SEQ_EDGE0 + (i - 248) / 16; k = (i - 248) % 16; }
+		else              { s = TRX_SEQ_DUMMY;                  k = i - 376; }
 		lseq[i] = make_float2(tab->seq[s].taps[k].re, tab->seq[s].taps[k].im);
 	}
 	for (int i = threadIdx.x; i < 8 * LSEQ_NHDR; i += blockDim.x) {
 		const int slot = i / 8;
-		const int s = (slot < 8) ? TRX_SEQ_TSC0 + slot : (slot < 11) ? TRX_SEQ_RACH0 + (slot - 8) : TRX_SEQ_EDGE0 + (slot - 11);
+		const int s = (slot < 8) ? TRX_SEQ_TSC0 + slot : (slot < 11) ? TRX_SEQ_RACH0 + (slot - 8) : (slot < 19) ? TRX_SEQ_EDGE0 + (slot - 11) : TRX_SEQ_DUMMY;
 		lhdr[i] = reinterpret_cast<const float *>(&tab->seq[s].gain)[i % 8];
 	}
 	for (int i = lane; i < K4_SLICE; i += WAVE)
@@ -217,7 +218,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 				toa = unif(e.x);
 				amp = make_float2(unif(e.y), unif(e.z));
 				out_tsc = tsc;
-			} else if (type != TRXHIP_IDLE && !ABL(3)) {            // Transceiver.cpp:754-755
+			} else if ((type != TRXHIP_IDLE || (slice & TRXHIP_FLAG_IDLE_DUMMY)) && !ABL(3)) {   // Transceiver.cpp:754-755
 				// ---- detectAnyBurst (:1926-1957); decimation on the polyphase layout:
 				// dec[i] = sum_k x[4i-15+k] * g[k];  x[4(i-4) + k'] with k' = k+1 -> phase k'&3, m = i-4 + k'>>2
 				auto decimate = [&](int lo, int hi) {

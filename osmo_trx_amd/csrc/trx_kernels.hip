@@ -52,7 +52,7 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 	c32 *rrot = reinterpret_cast<c32 *>(dfilt + TRX_DELAY_FILTS * TRX_DELAY_HLEN);   // [160] reverse rotation
 	float *gdec = reinterpret_cast<float *>(rrot + 160);           // [16] decimator taps
 	c32 *lseq = reinterpret_cast<c32 *>(gdec + 16);                // [376] training sequences
-	float *lhdr = reinterpret_cast<float *>(lseq + LSEQ_TAPS);     // [19][8] sequence headers
+	float *lhdr = reinterpret_cast<float *>(lseq + LSEQ_TAPS);     // [20][8] sequence headers
 	const int xs_len = TRX_PAD + L + TRX_PAD;
 	const int xs_alloc = (xs_len + 1) & ~1;
 	const int slice_c32 = xs_alloc + TRX_DEC_LEN + TRX_CZ_LEN;
@@ -74,13 +74,14 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 		int s, k;
 		if (i < 128)      { s = TRX_SEQ_TSC0 + i / 16;          k = i % 16; }
 		else if (i < 248) { s = TRX_SEQ_RACH0 + (i - 128) / 40; k = (i - 128) % 40; }
-		else              { s = TRX_SEQ_EDGE0 + (i - 248) / 16; k = (i - 248) % 16; }
+		else if (i < 376) { s = TRX_SEQ_EDGE0 + (i - 248) / 16; k = (i - 248) % 16; }
+		else              { s = TRX_SEQ_DUMMY;                  k = i - 376; }
 		lseq[i] = make_float2(tab->seq[s].taps[k].re, tab->seq[s].taps[k].im);
 	}
 	for (int i = threadIdx.x; i < 8 * LSEQ_NHDR; i += blockDim.x) {
-		// header of LDS sequence slot: slots 0-7 TSC, 8-10 RACH, 11-18 EDGE
+		// header of LDS sequence slot: slots 0-7 TSC, 8-10 RACH, 11-18 EDGE, 19 dummy
 		const int slot = i / 8;
-		const int s = (slot < 8) ? TRX_SEQ_TSC0 + slot : (slot < 11) ? TRX_SEQ_RACH0 + (slot - 8) : TRX_SEQ_EDGE0 + (slot - 11);
+		const int s = (slot < 8) ? TRX_SEQ_TSC0 + slot : (slot < 11) ? TRX_SEQ_RACH0 + (slot - 8) : (slot < 19) ? TRX_SEQ_EDGE0 + (slot - 11) : TRX_SEQ_DUMMY;
 		lhdr[i] = reinterpret_cast<const float *>(&tab->seq[s].gain)[i % 8];
 	}
 	for (int i = lane; i < slice_c32; i += WAVE)
@@ -188,7 +189,7 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 				toa = unif(e.x);
 				amp = make_float2(unif(e.y), unif(e.z));
 				out_tsc = tsc;
-			} else if (type != TRXHIP_IDLE && !ABL(3)) {            // Transceiver.cpp:754-755
+			} else if ((type != TRXHIP_IDLE || (slice & TRXHIP_FLAG_IDLE_DUMMY)) && !ABL(3)) {   // Transceiver.cpp:754-755
 				// ---- detectAnyBurst (:1926-1957)
 				DetectOut d;
 				if (SPS == 4) {

@@ -161,7 +161,8 @@ int detectAnyBurst(const signalVector &burst, unsigned tsc, float threshold, int
 		return -SIGERR_INTERNAL;
 	int rc = trxhip_detect_demod_batch_cf32(g_ctx, static_cast<const float *>(t.d_iq), t.d_prm, t.d_res, t.d_soft, 1,
 						(int)n, sps, threshold, 1.0f, (int)stride,
-						TRXHIP_FLAG_EXACT_DEMOD /* raw soft bits, reference operand order */, t.stream);
+						TRXHIP_FLAG_EXACT_DEMOD /* raw soft bits, reference operand order */ |
+						TRXHIP_FLAG_IDLE_DUMMY /* detectAnyBurst(IDLE) = detectDummyBurst, :1945-1947 */, t.stream);
 	if (rc != TRXHIP_OK || !d2h(&res, t.d_res, sizeof(res), t.stream) ||
 	    !d2h(t.last_soft.data(), t.d_soft, stride * sizeof(float), t.stream) ||
 	    hipStreamSynchronize(t.stream) != hipSuccess)

@@ -24,6 +24,7 @@ assert PARAMS_DTYPE.itemsize == 8 and RESULT_DTYPE.itemsize == 32
 TRXD_RECORD_BYTES = 156
 FLAG_SLICE = 1          # TRXHIP_FLAG_SLICE
 FLAG_EXACT_DEMOD = 2    # TRXHIP_FLAG_EXACT_DEMOD
+FLAG_IDLE_DUMMY = 4     # TRXHIP_FLAG_IDLE_DUMMY
 SCH_DETECT_FULL, SCH_DETECT_NARROW, SCH_DETECT_BUFFER = 0, 1, 2   # sch_detect_type (sigProcLib.h:139-143)
 
 
@@ -171,7 +172,7 @@ class TrxHip:
 
     # ---- hot path ------------------------------------------------------------------------------
     def detect_demod(self, iq, params, sps=4, threshold=4.0, full_scale=32767.0, soft_stride=148, slice_bits=True,
-                     results=None, soft=None, stream=None, want_soft=True, exact=False, _diag_mask=0):
+                     results=None, soft=None, stream=None, want_soft=True, exact=False, idle_dummy=False, _diag_mask=0):
         """iq: int16[n, burst_len, 2] or complex64[n, burst_len] (device).  params: uint8[n, 8] (device).
         Returns (results uint8[n, 32], soft float32[n, soft_stride]) device tensors."""
         torch = self.torch
@@ -195,7 +196,8 @@ class TrxHip:
             raise TrxHipError(f"unsupported IQ dtype {iq.dtype}")
         rc = fn(self.h, ip, self._dev(params), self._dev(results), sp, n, burst_len, sps,
                 threshold, full_scale, soft_stride,
-                (FLAG_SLICE if slice_bits else 0) | (FLAG_EXACT_DEMOD if exact else 0) | (int(_diag_mask) << 8),
+                (FLAG_SLICE if slice_bits else 0) | (FLAG_EXACT_DEMOD if exact else 0) |
+                (FLAG_IDLE_DUMMY if idle_dummy else 0) | (int(_diag_mask) << 8),
                 self._stream(stream))
         _check(rc, "trxhip_detect_demod_batch")
         return results, soft

@@ -358,3 +358,52 @@ def test_capturable_in_a_hip_graph(trx):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(res, ref_res) and torch.equal(soft, ref_soft)
+
+
+def test_dummy_burst_detection_on_idle_slots(trx):
+    """detectAnyBurst(IDLE) -> detectDummyBurst (sigProcLib.cpp:1863-1877, :1945-1947): with TRXHIP_FLAG_IDLE_DUMMY the
+    IDLE slots are correlated with gDummySequence (rc = IDLE on a hit) instead of being skipped the way
+    pullRadioVector skips them.  Bursts carrying the dummy midamble, a normal TSC, or noise; vs the oracle per burst."""
+    import torch
+    from osmo_trx_amd import synth
+    n = 512
+    iq, params, _ = synth.make_normal_bursts(n, "cpu", 4, seed=55, max_toa=5)
+    # re-modulate a third of the bursts with the dummy midamble 0111000101110001011100010 1 (GSM 05.02 5.2.6)
+    dummy = np.array([int(c) for c in "01110001011100010111000101"], dtype=np.uint8)
+    rng = np.random.default_rng(56)
+    x = iq.numpy().copy()
+    for b in range(0, n, 3):
+        bits = rng.integers(0, 2, 148, dtype=np.uint8)
+        bits[:3] = 0; bits[-3:] = 0; bits[61:87] = dummy
+        m = O.modulate_burst(bits, 8, 4)
+        y = np.zeros(625, dtype=np.complex64)
+        off = int(rng.integers(0, 8))
+        y[off:off + min(len(m), 625 - off)] = m[:625 - off] * np.complex64(6000 * np.exp(1j * rng.uniform(0, 6.28)))
+        y += ((rng.normal(size=625) + 1j * rng.normal(size=625)) * 200).astype(np.complex64)
+        x[b, :, 0] = np.clip(np.rint(y.real), -32768, 32767)
+        x[b, :, 1] = np.clip(np.rint(y.imag), -32768, 32767)
+    iq = torch.from_numpy(x)
+    params["type"] = O.IDLE
+    # the dummy midamble repeats every 8 bits: its correlation peak-to-neighbourhood ratio stays below BURST_THRESH = 4
+    # on clean bursts (the reference would not find them either), so the comparison runs at a threshold of 1.5
+    thr = 1.5
+    res, soft = trx.detect_demod(iq.to("cuda:0"), trx.params_tensor(params), sps=4, threshold=thr, soft_stride=156,
+                                 slice_bits=False, exact=True, idle_dummy=True)
+    g = trx.results_to_numpy(res)
+    gs = soft.cpu().numpy()
+    nhit = 0
+    for b in range(n):
+        xb = x[b].astype(np.float32).view(np.complex64).reshape(625)
+        rc, ebp = O.detect_any_burst(xb, int(params["tsc"][b]), thr, 4, O.IDLE, int(params["max_toa"][b]))
+        assert g["rc"][b] == rc, (b, g["rc"][b], rc)
+        if rc > 0:
+            nhit += 1
+            assert rc == O.IDLE and g["toa"][b] == np.float32(ebp.toa) and g["tsc"][b] == 0 and g["idle"][b] == 0
+            assert g["amp_re"][b] == np.float32(ebp.amp[0]) and g["amp_im"][b] == np.float32(ebp.amp[1])
+            assert np.array_equal(gs[b], O.demod_any_burst(xb, rc, 4, ebp)[:156])
+        else:
+            assert g["idle"][b] == 1 and not gs[b].any()
+    assert nhit >= n // 3 - 8
+    # without the flag IDLE slots are skipped (Transceiver.cpp:754-755)
+    res2, _ = trx.detect_demod(iq.to("cuda:0"), trx.params_tensor(params), sps=4)
+    assert (trx.results_to_numpy(res2)["rc"] == 0).all()
