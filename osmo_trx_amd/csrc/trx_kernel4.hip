@@ -21,6 +21,7 @@
 //   * occupancy: 16 waves per CU (4 per SIMD) for the fused kernel -- per-wave LDS is cut to 7.7 KB (NARROW
 //     buffers, trx_device.h) and the kernel kept under 128 VGPRs; measured, the kernel is bound by VALU + LDS
 //     issue (profiles/), so every reduction below is an instruction-count reduction.
+#include <atomic>
 #include "trx_device.h"
 
 #define PH_A   180                 // entries per phase array (= 4 mod 16: conflict-free loader writes)
@@ -549,8 +550,17 @@ extern "C" int trx_launch_pull4(const void *d_iq, int cf32, const trxhip_burst_p
 #define LAUNCH4(CF_, EX_)                                                                                       \
 	do {                                                                                                    \
 		auto k = burst_pull4_kernel<CF_, EX_>;                                                          \
-		if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
-			return TRXHIP_EIO;                                                                      \
+		/* the > 64 KB dynamic-LDS opt-in is per kernel and device: once, not per launch (small batches) */ \
+		static std::atomic<unsigned long long> armed{0ull};                                             \
+		int dev = 0;                                                                                    \
+		if (hipGetDevice(&dev) != hipSuccess) return TRXHIP_EIO;                                        \
+		const unsigned long long bit = 1ull << (dev & 63);                                              \
+		if (!(armed.load(std::memory_order_acquire) & bit)) {                                           \
+			if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize,        \
+						(int)(K4_TABLES_BYTES + (size_t)(EX_ ? K4_WPB_EXACT : K4_WPB_FUSED) * K4_SLICE * sizeof(c32))) != hipSuccess) \
+				return TRXHIP_EIO;                                                                  \
+			armed.fetch_or(bit, std::memory_order_release);                                             \
+		}                                                                                               \
 		hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(wpb * WAVE), lds, stream, d_iq, d_params, d_results, \
 				   d_soft, d_tab, reinterpret_cast<const float4 *>(d_ebp_in), (unsigned)n_bursts, L, thresh, \
 				   full_scale, soft_stride, flags);                                             \
