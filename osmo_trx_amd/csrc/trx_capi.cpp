@@ -176,7 +176,7 @@ static int pull_common(trxhip_ctx *ctx, const void *d_iq, int cf32, const trxhip
 		return TRXHIP_EINVAL;
 	if (n_bursts == 0)
 		return TRXHIP_OK;                                      /* empty batch: nothing to do */
-	if (!d_iq || !d_params || !d_results || n_bursts > 0xffffffffull)
+	if (!d_iq || !d_params || !d_results || n_bursts > 0x7fffffffull)   /* 32-bit burst index + grid stride in the kernels */
 		return TRXHIP_EINVAL;
 	if ((reinterpret_cast<uintptr_t>(d_iq) & 3) != 0)
 		return TRXHIP_EINVAL;
@@ -294,7 +294,7 @@ int trxhip_detect_sch_batch_cf32(trxhip_ctx *ctx, const float *d_iq, trxhip_burs
 		return TRXHIP_EINVAL;
 	if (n_bufs == 0)
 		return TRXHIP_OK;
-	if (!d_iq || !d_results)
+	if (!d_iq || !d_results || n_bufs > 0x7fffffffull)
 		return TRXHIP_EINVAL;
 	if (with_device(ctx))
 		return TRXHIP_EIO;
@@ -334,7 +334,7 @@ int trxhip_demod_va_batch_cf32(trxhip_ctx *ctx, const float *d_iq, const trxhip_
 		return TRXHIP_EINVAL;
 	if (n_bursts == 0)
 		return TRXHIP_OK;
-	if (!d_iq || !d_params || !d_soft)
+	if (!d_iq || !d_params || !d_soft || n_bursts > 0x7fffffffull)
 		return TRXHIP_EINVAL;
 	if (with_device(ctx))
 		return TRXHIP_EIO;
