@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TRXHIP_ABI_VERSION 1
+#define TRXHIP_ABI_VERSION 2
 
 /* error codes */
 #define TRXHIP_OK          0
@@ -197,11 +197,94 @@ int trxhip_energy_detect_batch_cf32(trxhip_ctx *ctx, const float *d_iq_cf32, siz
 /* vectorSlicer() (sigProcLib.h:63): dest = clamp(0.5*(src+1), 0, 1), device arrays */
 int trxhip_vector_slicer(trxhip_ctx *ctx, float *d_dest, const float *d_src, size_t len, void *stream);
 
-/* TRXD v0/v1 payload packing on device, proto_trxd.c:36-66:
+/* TRXD field quantisation into a fixed 156-byte record (a compact device-side format, NOT the wire format -- see
+ * trxhip_pack_trxd_wire_batch below), proto_trxd.c:36-66:
  *   d_pkt: n_bursts * 156 bytes: [0..1] toa_int be16 (1/256 sym), [2] rssi u8 (-dBFS), [3..4] ci cB be16,
  *          [5] tsc, [6] idle, [7] nbits/4, [8..155] 148 soft bits uint8 = round(rx_burst*255) */
 int trxhip_pack_trxd_batch(trxhip_ctx *ctx, const trxhip_burst_result *d_results, const float *d_soft_sliced,
 			   int soft_stride, uint8_t *d_pkt, size_t n_bursts, float rssi_offset, void *stream);
+
+/* TRXD v0 / v1 uplink burst indications in wire format: byte for byte what trxd_send_burst_ind_v0() / _v1()
+ * hand to write() (proto_trxd.c:68-117; struct trxd_hdr_common / _v0_specific / _v1_specific, proto_trxd.h:56-106):
+ *   [0]     version << 4 | tn & 7             trxd_fill_common()        proto_trxd.c:28-34
+ *   [1..4]  fn, big endian
+ *   [5]     rssi = (uint8_t) bi->rssi         trxd_fill_v0_specific()   :36-45   (rssi = result.rssi + rssi_offset)
+ *   [6..7]  (int)(toa * 256.0 + 0.5), be16
+ *   v0:  [8..8+nbits) soft bits, then two trailing bytes (the reference leaves the first uninitialised and zeroes the
+ *        second, :83-87; both are 0 here); idle indications are not sent (length 0, :71-73)
+ *   v1:  [8] idle << 7 | modulation << 3 | tsc & 7    trxd_fill_v1_specific() :47-60; modulation = GMSK: tss & 3,
+ *        8-PSK: 4 | tss & 1 (TRXD_MODULATION_*, proto_trxd.h:84-88); [9..10] (int16)(ci * 10 + 0.5) be16;
+ *        [11..11+nbits) soft bits unless idle (:100-109)
+ *   soft bits: (uint8_t) round(rx_burst[i] * 255.0), nbits = 148 (GMSK) or 444 (8-PSK)     :62-66
+ * An idle indication carries toa = ci = tsc = 0 and GMSK, as pullRadioVector() leaves them (Transceiver.cpp:694-704,
+ * ret_idle :808-814).  A slot that is OFF produces nothing (pullRadioVector() returns -ENOENT, :704-707): length 0.
+ * rssi outside 0..255 (or NaN) is undefined behaviour in the reference's double -> uint8_t conversion; here it
+ * saturates.
+ *   d_results, d_params : the records of the detect/demod launch over the same batch (d_params gives OFF)
+ *   d_soft_sliced       : its soft output with TRXHIP_FLAG_SLICE, soft_stride >= 148 (>= 444 for 8-PSK rows)
+ *   d_meta              : per burst {fn, tn, version 0|1, tss}
+ *   d_pkt               : n_bursts x pkt_stride bytes, pkt_stride a multiple of 4 and >= 160 (>= 456 when 8-PSK rows
+ *                         are possible; a datagram that does not fit is truncated to pkt_stride); burst b's datagram
+ *                         starts at d_pkt + b * pkt_stride, bytes behind its length are 0
+ *   d_pkt_len           : n_bursts datagram lengths (0 = nothing to send) */
+typedef struct trxhip_trxd_meta {
+	uint32_t fn;        /* TDMA frame number */
+	uint8_t  tn;        /* timeslot 0..7 */
+	uint8_t  version;   /* TRXD header version negotiated for the channel: 0 or 1 (mVersionTRXD[chan]) */
+	uint8_t  tss;       /* training sequence set (the reference always sends 0, Transceiver.cpp:703) */
+	uint8_t  reserved;
+} trxhip_trxd_meta;
+#define TRXHIP_TRXD_V0_HDR   8
+#define TRXHIP_TRXD_V1_HDR  11
+#define TRXHIP_TRXD_MAX_PKT (TRXHIP_TRXD_V1_HDR + 444)
+int trxhip_pack_trxd_wire_batch(trxhip_ctx *ctx, const trxhip_burst_result *d_results, const trxhip_burst_params *d_params,
+				const float *d_soft_sliced, int soft_stride, const trxhip_trxd_meta *d_meta,
+				uint8_t *d_pkt, int pkt_stride, uint16_t *d_pkt_len, size_t n_bursts, float rssi_offset,
+				void *stream);
+
+/* ---- host-fed, stream-pipelined form of the hot path (host buffers in, host buffers out) ----
+ * pullRadioVector()'s callers hold their bursts in host memory.  A hostpipe owns `depth` staging slots of pinned
+ * host memory, each with its own device buffers and HIP stream; a submitted slot runs
+ *     H2D (iq, params, meta) -> trxhip_detect_demod_batch [-> trxhip_pack_trxd_wire_batch] -> D2H (results, soft | pkt)
+ * asynchronously, so that slot k+1's upload, slot k's kernels and slot k-1's download overlap.  Nothing is
+ * allocated after create.  The producer writes bursts straight into trxhip_hostpipe_slot_buffers().iq (no second
+ * copy); trxhip_hostpipe_run() is the convenience form for pageable caller buffers (it copies through the slots). */
+typedef struct trxhip_hostpipe trxhip_hostpipe;
+typedef struct trxhip_hostpipe_cfg {
+	uint32_t max_bursts;   /* capacity of one slot */
+	int32_t  depth;        /* number of slots, 2..16 */
+	int32_t  burst_len;    /* 625 at 4 SPS */
+	int32_t  sps;
+	int32_t  soft_stride;  /* floats per burst downloaded (148 / 156 / 444); 0 = no float soft output */
+	int32_t  pkt_stride;   /* bytes per burst of TRXD datagrams downloaded (multiple of 4, >= 160); 0 = no TRXD packing */
+	int32_t  flags;        /* TRXHIP_FLAG_*; TRXD packing implies TRXHIP_FLAG_SLICE */
+	float    threshold;    /* TRXHIP_BURST_THRESH */
+	float    full_scale;
+	float    rssi_offset;  /* enters the TRXD rssi byte only; result.rssi stays without it */
+} trxhip_hostpipe_cfg;
+typedef struct trxhip_hostpipe_slot {      /* pinned host memory, valid until trxhip_hostpipe_destroy() */
+	int16_t             *iq;       /* in : max_bursts x burst_len x 2 */
+	trxhip_burst_params *params;   /* in : max_bursts */
+	trxhip_trxd_meta    *meta;     /* in : max_bursts (NULL without TRXD packing) */
+	trxhip_burst_result *results;  /* out: max_bursts */
+	float               *soft;     /* out: max_bursts x soft_stride (NULL when soft_stride = 0) */
+	uint8_t             *pkt;      /* out: max_bursts x pkt_stride  (NULL when pkt_stride = 0) */
+	uint16_t            *pkt_len;  /* out: max_bursts */
+} trxhip_hostpipe_slot;
+int  trxhip_hostpipe_create(trxhip_ctx *ctx, const trxhip_hostpipe_cfg *cfg, trxhip_hostpipe **out);
+void trxhip_hostpipe_destroy(trxhip_hostpipe *p);
+int  trxhip_hostpipe_slot_buffers(trxhip_hostpipe *p, int slot, trxhip_hostpipe_slot *out);
+/* enqueue slot's first n_bursts bursts; returns at once.  The slot's buffers must not be touched until wait(). */
+int  trxhip_hostpipe_submit(trxhip_hostpipe *p, int slot, size_t n_bursts);
+/* block until the slot's job has finished (TRXHIP_OK), or return TRXHIP_EIO if it failed */
+int  trxhip_hostpipe_wait(trxhip_hostpipe *p, int slot);
+/* 0 = finished (or never submitted), 1 = still running, < 0 error */
+int  trxhip_hostpipe_query(trxhip_hostpipe *p, int slot);
+/* Pageable buffers: n bursts are cut into slot-sized chunks, staged, processed with all slots in flight and copied
+ * out.  h_meta / h_soft / h_pkt / h_pkt_len may be NULL (must be NULL when the pipe was created without them). */
+int  trxhip_hostpipe_run(trxhip_hostpipe *p, const int16_t *h_iq, const trxhip_burst_params *h_params,
+			 const trxhip_trxd_meta *h_meta, trxhip_burst_result *h_results, float *h_soft, uint8_t *h_pkt,
+			 uint16_t *h_pkt_len, size_t n_bursts);
 
 /* ---- arch kernels, batched (arch/common/convolve.h:6-14, convert.h:9) ----
  * y[b][i] = sum_k x[b][i + start - (h_len-1) + k] * h[k]  (correlation form, no tap flip), b < n_vec.
@@ -213,6 +296,13 @@ int trxhip_convolve_real_batch(trxhip_ctx *ctx, const float *d_x, int x_len, con
 int trxhip_convolve_complex_batch(trxhip_ctx *ctx, const float *d_x, int x_len, const float *d_h, int h_len,
 				  float *d_y, int y_len, int start, int len, size_t n_vec, void *stream);
 int trxhip_convert_short_float(trxhip_ctx *ctx, float *d_out, const int16_t *d_in, size_t len, void *stream);
+/* convert_float_short() in its generic-C form (convert.h:6, convert_base.c:20-25): out[i] = (short)(in[i] * scale) */
+int trxhip_convert_float_short(trxhip_ctx *ctx, int16_t *d_out, const float *d_in, float scale, size_t len, void *stream);
+/* cxvec_fft() (fft.h:6-11, fft.c:55-114): `howmany` M-point DFTs, transform t reading d_in[j*istride + t] and writing
+ * d_out[k*ostride + t] (complex64 units), forward (reverse = 0) or backward, unnormalised -- the layout of the
+ * reference's fftwf_plan_many_dft() call.  d_out must not alias d_in. */
+int trxhip_dft_batch(trxhip_ctx *ctx, const float *d_in, float *d_out, int m, size_t howmany, size_t istride, size_t ostride,
+		     int reverse, void *stream);
 
 /* ---- Channelizer::rotate (M-path polyphase analysis bank + M-point DFT), batched over blocks ----
  * d_in : n_blocks * block_len * m wideband samples as int16 IQ (a continuous stream; block j's

@@ -1184,6 +1184,50 @@ void orc_trxd_soft_u8(uint8_t *dst, const float *rx_burst, unsigned nbits)
 		dst[i] = (uint8_t)round(rx_burst[i] * 255.0);
 }
 
+/* proto_trxd.c:68-117, trxd_send_burst_ind_v0() / _v1(): the datagram handed to write(), built field by field
+ * as trxd_fill_common() :28-34, trxd_fill_v0_specific() :36-45, trxd_fill_v1_specific() :47-60 and
+ * trxd_fill_burst_normalized255() :62-66 do, with the packed little-endian bit-field layouts of proto_trxd.h:56-106
+ * written out (tn:3 | reserved:1 | version:4;  tsc:3 | modulation:4 | idle:1).
+ * Returns the datagram length; 0 when nothing is sent (v0 and idle, :71-73); -1 for an unknown version.
+ * Two places where the reference's bytes are not defined and this restatement picks a value:
+ *   - v0 trailing byte soft_bits[nbits] is uninitialised stack in the reference (:83-87): written as 0 here;
+ *   - `v0->rssi = bi->rssi` converts double to uint8_t, undefined outside 0..255: saturated here. */
+int orc_trxd_pack(uint8_t *buf, unsigned version, uint32_t fn, uint8_t tn, double rssi, double toa, int idle,
+		  int modulation_8psk, uint8_t tss, uint8_t tsc, float ci, const float *rx_burst, unsigned nbits)
+{
+	if (version > 1)
+		return -1;
+	if (version == 0 && idle)
+		return 0;
+	unsigned pos = 0;
+	buf[pos++] = (uint8_t)(((version & 0xf) << 4) | (tn & 0x7));
+	buf[pos++] = (uint8_t)(fn >> 24);                      /* osmo_store32be */
+	buf[pos++] = (uint8_t)(fn >> 16);
+	buf[pos++] = (uint8_t)(fn >> 8);
+	buf[pos++] = (uint8_t)fn;
+	buf[pos++] = rssi >= 255.0 ? 255 : (rssi > 0.0 ? (uint8_t)rssi : 0);
+	int toa_int = orc_trxd_toa256(toa);
+	buf[pos++] = (uint8_t)((unsigned)toa_int >> 8);        /* osmo_store16be */
+	buf[pos++] = (uint8_t)toa_int;
+	if (version == 1) {
+		int16_t ci_cb = orc_trxd_ci_cb(ci);
+		unsigned mod = modulation_8psk ? (0x4u | (tss & 0x1u)) : (0x0u | (tss & 0x3u));   /* TRXD_MODULATION_8PSK / _GMSK */
+		buf[pos++] = (uint8_t)(((idle ? 1u : 0u) << 7) | ((mod & 0xf) << 3) | (tsc & 0x7));
+		buf[pos++] = (uint8_t)((uint16_t)ci_cb >> 8);
+		buf[pos++] = (uint8_t)ci_cb;
+		if (!idle) {                                       /* :106-107 */
+			orc_trxd_soft_u8(buf + pos, rx_burst, nbits);
+			pos += nbits;
+		}
+		return (int)pos;
+	}
+	orc_trxd_soft_u8(buf + pos, rx_burst, nbits);
+	pos += nbits;
+	buf[pos++] = 0;                                        /* uninitialised in the reference */
+	buf[pos++] = '\0';                                     /* :87 */
+	return (int)pos;
+}
+
 /* ------------------------------------------------------------------------------------------
  * Channelizer.cpp / ChannelizerBase.cpp.  FFTW (arch/common/fft.c:55-114) is a third-party
  * dependency absent here ("fftw3f", unpinned via pkg-config, configure.ac:291); its M-point

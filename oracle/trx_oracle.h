@@ -149,6 +149,9 @@ void  orc_va_viterbi(const orc_cf *in, unsigned n, const orc_cf *rhh, unsigned s
 int     orc_trxd_toa256(double toa);
 int16_t orc_trxd_ci_cb(float ci);
 void    orc_trxd_soft_u8(uint8_t *dst, const float *rx_burst, unsigned nbits);
+/* proto_trxd.c:68-117: the whole v0 / v1 datagram; returns its length (0 = not sent) */
+int     orc_trxd_pack(uint8_t *buf, unsigned version, uint32_t fn, uint8_t tn, double rssi, double toa, int idle,
+		      int modulation_8psk, uint8_t tss, uint8_t tsc, float ci, const float *rx_burst, unsigned nbits);
 
 /* ---- Channelizer (Channelizer.cpp / ChannelizerBase.cpp), M-path polyphase + M-point DFT ---- */
 typedef struct orc_channelizer orc_channelizer;

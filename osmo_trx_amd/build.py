@@ -19,9 +19,13 @@ LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libtrxhip.so")
 
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+# host-only translation units (they call the HIP runtime API, they hold no kernels): plain g++ against libamdhip64
+HOSTCXX = [shutil.which("g++") or "g++", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROCM, "include")]
+HOSTLINK = ["-L", os.path.join(ROCM, "lib"), "-lamdhip64", "-Wl,-rpath," + os.path.join(ROCM, "lib")]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-result"]
 
-LIB_SOURCES = ["trx_kernel4.hip", "trx_kernels.hip", "trx_aux_kernels.hip", "trx_sch.hip", "trx_va.hip", "trx_capi.cpp", "trx_tables.cpp"]
+LIB_SOURCES = ["trx_kernel4.hip", "trx_kernels.hip", "trx_aux_kernels.hip", "trx_sch.hip", "trx_va.hip", "trx_capi.cpp", "trx_hostpipe.cpp", "trx_tables.cpp"]
 
 
 def _stale(target, sources):
@@ -63,34 +67,79 @@ def build_diag(force=False):
     return out
 
 
+def ref_include_dirs():
+    """Include directories of an osmo-trx checkout (TRXHIP_REF_INCLUDE=<checkout>, default /root/reference), or None.
+    The product shim is compiled against osmo-trx's own Vector.h / signalVector.h / Complex.h / BitVector.h /
+    sigProcLib.h so that its objects have the reference's layout (ABI-true drop-in)."""
+    ref = os.environ.get("TRXHIP_REF_INCLUDE", "/root/reference")
+    t52, common = os.path.join(ref, "Transceiver52M"), os.path.join(ref, "CommonLibs")
+    if all(os.path.exists(os.path.join(d, f)) for d, f in ((t52, "sigProcLib.h"), (t52, "signalVector.h"),
+                                                            (t52, "Complex.h"), (common, "Vector.h"), (common, "BitVector.h"))):
+        return [t52, common]
+    return None
+
+
+SHIM_SOURCES = ["sigProcLib.cpp", "MultiArfcnRx.cpp", "BurstGatherer.cpp"]
+
+
+def _build_shim(out, inc_dirs, force):
+    srcs = [os.path.join(HOST, f) for f in SHIM_SOURCES]
+    deps = srcs + [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".h")] + \
+        [os.path.join(HOST, "compat", f) for f in os.listdir(os.path.join(HOST, "compat"))]
+    if force or _stale(out, deps + [LIB]):
+        inc = []
+        for d in inc_dirs + [HOST, os.path.join(ROOT, "include")]:
+            inc += ["-I", d]
+        # -Wl,-z,undefs is the default for shared objects: the out-of-line members of the reference's signalVector
+        # (signalVector.cpp) stay undefined here and are resolved by the process that loads the shim, as in osmo-trx
+        _run(HOSTCXX + ["-shared"] + COMMON + ["-pthread"] + inc + ["-o", out] + srcs +
+             ["-L", LIBDIR, "-ltrxhip", "-Wl,-rpath,$ORIGIN"] + HOSTLINK)
+    return out
+
+
 def build_host(force=False):
-    """C++ host shim (sigProcLib.h-compatible API over the C ABI) + its test/demo executables."""
+    """C++ host shim (sigProcLib.h API over the C ABI) in its two builds + the selftest executable.
+
+    libtrxsigproc.so     against osmo-trx's own headers (only when a checkout is present: this container, or
+                         TRXHIP_REF_INCLUDE); on a box without one the prebuilt library that travelled is kept.
+    libtrxsigproc_sa.so  against host/compat (stand-alone look-alikes in namespace trxhip_sa) + sigproc_selftest.
+    The ABI-true selftest (same source, reference headers, the reference's signalVector.cpp compiled where it lies)
+    is built by oracle/Makefile into oracle/_ref/ -- reference objects only ever land there."""
     built = []
-    shim_src = os.path.join(HOST, "sigProcLib.cpp")
-    if not os.path.exists(shim_src):
+    if not os.path.exists(os.path.join(HOST, "sigProcLib.cpp")):
         return built
-    shim_srcs = [shim_src, os.path.join(HOST, "MultiArfcnRx.cpp")]
+    ref = ref_include_dirs()
     shim = os.path.join(LIBDIR, "libtrxsigproc.so")
-    deps = shim_srcs + [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".h")]
-    if force or _stale(shim, deps + [LIB]):
-        _run([HIPCC, "-shared"] + COMMON + ["-I", HOST, "-I", os.path.join(ROOT, "include"), "-o", shim] + shim_srcs + [
-              "-L", LIBDIR, "-ltrxhip", "-Wl,-rpath,$ORIGIN"])
-    built.append(shim)
-    for prog in ("sigproc_selftest",):
-        src = os.path.join(HOST, prog + ".cpp")
-        if not os.path.exists(src):
-            continue
-        exe = os.path.join(LIBDIR, prog)
-        if force or _stale(exe, [src, shim]):
-            _run([HIPCC] + COMMON + ["-I", HOST, "-I", os.path.join(ROOT, "include"), "-o", exe, src,
-                  "-L", LIBDIR, "-ltrxsigproc", "-ltrxhip", "-Wl,-rpath,$ORIGIN"])
-        built.append(exe)
+    if ref:
+        built.append(_build_shim(shim, ref, force))
+    elif os.path.exists(shim):
+        built.append(shim)
+    sa = _build_shim(os.path.join(LIBDIR, "libtrxsigproc_sa.so"), [os.path.join(HOST, "compat")], force)
+    built.append(sa)
+    src = os.path.join(HOST, "sigproc_selftest.cpp")
+    exe = os.path.join(LIBDIR, "sigproc_selftest")
+    if force or _stale(exe, [src, sa]):
+        _run(HOSTCXX + COMMON + ["-pthread", "-I", os.path.join(HOST, "compat"), "-I", HOST, "-I", os.path.join(ROOT, "include"),
+                       "-o", exe, src, "-L", LIBDIR, "-ltrxsigproc_sa", "-ltrxhip", "-Wl,-rpath,$ORIGIN"] + HOSTLINK)
+    built.append(exe)
     return built
+
+
+def build_arch(force=False):
+    """libtrxarch.so: the reference's arch seam (convolve_real, convert_short_float, cxvec_fft, ...) under its own names,
+    include/trxarch.h."""
+    out = os.path.join(LIBDIR, "libtrxarch.so")
+    src = os.path.join(HOST, "trxarch.cpp")
+    if force or _stale(out, [src, os.path.join(ROOT, "include", "trxarch.h"), LIB]):
+        _run(HOSTCXX + ["-shared"] + COMMON + ["-pthread", "-I", os.path.join(ROOT, "include"), "-o", out, src,
+                        "-L", LIBDIR, "-ltrxhip", "-Wl,-rpath,$ORIGIN"] + HOSTLINK)
+    return out
 
 
 def build_all(force=False, verbose=False):
     out = [build_lib(force, verbose)]
     out += build_host(force)
+    out.append(build_arch(force))
     return out
 
 

@@ -50,6 +50,79 @@ extern "C" int trx_launch_convert_short_float(float *d_out, const int16_t *d_in,
 	return hipGetLastError() == hipSuccess ? 0 : TRXHIP_EIO;
 }
 
+// fp32 -> int16 with scaling, the generic-C form: out[i] = (short)(in[i] * scale)  (convert_base.c:20-25: truncation
+// toward zero; the SSE path of the reference rounds to nearest and saturates instead, convert_sse_3.c:29-102)
+__global__ void __launch_bounds__(256)
+convert_float_short_kernel(int16_t *__restrict__ out, const float *__restrict__ in, float scale, size_t len)
+{
+	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x)
+		out[i] = (int16_t)(int)(in[i] * scale);
+}
+
+extern "C" int trx_launch_convert_float_short(int16_t *d_out, const float *d_in, float scale, size_t len, hipStream_t stream)
+{
+	if (len == 0)
+		return 0;
+	size_t blocks = (len + 255) / 256;
+	if (blocks > 2048) blocks = 2048;
+	hipLaunchKernelGGL(convert_float_short_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d_out, d_in, scale, len);
+	return hipGetLastError() == hipSuccess ? 0 : TRXHIP_EIO;
+}
+
+// ------------------------------------------------------------------------------------------------
+// cxvec_fft() (arch/common/fft.c:55-114): `howmany` independent M-point DFTs laid out as the reference's
+// fftwf_plan_many_dft(rank 1, n = m, howmany, in, istride, idist = 1, out, ostride, odist = 1) call does:
+// transform t reads in[j * istride + t] and writes out[k * ostride + t].  One thread per transform.
+// M = 4 (the only size the reference instantiates: Channelizer / Synthesis) uses exact +-1 / +-j butterflies;
+// other M evaluate X[k] = sum_j x[j] w^(jk) directly with twiddles from sincospi (double) -- FFTW is absent here, so
+// there is nothing to be bit-compatible with beyond the mathematical definition ("parity unpinned").
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+dft_strided_kernel(const c32 *__restrict__ in, c32 *__restrict__ out, int m, size_t howmany, size_t istride, size_t ostride,
+		   int reverse)
+{
+	for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < howmany; t += (size_t)gridDim.x * blockDim.x) {
+		if (m == 4) {
+			const c32 y0 = in[t], y1 = in[istride + t], y2 = in[2 * istride + t], y3 = in[3 * istride + t];
+			const c32 t1 = make_float2(y0.x + y2.x, y0.y + y2.y);
+			const c32 t2 = make_float2(y0.x - y2.x, y0.y - y2.y);
+			const c32 t3 = make_float2(y1.x + y3.x, y1.y + y3.y);
+			const c32 t4 = make_float2(y1.x - y3.x, y1.y - y3.y);
+			const c32 a = make_float2(t2.x + t4.y, t2.y - t4.x);       // t2 - j*t4
+			const c32 b = make_float2(t2.x - t4.y, t2.y + t4.x);       // t2 + j*t4
+			out[t] = make_float2(t1.x + t3.x, t1.y + t3.y);
+			out[ostride + t] = reverse ? b : a;
+			out[2 * ostride + t] = make_float2(t1.x - t3.x, t1.y - t3.y);
+			out[3 * ostride + t] = reverse ? a : b;
+		} else {
+			for (int k = 0; k < m; k++) {
+				double ar = 0.0, ai = 0.0;
+				for (int j = 0; j < m; j++) {
+					double sn, cs;
+					sincospi(2.0 * (double)((j * k) % m) / (double)m, &sn, &cs);
+					if (!reverse) sn = -sn;
+					const c32 x = in[(size_t)j * istride + t];
+					ar += (double)x.x * cs - (double)x.y * sn;
+					ai += (double)x.x * sn + (double)x.y * cs;
+				}
+				out[(size_t)k * ostride + t] = make_float2((float)ar, (float)ai);
+			}
+		}
+	}
+}
+
+extern "C" int trx_launch_dft_strided(const float *d_in, float *d_out, int m, size_t howmany, size_t istride, size_t ostride,
+				      int reverse, hipStream_t stream)
+{
+	if (howmany == 0)
+		return 0;
+	size_t blocks = (howmany + 255) / 256;
+	if (blocks > 2048) blocks = 2048;
+	hipLaunchKernelGGL(dft_strided_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<const c32 *>(d_in),
+			   reinterpret_cast<c32 *>(d_out), m, howmany, istride, ostride, reverse);
+	return hipGetLastError() == hipSuccess ? 0 : TRXHIP_EIO;
+}
+
 // ------------------------------------------------------------------------------------------------
 // batched correlation-form FIR:  y[v][i] = sum_k x[v][i + start - (H-1) + k] * h[k]
 // one thread per output sample, taps staged in LDS, sequential k (generic-C order)
@@ -336,6 +409,89 @@ extern "C" int trx_launch_pack_trxd(const trxhip_burst_result *d_results, const 
 	if (blocks > 256 * 8) blocks = 256 * 8;
 	hipLaunchKernelGGL(pack_trxd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d_results, d_soft, soft_stride,
 			   d_pkt, n_bursts, rssi_offset);
+	return hipGetLastError() == hipSuccess ? 0 : TRXHIP_EIO;
+}
+
+// ------------------------------------------------------------------------------------------------
+// TRXD v0 / v1 uplink burst indications in wire format (proto_trxd.c:28-117, proto_trxd.h:56-106): the datagram of
+// burst b at pkt + b * pkt_stride, its length in pkt_len[b].  One thread per output dword (coalesced stores); each
+// thread rebuilds the few header fields it needs from the 32-byte result record (L1/L2 hits) -- the kernel moves
+// 32 + 592 B in and <= 160 B out per burst and is a small fraction of the detect/demod launch in front of it.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t trxd_byte(int p, int hdr_len, int nbits, bool v1, const uint8_t *hdr, const float *s)
+{
+	if (p < hdr_len)
+		return hdr[p];
+	const int k = p - hdr_len;
+	if (k < nbits)
+		return (uint32_t)(uint8_t)round((double)s[k] * 255.0);      // trxd_fill_burst_normalized255(), :62-66
+	return 0u;                                                           // v0's two trailing bytes (:83-87), padding
+}
+
+__global__ void __launch_bounds__(256)
+pack_trxd_wire_kernel(const trxhip_burst_result *__restrict__ res, const trxhip_burst_params *__restrict__ prm,
+		      const float *__restrict__ soft, int soft_stride, const trxhip_trxd_meta *__restrict__ meta,
+		      uint8_t *__restrict__ pkt, int pkt_stride, uint16_t *__restrict__ pkt_len, size_t n_bursts, float rssi_offset)
+{
+	const int wpb = pkt_stride >> 2;                                     // dwords per burst
+	const size_t total = n_bursts * (size_t)wpb;
+	uint32_t *out = reinterpret_cast<uint32_t *>(pkt);
+	for (size_t o = blockIdx.x * (size_t)blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+		const size_t b = o / wpb;
+		const int wd = (int)(o - b * wpb);
+		const trxhip_burst_result r = res[b];
+		const trxhip_trxd_meta m = meta[b];
+		const bool v1 = m.version != 0;
+		const bool off = prm[b].type == TRXHIP_OFF;                      // -ENOENT: nothing is sent (Transceiver.cpp:704-707)
+		const bool idle = r.idle != 0;
+		int nbits = idle ? 0 : 4 * (int)r.nbits_div4;
+		const int hdr_len = v1 ? TRXHIP_TRXD_V1_HDR : TRXHIP_TRXD_V0_HDR;
+		int len = v1 ? hdr_len + nbits : hdr_len + nbits + 2;            // :76, :96-99
+		if (off || (!v1 && idle))                                        // v0 drops idle indications (:71-73)
+			len = 0;
+		if (len > pkt_stride) {
+			len = pkt_stride;
+			nbits = nbits < pkt_stride - hdr_len ? nbits : pkt_stride - hdr_len;
+		}
+		if (nbits > soft_stride) nbits = soft_stride;
+
+		uint8_t hdr[TRXHIP_TRXD_V1_HDR];
+		hdr[0] = (uint8_t)(((v1 ? 1u : 0u) << 4) | (m.tn & 7u));         // trxd_fill_common(): version:4 | reserved:1 | tn:3
+		hdr[1] = (uint8_t)(m.fn >> 24); hdr[2] = (uint8_t)(m.fn >> 16); hdr[3] = (uint8_t)(m.fn >> 8); hdr[4] = (uint8_t)m.fn;
+		const double rssi = (double)r.rssi + (double)rssi_offset;        // bi->rssi (Transceiver.cpp:751)
+		hdr[5] = (rssi >= 255.0) ? 255u : (rssi > 0.0 ? (uint8_t)rssi : 0u);   // v0->rssi = bi->rssi (NaN -> 0)
+		const int toa_int = idle ? 0 : (int)((double)r.toa * 256.0 + 0.5);     // trxd_fill_v0_specific(), :36-45
+		hdr[6] = (uint8_t)((uint32_t)toa_int >> 8); hdr[7] = (uint8_t)toa_int;
+		const bool psk = !idle && r.nbits_div4 == 111;                   // bi->modulation (Transceiver.cpp:794-800)
+		const uint32_t mod = psk ? (4u | (m.tss & 1u)) : (m.tss & 3u);   // TRXD_MODULATION_8PSK / _GMSK
+		hdr[8] = (uint8_t)(((idle ? 1u : 0u) << 7) | (mod << 3) | (idle ? 0u : (r.tsc & 7u)));   // tsc:3 | modulation:4 | idle:1
+		const int ci_cb = idle ? 0 : (int16_t)((double)(r.ci * 10) + 0.5);    // trxd_fill_v1_specific(), :47-60
+		hdr[9] = (uint8_t)((uint32_t)ci_cb >> 8); hdr[10] = (uint8_t)ci_cb;
+
+		const float *s = soft + b * (size_t)soft_stride;
+		uint32_t word = 0;
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			const int p = 4 * wd + k;
+			if (p < len)
+				word |= trxd_byte(p, hdr_len, nbits, v1, hdr, s) << (8 * k);
+		}
+		out[o] = word;
+		if (wd == 0)
+			pkt_len[b] = (uint16_t)len;
+	}
+}
+
+extern "C" int trx_launch_pack_trxd_wire(const trxhip_burst_result *d_results, const trxhip_burst_params *d_params,
+					 const float *d_soft, int soft_stride, const trxhip_trxd_meta *d_meta, uint8_t *d_pkt,
+					 int pkt_stride, uint16_t *d_pkt_len, size_t n_bursts, float rssi_offset, hipStream_t stream)
+{
+	if (n_bursts == 0)
+		return 0;
+	size_t blocks = (n_bursts * (size_t)(pkt_stride >> 2) + 255) / 256;
+	if (blocks > 256 * 8) blocks = 256 * 8;
+	hipLaunchKernelGGL(pack_trxd_wire_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d_results, d_params, d_soft,
+			   soft_stride, d_meta, d_pkt, pkt_stride, d_pkt_len, n_bursts, rssi_offset);
 	return hipGetLastError() == hipSuccess ? 0 : TRXHIP_EIO;
 }
 

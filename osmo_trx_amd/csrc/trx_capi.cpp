@@ -18,9 +18,15 @@ extern "C" int trx_launch_pull(const void *d_iq, int cf32, const trxhip_burst_pa
 			       int soft_stride, int slice, int n_cu, hipStream_t stream);
 extern "C" int trx_launch_pack_trxd(const trxhip_burst_result *d_results, const float *d_soft, int soft_stride,
 				    uint8_t *d_pkt, size_t n_bursts, float rssi_offset, hipStream_t stream);
+extern "C" int trx_launch_pack_trxd_wire(const trxhip_burst_result *d_results, const trxhip_burst_params *d_params,
+					 const float *d_soft, int soft_stride, const trxhip_trxd_meta *d_meta, uint8_t *d_pkt,
+					 int pkt_stride, uint16_t *d_pkt_len, size_t n_bursts, float rssi_offset, hipStream_t stream);
 extern "C" int trx_launch_convolve(const float *d_x, int x_len, const float *d_h, int h_len, int h_complex,
 				   float *d_y, int y_len, int start, int len, size_t n_vec, hipStream_t stream);
 extern "C" int trx_launch_convert_short_float(float *d_out, const int16_t *d_in, size_t len, hipStream_t stream);
+extern "C" int trx_launch_convert_float_short(int16_t *d_out, const float *d_in, float scale, size_t len, hipStream_t stream);
+extern "C" int trx_launch_dft_strided(const float *d_in, float *d_out, int m, size_t howmany, size_t istride, size_t ostride,
+				      int reverse, hipStream_t stream);
 extern "C" int trx_launch_channelize(const int16_t *d_in, float *d_out, size_t n_total, size_t out_stride,
 				     const trx_tables *d_tab, void *d_hist_io, hipStream_t stream);
 extern "C" int trx_launch_resample(const float *d_in, float *d_out, size_t n_in, int p, int q, size_t n_chan,
@@ -39,16 +45,7 @@ extern "C" int trx_launch_va_demod(const float *d_iq, const trxhip_burst_params 
 				   size_t n_bursts, int L, float scale, int soft_stride, int flags, hipStream_t stream);
 extern "C" int trx_launch_vector_slicer(float *d_dst, const float *d_src, size_t len, hipStream_t stream);
 
-struct trxhip_ctx {
-	int device;
-	int n_cu;
-	trx_tables *d_tables;
-};
-
-static int with_device(const trxhip_ctx *ctx)
-{
-	return hipSetDevice(ctx->device) == hipSuccess ? 0 : TRXHIP_EIO;
-}
+#include "trx_ctx.h"
 
 extern "C" {
 
@@ -223,6 +220,24 @@ int trxhip_pack_trxd_batch(trxhip_ctx *ctx, const trxhip_burst_result *d_results
 				    static_cast<hipStream_t>(stream));
 }
 
+int trxhip_pack_trxd_wire_batch(trxhip_ctx *ctx, const trxhip_burst_result *d_results, const trxhip_burst_params *d_params,
+				const float *d_soft_sliced, int soft_stride, const trxhip_trxd_meta *d_meta,
+				uint8_t *d_pkt, int pkt_stride, uint16_t *d_pkt_len, size_t n_bursts, float rssi_offset,
+				void *stream)
+{
+	if (!ctx || soft_stride < 148 || pkt_stride < 160 || (pkt_stride & 3))
+		return TRXHIP_EINVAL;
+	if (n_bursts == 0)
+		return TRXHIP_OK;
+	if (!d_results || !d_params || !d_soft_sliced || !d_meta || !d_pkt || !d_pkt_len || n_bursts > 0x7fffffffull ||
+	    (reinterpret_cast<uintptr_t>(d_pkt) & 3) != 0)
+		return TRXHIP_EINVAL;
+	if (with_device(ctx))
+		return TRXHIP_EIO;
+	return trx_launch_pack_trxd_wire(d_results, d_params, d_soft_sliced, soft_stride, d_meta, d_pkt, pkt_stride, d_pkt_len,
+					 n_bursts, rssi_offset, static_cast<hipStream_t>(stream));
+}
+
 static int conv_common(trxhip_ctx *ctx, const float *d_x, int x_len, const float *d_h, int h_len, int h_complex,
 		       float *d_y, int y_len, int start, int len, size_t n_vec, void *stream)
 {
@@ -258,6 +273,29 @@ int trxhip_convert_short_float(trxhip_ctx *ctx, float *d_out, const int16_t *d_i
 	if (with_device(ctx))
 		return TRXHIP_EIO;
 	return trx_launch_convert_short_float(d_out, d_in, len, static_cast<hipStream_t>(stream));
+}
+
+int trxhip_convert_float_short(trxhip_ctx *ctx, int16_t *d_out, const float *d_in, float scale, size_t len, void *stream)
+{
+	if (!ctx || (len && (!d_out || !d_in)))
+		return TRXHIP_EINVAL;
+	if (with_device(ctx))
+		return TRXHIP_EIO;
+	return trx_launch_convert_float_short(d_out, d_in, scale, len, static_cast<hipStream_t>(stream));
+}
+
+int trxhip_dft_batch(trxhip_ctx *ctx, const float *d_in, float *d_out, int m, size_t howmany, size_t istride, size_t ostride,
+		     int reverse, void *stream)
+{
+	if (!ctx || m < 1 || m > 4096 || istride < howmany || ostride < howmany)
+		return TRXHIP_EINVAL;
+	if (howmany == 0)
+		return TRXHIP_OK;
+	if (!d_in || !d_out || d_in == d_out)
+		return TRXHIP_EINVAL;
+	if (with_device(ctx))
+		return TRXHIP_EIO;
+	return trx_launch_dft_strided(d_in, d_out, m, howmany, istride, ostride, reverse, static_cast<hipStream_t>(stream));
 }
 
 int trxhip_energy_detect_batch_cf32(trxhip_ctx *ctx, const float *d_iq, size_t n_bursts, int burst_len,

@@ -1,0 +1,18 @@
+// trx_ctx.h -- the context object behind trxhip_ctx* (internal to csrc/; the C ABI only hands out the pointer).
+#ifndef TRX_CTX_H
+#define TRX_CTX_H
+#include <hip/hip_runtime.h>
+#include "../../include/trxhip.h"
+#include "trx_tables.h"
+
+struct trxhip_ctx {
+	int device;
+	int n_cu;
+	trx_tables *d_tables;
+};
+
+static inline int with_device(const trxhip_ctx *ctx)
+{
+	return hipSetDevice(ctx->device) == hipSuccess ? 0 : TRXHIP_EIO;
+}
+#endif

@@ -1,0 +1,227 @@
+// trx_hostpipe.cpp -- host-fed, stream-pipelined form of the hot path (include/trxhip.h, trxhip_hostpipe_*).
+//
+// pullRadioVector()'s callers (Transceiver.cpp:665-815) hold bursts in host memory; this is the piece between
+// them and trxhip_detect_demod_batch(): `depth` staging slots, each = pinned host buffers + device buffers + one
+// HIP stream.  A submitted slot runs H2D -> detect/demod [-> TRXD wire packer] -> D2H on its own stream, so the
+// upload of one slot, the kernels of another and the download of a third overlap (the two DMA directions and the
+// compute queue are independent engines).  Everything is allocated in create(); submit() only enqueues.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <new>
+
+#include "trx_ctx.h"
+
+struct trxhip_hostpipe {
+	trxhip_ctx *ctx;
+	trxhip_hostpipe_cfg cfg;
+	int dev_soft_stride;               /* stride of the device-side soft rows (>= what the packer needs) */
+	struct Slot {
+		hipStream_t stream;
+		hipEvent_t done;
+		bool busy, failed;
+		size_t n;
+		trxhip_hostpipe_slot h;        /* pinned host */
+		int16_t *d_iq;
+		trxhip_burst_params *d_params;
+		trxhip_trxd_meta *d_meta;
+		trxhip_burst_result *d_results;
+		float *d_soft;
+		uint8_t *d_pkt;
+		uint16_t *d_pkt_len;
+	} slot[16];
+};
+
+static bool pin(void **p, size_t bytes) { return hipHostMalloc(p, bytes ? bytes : 16, hipHostMallocDefault) == hipSuccess; }
+static bool dev(void **p, size_t bytes) { return hipMalloc(p, bytes ? bytes : 16) == hipSuccess; }
+
+extern "C" {
+
+int trxhip_hostpipe_create(trxhip_ctx *ctx, const trxhip_hostpipe_cfg *c, trxhip_hostpipe **out)
+{
+	if (!ctx || !c || !out)
+		return TRXHIP_EINVAL;
+	if (c->max_bursts < 1 || c->max_bursts > (1u << 24) || c->depth < 2 || c->depth > 16)
+		return TRXHIP_EINVAL;
+	if ((c->sps != 1 && c->sps != 4) || c->burst_len < 148 || c->burst_len > TRXHIP_MAX_BURST_LEN)
+		return TRXHIP_EINVAL;
+	if (c->soft_stride < 0 || (c->soft_stride > 0 && c->soft_stride < 148))
+		return TRXHIP_EINVAL;
+	if (c->pkt_stride < 0 || (c->pkt_stride > 0 && (c->pkt_stride < 160 || (c->pkt_stride & 3))))
+		return TRXHIP_EINVAL;
+	if (c->soft_stride == 0 && c->pkt_stride == 0)
+		return TRXHIP_EINVAL;
+	if (with_device(ctx))
+		return TRXHIP_EIO;
+
+	trxhip_hostpipe *p = new (std::nothrow) trxhip_hostpipe();
+	if (!p)
+		return TRXHIP_ENOMEM;
+	memset(p, 0, sizeof(*p));
+	p->ctx = ctx;
+	p->cfg = *c;
+	if (c->pkt_stride)
+		p->cfg.flags |= TRXHIP_FLAG_SLICE;                     /* the packer quantises vectorSlicer()'s 0..1 values */
+	/* device rows: what the caller downloads, or -- TRXD only -- what the packer can consume */
+	p->dev_soft_stride = c->soft_stride ? c->soft_stride : (c->pkt_stride >= TRXHIP_TRXD_V1_HDR + 444 ? 444 : 148);
+	const size_t nb = c->max_bursts;
+	bool ok = true;
+	for (int s = 0; s < c->depth && ok; s++) {
+		trxhip_hostpipe::Slot &sl = p->slot[s];
+		ok = hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) == hipSuccess &&
+		     hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) == hipSuccess &&
+		     pin((void **)&sl.h.iq, nb * c->burst_len * 4) && pin((void **)&sl.h.params, nb * sizeof(trxhip_burst_params)) &&
+		     pin((void **)&sl.h.results, nb * sizeof(trxhip_burst_result)) &&
+		     dev((void **)&sl.d_iq, nb * c->burst_len * 4) && dev((void **)&sl.d_params, nb * sizeof(trxhip_burst_params)) &&
+		     dev((void **)&sl.d_results, nb * sizeof(trxhip_burst_result)) &&
+		     dev((void **)&sl.d_soft, nb * p->dev_soft_stride * sizeof(float));
+		if (ok && c->soft_stride)
+			ok = pin((void **)&sl.h.soft, nb * c->soft_stride * sizeof(float));
+		if (ok && c->pkt_stride)
+			ok = pin((void **)&sl.h.meta, nb * sizeof(trxhip_trxd_meta)) && pin((void **)&sl.h.pkt, nb * c->pkt_stride) &&
+			     pin((void **)&sl.h.pkt_len, nb * sizeof(uint16_t)) && dev((void **)&sl.d_meta, nb * sizeof(trxhip_trxd_meta)) &&
+			     dev((void **)&sl.d_pkt, nb * c->pkt_stride) && dev((void **)&sl.d_pkt_len, nb * sizeof(uint16_t));
+	}
+	if (!ok) {
+		trxhip_hostpipe_destroy(p);
+		return TRXHIP_ENOMEM;
+	}
+	*out = p;
+	return TRXHIP_OK;
+}
+
+void trxhip_hostpipe_destroy(trxhip_hostpipe *p)
+{
+	if (!p)
+		return;
+	(void)with_device(p->ctx);
+	for (int s = 0; s < 16; s++) {
+		trxhip_hostpipe::Slot &sl = p->slot[s];
+		if (sl.stream) (void)hipStreamSynchronize(sl.stream);
+		void *hp[] = { sl.h.iq, sl.h.params, sl.h.meta, sl.h.results, sl.h.soft, sl.h.pkt, sl.h.pkt_len };
+		for (void *q : hp) if (q) (void)hipHostFree(q);
+		void *dp[] = { sl.d_iq, sl.d_params, sl.d_meta, sl.d_results, sl.d_soft, sl.d_pkt, sl.d_pkt_len };
+		for (void *q : dp) if (q) (void)hipFree(q);
+		if (sl.done) (void)hipEventDestroy(sl.done);
+		if (sl.stream) (void)hipStreamDestroy(sl.stream);
+	}
+	delete p;
+}
+
+int trxhip_hostpipe_slot_buffers(trxhip_hostpipe *p, int slot, trxhip_hostpipe_slot *out)
+{
+	if (!p || !out || slot < 0 || slot >= p->cfg.depth)
+		return TRXHIP_EINVAL;
+	*out = p->slot[slot].h;
+	return TRXHIP_OK;
+}
+
+int trxhip_hostpipe_submit(trxhip_hostpipe *p, int slot, size_t n)
+{
+	if (!p || slot < 0 || slot >= p->cfg.depth || n > p->cfg.max_bursts)
+		return TRXHIP_EINVAL;
+	trxhip_hostpipe::Slot &sl = p->slot[slot];
+	if (sl.busy)
+		return TRXHIP_EINVAL;                                  /* wait() first */
+	sl.n = n;
+	sl.failed = false;
+	if (n == 0)
+		return TRXHIP_OK;
+	const trxhip_hostpipe_cfg &c = p->cfg;
+	if (with_device(p->ctx))
+		return TRXHIP_EIO;
+	hipStream_t st = sl.stream;
+	bool ok = hipMemcpyAsync(sl.d_iq, sl.h.iq, n * c.burst_len * 4, hipMemcpyHostToDevice, st) == hipSuccess &&
+		  hipMemcpyAsync(sl.d_params, sl.h.params, n * sizeof(trxhip_burst_params), hipMemcpyHostToDevice, st) == hipSuccess;
+	if (ok && c.pkt_stride)
+		ok = hipMemcpyAsync(sl.d_meta, sl.h.meta, n * sizeof(trxhip_trxd_meta), hipMemcpyHostToDevice, st) == hipSuccess;
+	int rc = ok ? trxhip_detect_demod_batch(p->ctx, sl.d_iq, sl.d_params, sl.d_results, sl.d_soft, n, c.burst_len, c.sps,
+						c.threshold, c.full_scale, p->dev_soft_stride, c.flags, st)
+		    : TRXHIP_EIO;
+	if (rc == TRXHIP_OK && c.pkt_stride)
+		rc = trxhip_pack_trxd_wire_batch(p->ctx, sl.d_results, sl.d_params, sl.d_soft, p->dev_soft_stride, sl.d_meta, sl.d_pkt,
+						 c.pkt_stride, sl.d_pkt_len, n, c.rssi_offset, st);
+	ok = rc == TRXHIP_OK &&
+	     hipMemcpyAsync(sl.h.results, sl.d_results, n * sizeof(trxhip_burst_result), hipMemcpyDeviceToHost, st) == hipSuccess;
+	if (ok && c.soft_stride)
+		ok = hipMemcpyAsync(sl.h.soft, sl.d_soft, n * c.soft_stride * sizeof(float), hipMemcpyDeviceToHost, st) == hipSuccess;
+	if (ok && c.pkt_stride)
+		ok = hipMemcpyAsync(sl.h.pkt, sl.d_pkt, n * (size_t)c.pkt_stride, hipMemcpyDeviceToHost, st) == hipSuccess &&
+		     hipMemcpyAsync(sl.h.pkt_len, sl.d_pkt_len, n * sizeof(uint16_t), hipMemcpyDeviceToHost, st) == hipSuccess;
+	if (ok)
+		ok = hipEventRecord(sl.done, st) == hipSuccess;
+	sl.busy = true;                                            /* even on failure: wait() drains what was enqueued */
+	sl.failed = !ok;
+	return ok ? TRXHIP_OK : (rc != TRXHIP_OK ? rc : TRXHIP_EIO);
+}
+
+int trxhip_hostpipe_wait(trxhip_hostpipe *p, int slot)
+{
+	if (!p || slot < 0 || slot >= p->cfg.depth)
+		return TRXHIP_EINVAL;
+	trxhip_hostpipe::Slot &sl = p->slot[slot];
+	if (!sl.busy)
+		return TRXHIP_OK;
+	const bool ok = hipStreamSynchronize(sl.stream) == hipSuccess && !sl.failed;
+	sl.busy = false;
+	return ok ? TRXHIP_OK : TRXHIP_EIO;
+}
+
+int trxhip_hostpipe_query(trxhip_hostpipe *p, int slot)
+{
+	if (!p || slot < 0 || slot >= p->cfg.depth)
+		return TRXHIP_EINVAL;
+	trxhip_hostpipe::Slot &sl = p->slot[slot];
+	if (!sl.busy || sl.failed)
+		return 0;
+	const hipError_t e = hipEventQuery(sl.done);
+	return e == hipSuccess ? 0 : (e == hipErrorNotReady ? 1 : TRXHIP_EIO);
+}
+
+int trxhip_hostpipe_run(trxhip_hostpipe *p, const int16_t *h_iq, const trxhip_burst_params *h_params,
+			const trxhip_trxd_meta *h_meta, trxhip_burst_result *h_results, float *h_soft, uint8_t *h_pkt,
+			uint16_t *h_pkt_len, size_t n)
+{
+	if (!p || (n && (!h_iq || !h_params || !h_results)))
+		return TRXHIP_EINVAL;
+	const trxhip_hostpipe_cfg &c = p->cfg;
+	if ((h_soft && !c.soft_stride) || ((h_pkt || h_pkt_len) && !c.pkt_stride) || (c.pkt_stride && n && !h_meta))
+		return TRXHIP_EINVAL;
+	for (int s = 0; s < c.depth; s++)
+		if (p->slot[s].busy)
+			return TRXHIP_EINVAL;
+	const size_t chunk = c.max_bursts, burst_bytes = (size_t)c.burst_len * 4;
+	const size_t n_chunks = (n + chunk - 1) / chunk;
+	int rc = TRXHIP_OK;
+	/* chunk k uses slot k % depth: stage k, submit k, then collect chunk k - depth + 1 (oldest in flight) */
+	auto collect = [&](size_t k) {
+		const int s = (int)(k % c.depth);
+		const size_t off = k * chunk, m = (off + chunk <= n) ? chunk : n - off;
+		const int r = trxhip_hostpipe_wait(p, s);
+		if (r != TRXHIP_OK) { rc = r; return; }
+		const trxhip_hostpipe_slot &h = p->slot[s].h;
+		memcpy(h_results + off, h.results, m * sizeof(trxhip_burst_result));
+		if (h_soft) memcpy(h_soft + off * c.soft_stride, h.soft, m * c.soft_stride * sizeof(float));
+		if (h_pkt) memcpy(h_pkt + off * c.pkt_stride, h.pkt, m * (size_t)c.pkt_stride);
+		if (h_pkt_len) memcpy(h_pkt_len + off, h.pkt_len, m * sizeof(uint16_t));
+	};
+	for (size_t k = 0; k < n_chunks; k++) {
+		if (k >= (size_t)c.depth)
+			collect(k - c.depth);
+		const int s = (int)(k % c.depth);
+		const size_t off = k * chunk, m = (off + chunk <= n) ? chunk : n - off;
+		const trxhip_hostpipe_slot &h = p->slot[s].h;
+		memcpy(h.iq, h_iq + off * c.burst_len * 2, m * burst_bytes);
+		memcpy(h.params, h_params + off, m * sizeof(trxhip_burst_params));
+		if (c.pkt_stride) memcpy(h.meta, h_meta + off, m * sizeof(trxhip_trxd_meta));
+		const int r = trxhip_hostpipe_submit(p, s, m);
+		if (r != TRXHIP_OK && rc == TRXHIP_OK) rc = r;
+	}
+	for (size_t k = (n_chunks > (size_t)c.depth ? n_chunks - c.depth : 0); k < n_chunks; k++)
+		collect(k);
+	for (int s = 0; s < c.depth; s++)                              /* after an error: leave no slot busy */
+		(void)trxhip_hostpipe_wait(p, s);
+	return rc;
+}
+
+}  // extern "C"

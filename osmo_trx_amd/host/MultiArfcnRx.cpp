@@ -6,7 +6,7 @@
 #include "MultiArfcnRx.h"
 #include "trxhip.h"
 
-extern trxhip_ctx *trx_shim_context(void);      /* sigProcLib.cpp: the context sigProcLibSetup() created */
+extern "C" trxhip_ctx *trxsigproc_context(void);      /* sigProcLib.cpp: the context sigProcLibSetup() created */
 
 MultiArfcnRx::MultiArfcnRx(size_t chans, size_t block_len, int resamp_p, int resamp_q)
 	: chans_(chans), block_len_(block_len), p_(resamp_p), q_(resamp_q), fe_(nullptr), stream_(nullptr),
@@ -35,13 +35,13 @@ int MultiArfcnRx::getLogicalChan(size_t pchan, size_t chans)
 
 bool MultiArfcnRx::init()
 {
-	if (chans_ < 1 || chans_ > 3 || !trx_shim_context())
+	if (chans_ < 1 || chans_ > 3 || !trxsigproc_context())
 		return false;
 	hipStream_t s;
 	if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess)
 		return false;
 	stream_ = s;
-	return trxhip_rx_frontend_create(trx_shim_context(), (int)block_len_, p_, q_, &fe_) == TRXHIP_OK;
+	return trxhip_rx_frontend_create(trxsigproc_context(), (int)block_len_, p_, q_, &fe_) == TRXHIP_OK;
 }
 
 int MultiArfcnRx::pullBuffer(const int16_t *wide, size_t n_blocks, std::vector<std::vector<complex> > &out)

@@ -3,18 +3,29 @@
 // (hipMemcpyAsync on a per-thread stream) and converts between the reference's containers and the
 // C-ABI records.  Errors map to the reference's conventions: detectAnyBurst() -> -SIGERR_INTERNAL,
 // demodAnyBurst() -> NULL, pullRadioVectorBatch() -> -EIO (Transceiver.cpp:686).
+//
+// Two builds of this one source (osmo_trx_amd/build.py):
+//   libtrxsigproc.so     -I<osmo-trx>/Transceiver52M -I<osmo-trx>/CommonLibs: "sigProcLib.h" is the reference's own
+//                        header, so signalVector / SoftVector / estim_burst_params have the reference's layout and the
+//                        exported symbols are the ones reference-compiled callers (Transceiver.o) import.  Only public
+//                        methods of those classes are used (begin/end/size/bytes/isReal/clone, new signalVector(n),
+//                        new SoftVector(n)); their out-of-line members come from the caller's own signalVector.o.
+//   libtrxsigproc_sa.so  -Ihost/compat: the same API on look-alike containers in the inline namespace trxhip_sa, for
+//                        boxes without an osmo-trx checkout (different mangled names: cannot be mixed up).
 #include <hip/hip_runtime.h>
 
 #include <cerrno>
+#include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <vector>
 
-#include "sigProcLib.h"
-#include <cmath>
-#include "trxhip.h"
+#include "shim_internal.h"
 
+TRX_SHIM_NS_BEGIN
 namespace {
 
 trxhip_ctx *g_ctx = nullptr;
@@ -40,39 +51,44 @@ struct Scratch {
 	std::vector<float> last_soft;
 	trxhip_burst_result last_res;
 
+	static void drop(void *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
+	template <class T> static void drop(T *&p) { void *q = p; drop(q); p = nullptr; }
 	bool ensure(size_t n, size_t iq_b, size_t stride)
 	{
 		if (!stream && hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess)
 			return false;
 		if (iq_b > iq_bytes) {
-			if (d_iq) hipFree(d_iq);
-			if (hipMalloc(&d_iq, iq_b) != hipSuccess) { d_iq = nullptr; iq_bytes = 0; return false; }
+			drop(d_iq);
+			iq_bytes = 0;
+			if (hipMalloc(&d_iq, iq_b) != hipSuccess) { d_iq = nullptr; return false; }
 			iq_bytes = iq_b;
 		}
 		if (n > cap || stride > soft_stride) {
-			if (d_prm) hipFree(d_prm);
-			if (d_res) hipFree(d_res);
-			if (d_soft) hipFree(d_soft);
-			if (d_ebp) hipFree(d_ebp);
-			size_t nn = n > cap ? n : cap, ss = stride > soft_stride ? stride : soft_stride;
+			const size_t nn = n > cap ? n : cap, ss = stride > soft_stride ? stride : soft_stride;
+			/* nothing stale survives a failed re-allocation: pointers nulled, capacities zeroed */
+			drop(d_prm); drop(d_res); drop(d_soft); drop(d_ebp);
+			cap = 0;
+			soft_stride = 0;
 			if (hipMalloc((void **)&d_prm, nn * sizeof(trxhip_burst_params)) != hipSuccess ||
 			    hipMalloc((void **)&d_res, nn * sizeof(trxhip_burst_result)) != hipSuccess ||
 			    hipMalloc((void **)&d_soft, nn * ss * sizeof(float)) != hipSuccess ||
-			    hipMalloc((void **)&d_ebp, nn * 4 * sizeof(float)) != hipSuccess)
+			    hipMalloc((void **)&d_ebp, nn * 4 * sizeof(float)) != hipSuccess) {
+				drop(d_prm); drop(d_res); drop(d_soft); drop(d_ebp);
 				return false;
+			}
 			cap = nn;
 			soft_stride = ss;
 		}
 		return true;
 	}
+	/* host-fed pipeline of the batched calls: created on first use, re-created when the geometry changes */
+	trxhip_hostpipe *pipe = nullptr;
+	trxhip_hostpipe_cfg pipe_cfg;
 	~Scratch()
 	{
-		if (d_iq) hipFree(d_iq);
-		if (d_prm) hipFree(d_prm);
-		if (d_res) hipFree(d_res);
-		if (d_soft) hipFree(d_soft);
-		if (d_ebp) hipFree(d_ebp);
-		if (stream) hipStreamDestroy(stream);
+		if (pipe) trxhip_hostpipe_destroy(pipe);
+		drop(d_iq); drop(d_prm); drop(d_res); drop(d_soft); drop(d_ebp);
+		if (stream) (void)hipStreamDestroy(stream);
 	}
 };
 thread_local Scratch tls;
@@ -85,8 +101,29 @@ size_t soft_cap(int sps, size_t burst_size) { size_t n = soft_len(sps, burst_siz
 
 }  // namespace
 
-/* the context for the other host classes of the shim (MultiArfcnRx) */
-trxhip_ctx *trx_shim_context(void) { return g_ctx; }
+/* the context for the other host classes of the shim (MultiArfcnRx, BurstGatherer) */
+extern "C" trxhip_ctx *trxsigproc_context(void) { return g_ctx; }
+
+/* Which headers this library was compiled against, and the object layout it therefore assumes: a caller (or
+ * tests/test_shim_abi.py) compares these with its own sizeof/offsetof before handing objects across. */
+extern "C" const char *trxsigproc_abi(void) { return TRX_SHIM_ABI; }
+extern "C" void trxsigproc_abi_layout(size_t out[8])
+{
+	out[0] = sizeof(signalVector);
+	out[1] = sizeof(SoftVector);
+	out[2] = sizeof(complex);
+	out[3] = sizeof(struct estim_burst_params);
+	out[4] = offsetof(struct estim_burst_params, toa);
+	out[5] = offsetof(struct estim_burst_params, tsc);
+	out[6] = offsetof(struct estim_burst_params, ci);
+	out[7] = sizeof(Vector<float>);
+}
+
+static void gpu_error(const char *where)
+{
+	/* the reference would LOG(ERR); the shim has no libosmocore logging context, stderr it is */
+	fprintf(stderr, "trxsigproc: %s: GPU error (%s)\n", where, hipGetErrorString(hipGetLastError()));
+}
 
 bool sigProcLibSetup()
 {
@@ -113,13 +150,17 @@ void sigProcLibDestroy(void)
 void vectorSlicer(float *dest, const float *src, size_t len)
 {
 	Scratch &t = tls;
-	if (!g_ctx || !len || !t.ensure(1, 2 * len * sizeof(float), 1))
+	if (!len)
 		return;
+	if (!g_ctx || !t.ensure(1, 2 * len * sizeof(float), 1)) {
+		gpu_error("vectorSlicer");
+		return;
+	}
 	float *d_src = static_cast<float *>(t.d_iq), *d_dst = d_src + len;
-	if (h2d(d_src, src, len * sizeof(float), t.stream) &&
-	    trxhip_vector_slicer(g_ctx, d_dst, d_src, len, t.stream) == TRXHIP_OK &&
-	    d2h(dest, d_dst, len * sizeof(float), t.stream))
-		hipStreamSynchronize(t.stream);
+	if (!(h2d(d_src, src, len * sizeof(float), t.stream) &&
+	      trxhip_vector_slicer(g_ctx, d_dst, d_src, len, t.stream) == TRXHIP_OK &&
+	      d2h(dest, d_dst, len * sizeof(float), t.stream) && hipStreamSynchronize(t.stream) == hipSuccess))
+		gpu_error("vectorSlicer");
 }
 
 float energyDetect(const signalVector &rxBurst, unsigned windowLength)
@@ -202,7 +243,7 @@ signalVector *delayVector(const signalVector *in, signalVector *out, float delay
 	}
 	if (!out)
 		return res;
-	*out = *res;                                               /* out->clone(*shift), :1094 */
+	out->clone(*res);                                          /* :1094 */
 	delete res;
 	return out;
 }
@@ -210,12 +251,24 @@ signalVector *delayVector(const signalVector *in, signalVector *out, float delay
 void scaleVector(signalVector &x, complex scale)
 {
 	Scratch &t = tls;
-	if (!g_ctx || !x.size() || !t.ensure(1, x.bytes(), 1))
+	if (!x.size())
 		return;
-	if (h2d(t.d_iq, x.begin(), x.bytes(), t.stream) &&
-	    trxhip_scale_vector_cf32(g_ctx, static_cast<float *>(t.d_iq), x.size(), scale.real(), scale.imag(), t.stream) == TRXHIP_OK &&
-	    d2h(x.begin(), t.d_iq, x.bytes(), t.stream))
-		hipStreamSynchronize(t.stream);
+	if (!g_ctx || !t.ensure(1, x.bytes(), 1)) {
+		gpu_error("scaleVector");
+		return;
+	}
+	const complex *src = x.begin();
+	std::vector<complex> re;
+	if (x.isReal()) {                                          /* *xP = xP->real() * scale (:1207-1210): imaginary parts ignored */
+		re.assign(x.begin(), x.end());
+		for (size_t k = 0; k < re.size(); k++)
+			re[k] = complex(re[k].real(), 0.0f);
+		src = re.data();
+	}
+	if (!(h2d(t.d_iq, src, x.bytes(), t.stream) &&
+	      trxhip_scale_vector_cf32(g_ctx, static_cast<float *>(t.d_iq), x.size(), scale.real(), scale.imag(), t.stream) == TRXHIP_OK &&
+	      d2h(x.begin(), t.d_iq, x.bytes(), t.stream) && hipStreamSynchronize(t.stream) == hipSuccess))
+		gpu_error("scaleVector");
 }
 
 SoftVector *demodAnyBurst_va(const signalVector &burst, CorrType type, int sps, int rach_max_toa, int tsc)
@@ -299,6 +352,34 @@ SoftVector *demodAnyBurst(const signalVector &burst, CorrType type, int sps, str
 	return bits;
 }
 
+void trxsigproc_fill_indication(BurstIndication &bi, const BurstRequest &rq, const trxhip_burst_result &r, const float *soft,
+				size_t stride, double rssi_offset)
+{
+	bi.nbits = 0;
+	bi.fn = rq.fn;
+	bi.tn = rq.tn;
+	bi.rssi = 0.0;
+	bi.toa = 0.0;
+	bi.idle = r.idle != 0;
+	bi.modulation = 0;
+	bi.tss = 0;
+	bi.tsc = 0;
+	bi.ci = 0.0f;
+	bi.rc = r.rc;
+	bi.energy = r.energy;
+	if (rq.type != OFF)
+		bi.rssi = (double)r.rssi + rssi_offset;                /* Transceiver.cpp:751 */
+	if (bi.idle)
+		return;
+	bi.toa = r.toa;
+	bi.tsc = r.tsc;
+	bi.ci = r.ci;
+	bi.nbits = 4u * r.nbits_div4;
+	bi.modulation = bi.nbits == EDGE_BURST_NBITS ? 1 : 0;      /* :794-800 */
+	if (soft)
+		memcpy(bi.rx_burst, soft, (bi.nbits < stride ? bi.nbits : stride) * sizeof(float));
+}
+
 int pullRadioVectorBatch(const BurstRequest *req, size_t n, int sps, size_t burst_len, double rxFullScale,
 			 double rssi_offset, BurstIndication *out, bool egprs)
 {
@@ -308,46 +389,60 @@ int pullRadioVectorBatch(const BurstRequest *req, size_t n, int sps, size_t burs
 		return 0;
 	if (!g_ctx || !req || !out)
 		return -EIO;
+	/* pinned staging slots, one stream each: while chunk k's kernels run, chunk k+1 uploads and chunk k-1 downloads */
+	trxhip_hostpipe_cfg c;
+	memset(&c, 0, sizeof(c));
+	c.max_bursts = 2048;
+	c.depth = 3;
+	c.burst_len = (int32_t)burst_len;
+	c.sps = sps;
+	c.soft_stride = (int32_t)stride;
+	c.flags = TRXHIP_FLAG_SLICE;                               /* vectorSlicer applied; fused demodulator */
+	c.threshold = BURST_THRESH;
+	c.full_scale = (float)rxFullScale;
+	if (!t.pipe || memcmp(&c, &t.pipe_cfg, sizeof(c)) != 0) {
+		if (t.pipe) trxhip_hostpipe_destroy(t.pipe);
+		t.pipe = nullptr;
+		if (trxhip_hostpipe_create(g_ctx, &c, &t.pipe) != TRXHIP_OK)
+			return -EIO;
+		t.pipe_cfg = c;
+	}
 	const size_t burst_bytes = burst_len * 2 * sizeof(int16_t);
-	if (!t.ensure(n, n * burst_bytes, stride))
-		return -EIO;
-
-	std::vector<int16_t> iq(n * burst_len * 2);
-	std::vector<trxhip_burst_params> prm(n);
-	for (size_t i = 0; i < n; i++) {
-		memcpy(&iq[i * burst_len * 2], req[i].iq, burst_bytes);
-		memset(&prm[i], 0, sizeof(prm[i]));
-		prm[i].type = (uint8_t)req[i].type;
-		prm[i].tsc = (uint8_t)req[i].tsc;
-		prm[i].max_toa = (uint16_t)req[i].max_toa;
-	}
-	std::vector<trxhip_burst_result> res(n);
-	std::vector<float> soft(n * stride);
-	if (!h2d(t.d_iq, iq.data(), n * burst_bytes, t.stream) || !h2d(t.d_prm, prm.data(), n * sizeof(prm[0]), t.stream))
-		return -EIO;
-	int rc = trxhip_detect_demod_batch(g_ctx, static_cast<const int16_t *>(t.d_iq), t.d_prm, t.d_res, t.d_soft, n,
-					   (int)burst_len, sps, BURST_THRESH, (float)rxFullScale, (int)stride,
-					   TRXHIP_FLAG_SLICE /* vectorSlicer applied; fused demodulator */, t.stream);
-	if (rc != TRXHIP_OK || !d2h(res.data(), t.d_res, n * sizeof(res[0]), t.stream) ||
-	    !d2h(soft.data(), t.d_soft, soft.size() * sizeof(float), t.stream) || hipStreamSynchronize(t.stream) != hipSuccess)
-		return -EIO;
-
-	for (size_t i = 0; i < n; i++) {
-		BurstIndication &bi = out[i];
-		memset(&bi, 0, sizeof(bi));
-		bi.rc = res[i].rc;
-		bi.idle = res[i].idle != 0;
-		bi.energy = res[i].energy;
-		bi.rssi = req[i].type == OFF ? 0.0 : (double)res[i].rssi + rssi_offset;     /* Transceiver.cpp:751 */
-		if (!bi.idle) {
-			bi.toa = res[i].toa;
-			bi.tsc = res[i].tsc;
-			bi.ci = res[i].ci;
-			bi.nbits = 4u * res[i].nbits_div4;
-			memcpy(bi.rx_burst, &soft[i * stride], (bi.nbits < stride ? bi.nbits : stride) * sizeof(float));
+	const size_t n_chunks = (n + c.max_bursts - 1) / c.max_bursts;
+	int err = 0;
+	auto collect = [&](size_t k) {
+		const int s = (int)(k % c.depth);
+		const size_t off = k * c.max_bursts, m = (off + c.max_bursts <= n) ? c.max_bursts : n - off;
+		trxhip_hostpipe_slot h;
+		if (trxhip_hostpipe_wait(t.pipe, s) != TRXHIP_OK || trxhip_hostpipe_slot_buffers(t.pipe, s, &h) != TRXHIP_OK) {
+			err = -EIO;
+			return;
 		}
+		for (size_t i = 0; i < m; i++)
+			trxsigproc_fill_indication(out[off + i], req[off + i], h.results[i], h.soft + i * stride, stride, rssi_offset);
+	};
+	for (size_t k = 0; k < n_chunks; k++) {
+		if (k >= (size_t)c.depth)
+			collect(k - c.depth);
+		const int s = (int)(k % c.depth);
+		const size_t off = k * c.max_bursts, m = (off + c.max_bursts <= n) ? c.max_bursts : n - off;
+		trxhip_hostpipe_slot h;
+		if (trxhip_hostpipe_slot_buffers(t.pipe, s, &h) != TRXHIP_OK) { err = -EIO; break; }
+		for (size_t i = 0; i < m; i++) {                       /* gather straight into the pinned slot: the only host copy */
+			memcpy(h.iq + i * burst_len * 2, req[off + i].iq, burst_bytes);
+			memset(&h.params[i], 0, sizeof(h.params[i]));
+			h.params[i].type = (uint8_t)req[off + i].type;
+			h.params[i].tsc = (uint8_t)req[off + i].tsc;
+			h.params[i].max_toa = (uint16_t)req[off + i].max_toa;
+		}
+		if (trxhip_hostpipe_submit(t.pipe, s, m) != TRXHIP_OK)
+			err = -EIO;
 	}
-	return 0;
+	for (size_t k = (n_chunks > (size_t)c.depth ? n_chunks - c.depth : 0); k < n_chunks; k++)
+		collect(k);
+	for (int s = 0; s < c.depth; s++)
+		(void)trxhip_hostpipe_wait(t.pipe, s);
+	return err;
 }
 
 int pullRadioVectorBatchVA(const BurstRequest *req, size_t n, int sps, size_t burst_len, double rxFullScale,
@@ -400,6 +495,8 @@ int pullRadioVectorBatchVA(const BurstRequest *req, size_t n, int sps, size_t bu
 	for (size_t i = 0; i < n; i++) {
 		BurstIndication &bi = out[i];
 		memset(&bi, 0, sizeof(bi));
+		bi.fn = req[i].fn;
+		bi.tn = req[i].tn;
 		bi.rc = res[i].rc;
 		bi.idle = res[i].idle != 0;
 		bi.energy = energy[i];
@@ -417,3 +514,5 @@ int pullRadioVectorBatchVA(const BurstRequest *req, size_t n, int sps, size_t bu
 	}
 	return 0;
 }
+
+TRX_SHIM_NS_END

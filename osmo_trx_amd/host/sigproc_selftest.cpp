@@ -13,8 +13,25 @@
 #include <memory>
 #include <vector>
 
-#include "sigProcLib.h"
+#include <atomic>
+#include <chrono>
+#include <thread>
+
+#include "trxBatch.h"
 #include "MultiArfcnRx.h"
+
+// "signalvector is owning despite claiming not to" (Transceiver.cpp:648-654): a vector built over memory it must not
+// delete[] gets a no-op deallocator, exactly as pullRadioVector() does for its shift buffer (:680)
+static void dummy_free(void *) {}
+static void *dummy_alloc(size_t) { return 0; }
+
+// the layout every reference-compiled caller was built with (CommonLibs/Vector.h:72-76: three pointers + two function
+// pointers; signalVector.h:48-51: two bools + enum)
+static_assert(sizeof(signalVector) == 48, "signalVector layout");
+static_assert(sizeof(SoftVector) == 40 && sizeof(complex) == 8, "SoftVector / complex layout");
+
+extern "C" const char *trxsigproc_abi(void);
+extern "C" void trxsigproc_abi_layout(size_t out[8]);
 
 static std::vector<char> slurp(const char *path)
 {
@@ -30,15 +47,49 @@ static std::vector<char> slurp(const char *path)
 	return v;
 }
 
+// abi: what this executable's compiler sees vs what the library was compiled with (no GPU needed)
+static int abi_report()
+{
+	size_t lib[8];
+	trxsigproc_abi_layout(lib);
+	const size_t mine[8] = { sizeof(signalVector), sizeof(SoftVector), sizeof(complex), sizeof(struct estim_burst_params),
+				 offsetof(struct estim_burst_params, toa), offsetof(struct estim_burst_params, tsc),
+				 offsetof(struct estim_burst_params, ci), sizeof(Vector<float>) };
+	int bad = 0;
+	printf("abi %s\n", trxsigproc_abi());
+	static const char *const name[8] = { "sizeof_signalVector", "sizeof_SoftVector", "sizeof_complex", "sizeof_ebp",
+					     "offsetof_ebp_toa", "offsetof_ebp_tsc", "offsetof_ebp_ci", "sizeof_Vector_float" };
+	for (int k = 0; k < 8; k++) {
+		printf("%s %zu %zu\n", name[k], mine[k], lib[k]);
+		bad |= mine[k] != lib[k];
+	}
+	/* the 5-argument constructor and head-room form pullRadioVector() and radioVector use */
+	static complex buf[625];
+	signalVector alias(buf, 0, 625, dummy_alloc, dummy_free);
+	signalVector headroom(625, 41);
+	printf("alias_size %zu alias_start %zu headroom_size %zu headroom_start %zu\n", alias.size(), alias.getStart(),
+	       headroom.size(), headroom.getStart());
+	struct estim_burst_params ebp;
+	memset(&ebp, 0, sizeof(ebp));
+	/* without a GPU (or before sigProcLibSetup) the calls fail the reference's way instead of touching the objects */
+	printf("detect_without_setup %d\n", detectAnyBurst(alias, 0, BURST_THRESH, 4, TSC, 3, &ebp));
+	SoftVector *sv = demodAnyBurst(alias, TSC, 4, &ebp);
+	printf("demod_without_setup %s\n", sv ? "non-null" : "null");
+	delete sv;
+	return bad ? 1 : 0;
+}
+
 int main(int argc, char **argv)
 {
 	if (argc < 2) return 2;
+	if (!strcmp(argv[1], "abi"))
+		return abi_report();
 	if (!sigProcLibSetup()) { fprintf(stderr, "no GPU\n"); return 3; }
 
 	if (!strcmp(argv[1], "capture") && argc == 4) {
 		std::vector<char> raw = slurp(argv[2]);
 		size_t n = raw.size() / sizeof(complex);
-		signalVector sv(reinterpret_cast<complex *>(raw.data()), 0, n);
+		signalVector sv(reinterpret_cast<complex *>(raw.data()), 0, n, dummy_alloc, dummy_free);
 		struct estim_burst_params ebp;
 		int rc = detectAnyBurst(sv, 7, BURST_THRESH, 4, TSC, 40, &ebp);
 		FILE *o = fopen(argv[3], "w");
@@ -68,7 +119,7 @@ int main(int argc, char **argv)
 		/* delayVector(burst, NULL, d) then scaleVector(*delay, s): the pair demodCommon() and ms_rx_lower.cpp:243-245 use */
 		std::vector<char> raw = slurp(argv[2]);
 		size_t n = raw.size() / sizeof(complex);
-		signalVector sv(reinterpret_cast<complex *>(raw.data()), 0, n);
+		signalVector sv(reinterpret_cast<complex *>(raw.data()), 0, n, dummy_alloc, dummy_free);
 		std::unique_ptr<signalVector> d(delayVector(&sv, NULL, (float)atof(argv[3])));
 		if (!d) return 4;
 		scaleVector(*d, complex((float)atof(argv[4]), (float)atof(argv[5])));
@@ -83,7 +134,7 @@ int main(int argc, char **argv)
 		/* Transceiver.cpp:782-784: scaleVector(*burst, 1/16383) then demodAnyBurst_va(*burst, TSC, 4, max_toa, tsc) */
 		std::vector<char> raw = slurp(argv[2]);
 		size_t n = raw.size() / sizeof(complex);
-		signalVector sv(reinterpret_cast<complex *>(raw.data()), 0, n);
+		signalVector sv(reinterpret_cast<complex *>(raw.data()), 0, n, dummy_alloc, dummy_free);
 		scaleVector(sv, complex((float)(1. / (float)((1 << 14) - 1)), 0));
 		std::unique_ptr<SoftVector> bits(demodAnyBurst_va(sv, TSC, 4, 3, atoi(argv[3])));
 		if (!bits) return 4;
@@ -98,7 +149,7 @@ int main(int argc, char **argv)
 		/* ms_rx_lower.cpp:213-250: detectSCHBurst() then demodAnyBurst(burst, SCH, 4, &ebp) on the first 625 samples */
 		std::vector<char> raw = slurp(argv[2]);
 		size_t n = raw.size() / sizeof(complex);
-		signalVector sv(reinterpret_cast<complex *>(raw.data()), 0, n);
+		signalVector sv(reinterpret_cast<complex *>(raw.data()), 0, n, dummy_alloc, dummy_free);
 		const int st = atoi(argv[3]);
 		struct estim_burst_params ebp;
 		memset(&ebp, 0, sizeof(ebp));
@@ -107,7 +158,7 @@ int main(int argc, char **argv)
 		FILE *o = fopen(argv[4], "w");
 		fprintf(o, "rc %d\ntoa %.9g\namp %.9g %.9g\nci %.9g\n", rc, ebp.toa, ebp.amp.real(), ebp.amp.imag(), ebp.ci);
 		if (rc > 0 && st == 0) {
-			signalVector one(reinterpret_cast<complex *>(raw.data()), 0, 625);
+			signalVector one(reinterpret_cast<complex *>(raw.data()), 0, 625, dummy_alloc, dummy_free);
 			std::unique_ptr<SoftVector> soft(demodAnyBurst(one, SCH, 4, &ebp));
 			fprintf(o, "bits ");
 			for (size_t i = 0; soft && i < 148; i++) fputc(soft->bit(i) ? '1' : '0', o);
@@ -127,6 +178,7 @@ int main(int argc, char **argv)
 		const int16_t *s = reinterpret_cast<const int16_t *>(iq.data());
 		for (size_t i = 0; i < n; i++) {
 			const unsigned char *p = reinterpret_cast<const unsigned char *>(pr.data()) + 8 * i;
+			req[i].fn = (uint32_t)i; req[i].tn = (uint8_t)(i & 7);
 			req[i].iq = s + i * burst_len * 2;
 			req[i].type = (CorrType)p[0];
 			req[i].tsc = p[1];
@@ -157,6 +209,7 @@ int main(int argc, char **argv)
 		std::vector<BurstRequest> req(n);
 		for (size_t i = 0; i < n; i++) {
 			const unsigned char *p = reinterpret_cast<const unsigned char *>(pr.data()) + 8 * i;
+			req[i].fn = (uint32_t)i; req[i].tn = (uint8_t)(i & 7);
 			req[i].iq = reinterpret_cast<const int16_t *>(iq.data()) + i * 625 * 2;
 			req[i].type = (CorrType)p[0];
 			req[i].tsc = p[1];
@@ -171,6 +224,112 @@ int main(int argc, char **argv)
 			fwrite(ind[i].rx_burst, sizeof(float), 148, fs);
 		}
 		fclose(fr); fclose(fs);
+		sigProcLibDestroy();
+		return 0;
+	}
+
+	// gather <iq.s16> <params.bin> <n> <chans> <max_batch> <timeout_us> <trxd_version|-1> <out.bin> [repeat]
+	// `chans` producer threads push their share of the n bursts (burst i belongs to channel i % chans, fn = i / chans),
+	// `chans` consumer threads pull them back (pullRadioVector's role).  out.bin: per burst, in input order,
+	// {int32 code, int32 rc, float toa, float ci, float rssi, uint32 fn, uint32 tn|idle<<8|nbits<<16, uint32 pkt_len}
+	// followed by 456 bytes: the TRXD datagram (trxd_version >= 0) or the first 114 soft floats (-1).
+	if (!strcmp(argv[1], "gather") && (argc == 10 || argc == 11)) {
+		std::vector<char> iq = slurp(argv[2]), pr = slurp(argv[3]);
+		const size_t n = atol(argv[4]), chans = atol(argv[5]);
+		const int repeat = argc == 11 ? atoi(argv[10]) : 1;
+		BurstGathererConfig cfg;
+		memset(&cfg, 0, sizeof(cfg));
+		cfg.chans = chans;
+		cfg.max_batch = atol(argv[6]);
+		cfg.timeout_us = atoi(argv[7]);
+		cfg.fifo_depth = 32;
+		cfg.sps = 4;
+		cfg.burst_len = 625;
+		cfg.rxFullScale = 32767.0;
+		cfg.rssi_offset = 0.0;
+		cfg.egprs = false;
+		cfg.trxd_version = atoi(argv[8]);
+		cfg.depth = 4;
+		BurstGatherer g(cfg);
+		if (!g.start()) { fprintf(stderr, "BurstGatherer::start failed\n"); return 5; }
+		struct Rec { int32_t code, rc; float toa, ci, rssi; uint32_t fn, misc, pkt_len; uint8_t body[456]; };
+		std::vector<Rec> rec(n);
+		memset(rec.data(), 0, n * sizeof(Rec));
+		const int16_t *s16 = reinterpret_cast<const int16_t *>(iq.data());
+		std::atomic<uint64_t> retries{0};
+		const auto t0 = std::chrono::steady_clock::now();
+		std::vector<std::thread> th;
+		for (size_t c = 0; c < chans; c++) {
+			th.emplace_back([&, c] {                         /* RxLower's role for channel c (radioInterface.cpp:272-291) */
+				for (int rep = 0; rep < repeat; rep++)
+					for (size_t i = c; i < n; i += chans) {
+						const unsigned char *p = reinterpret_cast<const unsigned char *>(pr.data()) + 8 * i;
+						BurstRequest rq;
+						rq.iq = s16 + i * 625 * 2;
+						rq.type = (CorrType)p[0];
+						rq.tsc = p[1];
+						rq.max_toa = p[2] | (p[3] << 8);
+						rq.fn = (uint32_t)(i / chans);
+						rq.tn = (uint8_t)(i & 7);
+						while (!g.push(c, rq)) {             /* a real radio would drop; the test wants every burst back */
+							retries++;
+							std::this_thread::yield();
+						}
+					}
+			});
+			th.emplace_back([&, c] {                         /* RxUpper<c>'s role (Transceiver.cpp:1229-1253) */
+				BurstIndication bi;
+				uint8_t pkt[TRXD_MAX_PKT_LEN + 1];
+				for (int rep = 0; rep < repeat; rep++)
+					for (size_t i = c; i < n; i += chans) {
+						size_t len = 0;
+						Rec &r = rec[i];
+						r.code = g.pull(c, &bi, cfg.trxd_version >= 0 ? pkt : NULL, &len);
+						r.rc = bi.rc; r.toa = (float)bi.toa; r.ci = bi.ci; r.rssi = (float)bi.rssi; r.fn = bi.fn;
+						r.misc = bi.tn | ((uint32_t)bi.idle << 8) | (bi.nbits << 16);
+						r.pkt_len = (uint32_t)len;
+						if (cfg.trxd_version >= 0) memcpy(r.body, pkt, len);
+						else memcpy(r.body, bi.rx_burst, 456);
+					}
+			});
+		}
+		for (auto &t : th) t.join();
+		const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+		printf("gather bursts %zu seconds %.6f mbursts_per_s %.3f batches %llu push_retries %llu dropped %llu\n", n * repeat, dt,
+		       n * repeat / dt * 1e-6, (unsigned long long)g.batches(), (unsigned long long)retries.load(),
+		       (unsigned long long)g.dropped());
+		g.stop();
+		FILE *o = fopen(argv[9], "wb");
+		fwrite(rec.data(), sizeof(Rec), n, o);
+		fclose(o);
+		sigProcLibDestroy();
+		return 0;
+	}
+
+	// trxdhost <ind.bin> <n> <version> <out.bin>: the host packer trxdPackBurstInd() over n indications given as
+	// {float rx_burst[444]; uint32 nbits, fn, tn, idle, modulation, tss, tsc; float ci; double rssi, toa}; out: n x (u16 len + 456 bytes)
+	if (!strcmp(argv[1], "trxdhost") && argc == 6) {
+		std::vector<char> raw = slurp(argv[2]);
+		const size_t n = atol(argv[3]);
+		const unsigned ver = atoi(argv[4]);
+		struct In { float rx[444]; uint32_t nbits, fn, tn, idle, modulation, tss, tsc; float ci; double rssi, toa; };
+		const In *in = reinterpret_cast<const In *>(raw.data());
+		FILE *o = fopen(argv[5], "wb");
+		for (size_t i = 0; i < n; i++) {
+			BurstIndication bi;
+			memset(&bi, 0, sizeof(bi));
+			memcpy(bi.rx_burst, in[i].rx, sizeof(bi.rx_burst));
+			bi.nbits = in[i].nbits; bi.fn = in[i].fn; bi.tn = (uint8_t)in[i].tn; bi.idle = in[i].idle != 0;
+			bi.modulation = (uint8_t)in[i].modulation; bi.tss = (uint8_t)in[i].tss; bi.tsc = (uint8_t)in[i].tsc;
+			bi.ci = in[i].ci; bi.rssi = in[i].rssi; bi.toa = in[i].toa;
+			uint8_t buf[460];
+			memset(buf, 0, sizeof(buf));
+			const int len = trxdPackBurstInd(buf, &bi, ver);
+			const uint16_t l16 = (uint16_t)(len < 0 ? 0xffff : len);
+			fwrite(&l16, 2, 1, o);
+			fwrite(buf, 1, 456, o);
+		}
+		fclose(o);
 		sigProcLibDestroy();
 		return 0;
 	}

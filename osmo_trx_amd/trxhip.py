@@ -19,7 +19,8 @@ RESULT_DTYPE = np.dtype([
     ("rc", "<i4"), ("toa", "<f4"), ("amp_re", "<f4"), ("amp_im", "<f4"), ("ci", "<f4"),
     ("energy", "<f4"), ("rssi", "<f4"), ("tsc", "u1"), ("clip", "u1"), ("idle", "u1"), ("nbits_div4", "u1"),
 ])
-assert PARAMS_DTYPE.itemsize == 8 and RESULT_DTYPE.itemsize == 32
+TRXD_META_DTYPE = np.dtype([("fn", "<u4"), ("tn", "u1"), ("version", "u1"), ("tss", "u1"), ("reserved", "u1")])
+assert PARAMS_DTYPE.itemsize == 8 and RESULT_DTYPE.itemsize == 32 and TRXD_META_DTYPE.itemsize == 8
 
 TRXD_RECORD_BYTES = 156
 FLAG_SLICE = 1          # TRXHIP_FLAG_SLICE
@@ -62,9 +63,19 @@ SYMBOLS = {
     "trxhip_detect_sch_batch_cf32": (_I, [_VP, _VP, _VP, _SZ, _SZ, _I, _I, C.c_float, _VP]),
     "trxhip_vector_slicer": (_I, [_VP, _VP, _VP, _SZ, _VP]),
     "trxhip_pack_trxd_batch": (_I, [_VP, _VP, _VP, _I, _VP, _SZ, _F, _VP]),
+    "trxhip_pack_trxd_wire_batch": (_I, [_VP, _VP, _VP, _VP, _I, _VP, _VP, _I, _VP, _SZ, _F, _VP]),
+    "trxhip_hostpipe_create": (_I, [_VP, _VP, C.POINTER(_VP)]),
+    "trxhip_hostpipe_destroy": (None, [_VP]),
+    "trxhip_hostpipe_slot_buffers": (_I, [_VP, _I, _VP]),
+    "trxhip_hostpipe_submit": (_I, [_VP, _I, _SZ]),
+    "trxhip_hostpipe_wait": (_I, [_VP, _I]),
+    "trxhip_hostpipe_query": (_I, [_VP, _I]),
+    "trxhip_hostpipe_run": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _SZ]),
     "trxhip_convolve_real_batch": (_I, [_VP, _VP, _I, _VP, _I, _VP, _I, _I, _I, _SZ, _VP]),
     "trxhip_convolve_complex_batch": (_I, [_VP, _VP, _I, _VP, _I, _VP, _I, _I, _I, _SZ, _VP]),
     "trxhip_convert_short_float": (_I, [_VP, _VP, _VP, _SZ, _VP]),
+    "trxhip_convert_float_short": (_I, [_VP, _VP, _VP, _F, _SZ, _VP]),
+    "trxhip_dft_batch": (_I, [_VP, _VP, _VP, _I, _SZ, _SZ, _SZ, _I, _VP]),
     "trxhip_channelize_batch": (_I, [_VP, _VP, _VP, _SZ, _I, _I, _I, _VP]),
     "trxhip_resample_batch": (_I, [_VP, _VP, _VP, _SZ, _I, _I, _SZ, _SZ, _SZ, _VP]),
     "trxhip_rx_frontend_create": (_I, [_VP, _I, _I, _I, C.POINTER(_VP)]),
@@ -270,6 +281,19 @@ class TrxHip:
         _check(rc, "trxhip_pack_trxd_batch")
         return pkt
 
+    def pack_trxd_wire(self, results, params, soft, meta, pkt_stride=160, rssi_offset=0.0, stream=None):
+        """TRXD v0/v1 datagrams (proto_trxd.c:68-117).  results uint8[n, 32], params uint8[n, 8], soft float32[n, stride]
+        (sliced), meta uint8[n, 8] (TRXD_META_DTYPE).  Returns (pkt uint8[n, pkt_stride], pkt_len int16[n])."""
+        torch = self.torch
+        n = results.shape[0]
+        pkt = torch.empty((n, pkt_stride), dtype=torch.uint8, device=results.device)
+        plen = torch.empty(n, dtype=torch.int16, device=results.device)
+        rc = self.L.trxhip_pack_trxd_wire_batch(self.h, self._dev(results), self._dev(params), self._dev(soft, torch.float32),
+                                                soft.shape[1], self._dev(meta), self._dev(pkt), pkt_stride, self._dev(plen), n,
+                                                rssi_offset, self._stream(stream))
+        _check(rc, "trxhip_pack_trxd_wire_batch")
+        return pkt, plen
+
     # ---- arch kernels ---------------------------------------------------------------------------
     def convolve(self, x, h, start, length, complex_taps, stream=None):
         """x: complex64[n_vec, x_len], h: complex64[h_len] -> complex64[n_vec, length]"""
@@ -348,6 +372,99 @@ class RxFrontEnd:
     def close(self):
         if getattr(self, "h", None):
             self.trx.L.trxhip_rx_frontend_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _HostPipeCfg(C.Structure):
+    _fields_ = [("max_bursts", C.c_uint32), ("depth", C.c_int32), ("burst_len", C.c_int32), ("sps", C.c_int32),
+                ("soft_stride", C.c_int32), ("pkt_stride", C.c_int32), ("flags", C.c_int32), ("threshold", C.c_float),
+                ("full_scale", C.c_float), ("rssi_offset", C.c_float)]
+
+
+class _HostPipeSlot(C.Structure):
+    _fields_ = [("iq", _VP), ("params", _VP), ("meta", _VP), ("results", _VP), ("soft", _VP), ("pkt", _VP), ("pkt_len", _VP)]
+
+
+class HostPipe:
+    """Host-fed, stream-pipelined hot path (trxhip_hostpipe_*): pinned staging slots, one stream each.
+
+    slot(i) gives numpy views of slot i's pinned buffers; fill iq/params(/meta), submit(i, n), wait(i), read
+    results/soft/pkt.  run() is the convenience form for ordinary numpy arrays."""
+
+    def __init__(self, trx, max_bursts, depth=3, burst_len=625, sps=4, soft_stride=148, pkt_stride=0, flags=FLAG_SLICE,
+                 threshold=4.0, full_scale=32767.0, rssi_offset=0.0):
+        self.trx = trx
+        self.cfg = _HostPipeCfg(max_bursts, depth, burst_len, sps, soft_stride, pkt_stride, flags, threshold, full_scale,
+                                rssi_offset)
+        h = _VP()
+        _check(trx.L.trxhip_hostpipe_create(trx.h, C.byref(self.cfg), C.byref(h)), "trxhip_hostpipe_create")
+        self.h = h
+        self.depth = depth
+        self._slots = [self._views(i) for i in range(depth)]
+
+    def _views(self, i):
+        s = _HostPipeSlot()
+        _check(self.trx.L.trxhip_hostpipe_slot_buffers(self.h, i, C.byref(s)), "trxhip_hostpipe_slot_buffers")
+        c = self.cfg
+        n = c.max_bursts
+
+        def view(ptr, nbytes, dtype, shape):
+            if not ptr:
+                return None
+            buf = (C.c_ubyte * nbytes).from_address(ptr)
+            return np.frombuffer(buf, dtype=dtype).reshape(shape)
+        return {
+            "iq": view(s.iq, n * c.burst_len * 4, np.int16, (n, c.burst_len, 2)),
+            "params": view(s.params, n * 8, PARAMS_DTYPE, (n,)),
+            "meta": view(s.meta, n * 8, TRXD_META_DTYPE, (n,)),
+            "results": view(s.results, n * 32, RESULT_DTYPE, (n,)),
+            "soft": view(s.soft, n * c.soft_stride * 4, np.float32, (n, c.soft_stride)) if c.soft_stride else None,
+            "pkt": view(s.pkt, n * c.pkt_stride, np.uint8, (n, c.pkt_stride)) if c.pkt_stride else None,
+            "pkt_len": view(s.pkt_len, n * 2, np.uint16, (n,)) if c.pkt_stride else None,
+        }
+
+    def slot(self, i):
+        return self._slots[i]
+
+    def submit(self, i, n):
+        _check(self.trx.L.trxhip_hostpipe_submit(self.h, i, n), "trxhip_hostpipe_submit")
+
+    def wait(self, i):
+        _check(self.trx.L.trxhip_hostpipe_wait(self.h, i), "trxhip_hostpipe_wait")
+
+    def query(self, i):
+        return int(self.trx.L.trxhip_hostpipe_query(self.h, i))
+
+    def run(self, iq, params, meta=None):
+        """iq int16[n, burst_len, 2], params PARAMS_DTYPE[n], meta TRXD_META_DTYPE[n] (numpy, pageable).
+        Returns dict(results, soft, pkt, pkt_len) of numpy arrays."""
+        c = self.cfg
+        n = iq.shape[0]
+        iq = np.ascontiguousarray(iq, dtype=np.int16)
+        params = np.ascontiguousarray(params, dtype=PARAMS_DTYPE)
+        res = np.empty(n, dtype=RESULT_DTYPE)
+        soft = np.empty((n, c.soft_stride), dtype=np.float32) if c.soft_stride else None
+        pkt = np.empty((n, c.pkt_stride), dtype=np.uint8) if c.pkt_stride else None
+        plen = np.empty(n, dtype=np.uint16) if c.pkt_stride else None
+        if meta is not None:
+            meta = np.ascontiguousarray(meta, dtype=TRXD_META_DTYPE)
+
+        def ptr(a):
+            return _VP(a.ctypes.data) if a is not None else _VP(0)
+        _check(self.trx.L.trxhip_hostpipe_run(self.h, ptr(iq), ptr(params), ptr(meta), ptr(res), ptr(soft), ptr(pkt), ptr(plen), n),
+               "trxhip_hostpipe_run")
+        return {"results": res, "soft": soft, "pkt": pkt, "pkt_len": plen}
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._slots = None
+            self.trx.L.trxhip_hostpipe_destroy(self.h)
             self.h = None
 
     def __del__(self):

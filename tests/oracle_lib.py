@@ -101,6 +101,9 @@ def lib():
     L.orc_trxd_ci_cb.restype = C.c_int16
     L.orc_trxd_ci_cb.argtypes = [C.c_float]
     L.orc_trxd_soft_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
+    L.orc_trxd_pack.restype = C.c_int
+    L.orc_trxd_pack.argtypes = [C.c_void_p, C.c_uint, C.c_uint32, C.c_uint8, C.c_double, C.c_double, C.c_int, C.c_int,
+                                C.c_uint8, C.c_uint8, C.c_float, C.c_void_p, C.c_uint]
     L.orc_resampler_new.restype = C.c_void_p
     L.orc_resampler_new.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float]
     L.orc_resampler_free.argtypes = [C.c_void_p]
@@ -223,3 +226,30 @@ def convolve(x, h, start, length, complex_taps):
     f = lib().orc_convolve_complex if complex_taps else lib().orc_convolve_real
     f(_ptr(x), len(x), _ptr(h), len(h), _ptr(y), len(y), start, length)
     return y
+
+
+def trxd_pack_batch(res, params, soft, meta, rssi_offset=0.0, pkt_stride=160):
+    """pullRadioVector()'s bi -> trxd_send_burst_ind_v0/v1 bytes for a batch (Transceiver.cpp:694-814, proto_trxd.c:68-117).
+    res RESULT_DTYPE[n], params PARAMS_DTYPE[n], soft float32[n, stride] (sliced), meta {fn, tn, version, tss}[n].
+    Returns (uint8[n, pkt_stride] zero padded, uint16[n] lengths); OFF slots give length 0 (-ENOENT: nothing sent)."""
+    L = lib()
+    n = len(res)
+    pkt = np.zeros((n, pkt_stride), dtype=np.uint8)
+    plen = np.zeros(n, dtype=np.uint16)
+    buf = np.zeros(11 + 444 + 2, dtype=np.uint8)
+    for i in range(n):
+        if params["type"][i] == OFF:
+            continue
+        idle = bool(res["idle"][i])
+        nbits = 0 if idle else 4 * int(res["nbits_div4"][i])
+        row = np.ascontiguousarray(soft[i, :nbits], dtype=np.float32)
+        rssi = float(np.float64(res["rssi"][i]) + np.float64(np.float32(rssi_offset)))
+        # ret_idle leaves toa / tsc / ci at their initial zeros (Transceiver.cpp:694-704, :808-814)
+        ln = L.orc_trxd_pack(buf.ctypes.data, int(meta["version"][i]), int(meta["fn"][i]), int(meta["tn"][i]), rssi,
+                             0.0 if idle else float(res["toa"][i]), int(idle), int(nbits == 444), int(meta["tss"][i]),
+                             0 if idle else int(res["tsc"][i]), 0.0 if idle else float(res["ci"][i]), row.ctypes.data, nbits)
+        assert ln >= 0
+        ln = min(ln, pkt_stride)
+        pkt[i, :ln] = buf[:ln]
+        plen[i] = ln
+    return pkt, plen

@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported(lib):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/trxhip.h but not exported"
     assert sorted(trxhip.SYMBOLS) == names
-    assert lib.trxhip_abi_version() == 1
+    assert lib.trxhip_abi_version() == 2
 
 
 # device blob layout (osmo_trx_amd/csrc/trx_tables.h)
@@ -124,3 +124,27 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "oracle_lib" not in txt and "trx_oracle" not in txt and "liboracle" not in txt, f
+
+
+def test_trxarch_exports_the_reference_seam():
+    """libtrxarch.so loads without a GPU and exports every symbol include/trxarch.h declares -- the names of
+    arch/common/convolve.h:4-26, convert.h:4-13, fft.h:6-11."""
+    trx_build.build_all()
+    txt = open(os.path.join(ROOT, "include", "trxarch.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    names = sorted(set(re.findall(r"\b([a-z_0-9]+)\s*\(", txt)))
+    assert names == sorted(["convolve_h_alloc", "convolve_real", "convolve_complex", "base_convolve_real",
+                            "base_convolve_complex", "convolve_init", "convert_float_short", "convert_short_float",
+                            "base_convert_float_short", "base_convert_short_float", "convert_init", "init_fft",
+                            "fft_malloc", "fft_free", "free_fft", "cxvec_fft"])
+    L = C.CDLL(os.path.join(ROOT, "osmo_trx_amd", "lib", "libtrxarch.so"))
+    for n in names:
+        assert hasattr(L, n), n
+    import torch
+    if not torch.cuda.is_available():
+        # no CPU fallback: the reference's error value, not a computed result
+        x = np.zeros(64, dtype=np.float32)
+        y = np.full(16, 7.0, dtype=np.float32)
+        L.convolve_real.restype = C.c_int
+        assert L.convolve_real(x.ctypes.data, 32, x.ctypes.data, 4, y.ctypes.data, 8, 3, 8) == -1
+        assert (y == 7.0).all()

@@ -14,14 +14,21 @@ torch = pytest.importorskip("torch")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "osmo_trx_amd", "lib", "sigproc_selftest")
+# the same source compiled against the reference's unmodified headers + its signalVector.cpp, linked to the ABI-true
+# libtrxsigproc.so (built in the container where /root/reference exists; travels prebuilt in oracle/_ref/)
+ABI_EXE = os.path.join(ROOT, "oracle", "_ref", "sigproc_selftest_abi")
 
 
-@pytest.fixture(scope="module")
-def exe():
+@pytest.fixture(scope="module", params=["standalone", "reference_abi"])
+def exe(request):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from osmo_trx_amd import build as trx_build
     trx_build.build_all()
+    if request.param == "reference_abi":
+        if not os.path.exists(ABI_EXE):
+            pytest.skip("oracle/_ref/sigproc_selftest_abi was not built (no /root/reference at build time)")
+        return ABI_EXE
     assert os.path.exists(EXE)
     return EXE
 

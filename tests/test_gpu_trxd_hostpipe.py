@@ -1,0 +1,245 @@
+"""GPU tests of the pieces between the hot kernel and the reference's UDP plumbing:
+  * TRXD v0 / v1 wire-format packer (proto_trxd.c:68-117) -- byte-exact against the oracle's restatement;
+  * host-fed, stream-pipelined path (trxhip_hostpipe_*) -- identical to the device-resident path;
+  * BurstGatherer: N-bursts-or-timeout batching with pullRadioVector()'s per-channel, in-order, blocking semantics."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "osmo_trx_amd", "lib", "sigproc_selftest")
+ABI_EXE = os.path.join(ROOT, "oracle", "_ref", "sigproc_selftest_abi")
+
+
+@pytest.fixture(scope="module")
+def trx():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from osmo_trx_amd import TrxHip
+    return TrxHip(0)
+
+
+def mixed_workload(n, egprs=False, seed=0):
+    """NB / RACH mix with OFF and IDLE slots (and EDGE slots when egprs) -- every branch of the packer."""
+    from osmo_trx_amd import synth, trxhip
+    iq, params = synth.make_mixed_bursts(n, "cpu")
+    params = synth.make_idle_off_mix(params)
+    if egprs:
+        e_iq, e_p, _ = synth.make_edge_bursts(n // 4, "cpu")
+        iq = torch.cat([iq, e_iq])
+        params = np.concatenate([params, e_p])
+    m = len(params)
+    meta = np.zeros(m, dtype=trxhip.TRXD_META_DTYPE)
+    rng = np.random.default_rng(seed)
+    meta["fn"] = rng.integers(0, 2715648, m)
+    meta["tn"] = rng.integers(0, 8, m)
+    meta["version"] = rng.integers(0, 2, m)
+    meta["tss"] = 0
+    return iq, params, meta
+
+
+@pytest.mark.parametrize("egprs", [False, True])
+def test_trxd_wire_packer_byte_exact(trx, egprs):
+    """v0 / v1 x GMSK / 8-PSK / idle / OFF: the device packer's datagrams equal the restated proto_trxd.c byte for byte
+    when both start from the same burst indications."""
+    if egprs and not hasattr(__import__("osmo_trx_amd.synth", fromlist=["x"]), "make_edge_bursts"):
+        pytest.skip("no EDGE generator")
+    n = 1024
+    iq, params, meta = mixed_workload(n, egprs)
+    stride = 444 if egprs else 148
+    pkt_stride = 456 if egprs else 160
+    d_p = trx.params_tensor(params)
+    res, soft = trx.detect_demod(iq.to("cuda:0"), d_p, sps=4, soft_stride=stride, slice_bits=True)
+    d_meta = torch.from_numpy(meta.view(np.uint8).reshape(-1, 8).copy()).to("cuda:0")
+    pkt, plen = trx.pack_trxd_wire(res, d_p, soft, d_meta, pkt_stride=pkt_stride, rssi_offset=3.0)
+    torch.cuda.synchronize()
+    pkt = pkt.cpu().numpy()
+    plen = plen.cpu().numpy().view(np.uint16)
+    r = trx.results_to_numpy(res)
+    o_pkt, o_len = O.trxd_pack_batch(r, params, soft.cpu().numpy(), meta, rssi_offset=3.0, pkt_stride=pkt_stride)
+    assert np.array_equal(plen, o_len)
+    assert np.array_equal(pkt, o_pkt)
+    # every branch was there: v0 data (8 + nbits + 2), v1 data (11 + nbits), v1 idle (11), dropped (0)
+    lens = set(int(x) for x in plen)
+    assert {0, 11, 8 + 148 + 2, 11 + 148} <= lens
+    if egprs:
+        assert {8 + 444 + 2, 11 + 444} <= lens
+    # header spot check on a detected v1 burst, read the way osmo-bts parses it
+    i = int(np.flatnonzero((plen == 159) & (meta["version"] == 1))[0])
+    assert pkt[i, 0] == (1 << 4) | meta["tn"][i]
+    assert int.from_bytes(bytes(pkt[i, 1:5]), "big") == meta["fn"][i]
+    assert int.from_bytes(bytes(pkt[i, 6:8]), "big", signed=True) == int(np.floor(float(r["toa"][i]) * 256.0 + 0.5))
+    assert pkt[i, 8] >> 7 == 0 and (pkt[i, 8] & 7) == r["tsc"][i]
+
+
+def test_trxd_end_to_end_vs_oracle_chain(trx):
+    """Oracle detect+demod+pack against GPU detect+demod(exact)+pack: header bytes fn/tn/toa/tsc/flags and all soft bytes
+    identical; rssi and C/I bytes may differ by one count where the float value sits on a rounding boundary (the
+    kernel's rssi / C/I tolerances, 2e-5 dB)."""
+    n = 2048
+    iq, params, meta = mixed_workload(n)
+    d_p = trx.params_tensor(params)
+    res, soft = trx.detect_demod(iq.to("cuda:0"), d_p, sps=4, soft_stride=148, slice_bits=True, exact=True)
+    d_meta = torch.from_numpy(meta.view(np.uint8).reshape(-1, 8).copy()).to("cuda:0")
+    pkt, plen = trx.pack_trxd_wire(res, d_p, soft, d_meta)
+    pkt, plen = pkt.cpu().numpy(), plen.cpu().numpy().view(np.uint16)
+    o_res, o_soft = O.pull_batch(iq.numpy(), 4, params)
+    o_pkt, o_len = O.trxd_pack_batch(o_res, params, o_soft, meta)
+    assert np.array_equal(plen, o_len)
+    v1 = meta["version"] == 1
+    exact_cols = np.ones(160, dtype=bool)
+    exact_cols[5] = False                                 # rssi
+    diff = pkt != o_pkt
+    ci_cols = np.zeros(160, dtype=bool)
+    ci_cols[9:11] = True
+    assert not diff[~v1][:, exact_cols].any()
+    assert not diff[v1][:, exact_cols & ~ci_cols].any()
+    assert np.abs(pkt[:, 5].astype(int) - o_pkt[:, 5].astype(int)).max() <= 1
+    g_ci = pkt[v1][:, 9].astype(np.int32) * 256 + pkt[v1][:, 10]
+    o_ci = o_pkt[v1][:, 9].astype(np.int32) * 256 + o_pkt[v1][:, 10]
+    assert np.abs((g_ci - o_ci + 32768) % 65536 - 32768).max() <= 1
+    assert (diff[:, 5].mean() < 2e-3) and ((g_ci != o_ci).mean() < 5e-3)
+
+
+@pytest.mark.parametrize("n,max_bursts,depth", [(5000, 512, 3), (300, 1024, 2), (4096, 256, 4)])
+def test_hostpipe_equals_device_resident_path(trx, n, max_bursts, depth):
+    """Pageable host buffers through the pinned, multi-stream pipeline == tensors already resident in HBM."""
+    from osmo_trx_amd.trxhip import HostPipe
+    iq, params, meta = mixed_workload(n)
+    pipe = HostPipe(trx, max_bursts, depth=depth, soft_stride=148, pkt_stride=160, rssi_offset=1.5)
+    out = pipe.run(iq.numpy(), params, meta)
+    d_p = trx.params_tensor(params)
+    res, soft = trx.detect_demod(iq.to("cuda:0"), d_p, sps=4, soft_stride=148, slice_bits=True)
+    d_meta = torch.from_numpy(meta.view(np.uint8).reshape(-1, 8).copy()).to("cuda:0")
+    pkt, plen = trx.pack_trxd_wire(res, d_p, soft, d_meta, rssi_offset=1.5)
+    assert np.array_equal(out["results"].view(np.uint8), res.cpu().numpy().reshape(-1))
+    assert np.array_equal(out["soft"], soft.cpu().numpy())
+    assert np.array_equal(out["pkt"], pkt.cpu().numpy())
+    assert np.array_equal(out["pkt_len"], plen.cpu().numpy().view(np.uint16))
+    # the slot interface: fill pinned buffers directly, all slots in flight, collect in order
+    k = min(max_bursts, n)
+    for s in range(depth):
+        v = pipe.slot(s)
+        v["iq"][:k] = iq.numpy()[:k]
+        v["params"][:k] = params[:k]
+        v["meta"][:k] = meta[:k]
+        pipe.submit(s, k)
+    for s in range(depth):
+        pipe.wait(s)
+        v = pipe.slot(s)
+        assert np.array_equal(v["results"][:k], out["results"][:k])
+        assert np.array_equal(v["pkt"][:k], out["pkt"][:k])
+    pipe.close()
+
+
+def test_hostpipe_argument_checks(trx):
+    from osmo_trx_amd.trxhip import HostPipe, TrxHipError
+    with pytest.raises(TrxHipError):
+        HostPipe(trx, 256, depth=1)
+    with pytest.raises(TrxHipError):
+        HostPipe(trx, 256, soft_stride=0, pkt_stride=0)
+    with pytest.raises(TrxHipError):
+        HostPipe(trx, 256, pkt_stride=158)
+    p = HostPipe(trx, 64, depth=2)
+    with pytest.raises(TrxHipError):
+        p.submit(0, 65)
+    p.submit(0, 0)
+    p.wait(0)
+    out = p.run(np.zeros((0, 625, 2), dtype=np.int16), np.zeros(0, dtype=O.PARAMS_DTYPE))
+    assert len(out["results"]) == 0
+    p.close()
+
+
+def exes():
+    return [e for e in (EXE, ABI_EXE) if os.path.exists(e)]
+
+
+@pytest.mark.parametrize("version", [-1, 0, 1])
+def test_burst_gatherer_per_channel_semantics(trx, tmp_path, version):
+    """16 'ARFCN' producer threads + 16 consumer threads through BurstGatherer: every burst comes back exactly once, on
+    its own channel, in push order (fn sequence), with pullRadioVector()'s code (-ENOENT for OFF slots), and its
+    content equals the batched device path / the oracle's datagram."""
+    from osmo_trx_amd import build as trx_build
+    trx_build.build_all()
+    n, chans = 4096, 16
+    iq, params, meta = mixed_workload(n)
+    (tmp_path / "iq.s16").write_bytes(iq.numpy().tobytes())
+    (tmp_path / "p.bin").write_bytes(params.tobytes())
+    rec_dt = np.dtype([("code", "<i4"), ("rc", "<i4"), ("toa", "<f4"), ("ci", "<f4"), ("rssi", "<f4"), ("fn", "<u4"),
+                       ("misc", "<u4"), ("pkt_len", "<u4"), ("body", "u1", 456)])
+    d_p = trx.params_tensor(params)
+    res, soft = trx.detect_demod(iq.to("cuda:0"), d_p, sps=4, soft_stride=148, slice_bits=True)
+    r = trx.results_to_numpy(res)
+    soft = soft.cpu().numpy()
+    for exe in exes():
+        # small batches + short timeout: many partial (timed-out) batches; large: full batches
+        for max_batch, timeout_us in ((64, 50), (512, 2000)):
+            out = tmp_path / "g.bin"
+            txt = subprocess.run([exe, "gather", str(tmp_path / "iq.s16"), str(tmp_path / "p.bin"), str(n), str(chans),
+                                  str(max_batch), str(timeout_us), str(version), str(out)], stdout=subprocess.PIPE,
+                                 text=True, check=True).stdout
+            assert "gather bursts 4096" in txt
+            g = np.fromfile(out, dtype=rec_dt)
+            off = params["type"] == O.OFF
+            assert np.array_equal(g["code"], np.where(off, -2, 0))            # -ENOENT
+            assert np.array_equal(g["fn"], np.arange(n) // chans)             # per-channel order
+            assert np.array_equal(g["misc"] & 0xff, np.arange(n) & 7)
+            assert np.array_equal(g["rc"], r["rc"])
+            det = r["idle"] == 0
+            assert np.array_equal(g["toa"][det], r["toa"][det]) and np.array_equal(g["ci"][det], r["ci"][det])
+            assert np.array_equal((g["misc"] >> 8) & 1, r["idle"])
+            if version < 0:
+                got = g["body"][det].copy().view(np.float32)                  # first 114 soft floats
+                assert np.array_equal(got, soft[det][:, :114])
+            else:
+                m2 = meta.copy()
+                m2["fn"] = np.arange(n) // chans
+                m2["tn"] = np.arange(n) & 7
+                m2["version"] = version
+                o_pkt, o_len = O.trxd_pack_batch(r, params, soft, m2, pkt_stride=456)
+                assert np.array_equal(g["pkt_len"], o_len)
+                assert np.array_equal(g["body"], o_pkt)
+
+
+def test_host_trxd_packer_equals_oracle(trx, tmp_path):
+    """trxdPackBurstInd() (the per-indication host packer of the shim) against the oracle's restatement."""
+    rng = np.random.default_rng(5)
+    n = 600
+    dt = np.dtype([("rx", "<f4", 444), ("nbits", "<u4"), ("fn", "<u4"), ("tn", "<u4"), ("idle", "<u4"), ("modulation", "<u4"),
+                   ("tss", "<u4"), ("tsc", "<u4"), ("ci", "<f4"), ("rssi", "<f8"), ("toa", "<f8")])
+    a = np.zeros(n, dtype=dt)
+    a["rx"] = rng.random((n, 444), dtype=np.float32)
+    a["rx"][:, :8] = [0.0, 1.0, 0.5, 0.5 / 255, 1.5 / 255, 2.5 / 255, 0.998, 0.002]      # ties: round half away from zero
+    a["modulation"] = rng.integers(0, 2, n)
+    a["nbits"] = np.where(a["modulation"] == 1, 444, 148)
+    a["fn"] = rng.integers(0, 2715648, n)
+    a["tn"] = rng.integers(0, 8, n)
+    a["idle"] = rng.integers(0, 4, n) == 0
+    a["tss"] = rng.integers(0, 4, n)
+    a["tsc"] = rng.integers(0, 8, n)
+    a["ci"] = rng.normal(10, 15, n).astype(np.float32)
+    a["rssi"] = rng.uniform(-5, 260, n)
+    a["toa"] = rng.uniform(-3, 64, n)
+    (tmp_path / "ind.bin").write_bytes(a.tobytes())
+    L = O.lib()
+    for exe in exes():
+        for ver in (0, 1):
+            out = tmp_path / f"o{ver}.bin"
+            subprocess.check_call([exe, "trxdhost", str(tmp_path / "ind.bin"), str(n), str(ver), str(out)])
+            got = np.fromfile(out, dtype=np.dtype([("len", "<u2"), ("pkt", "u1", 456)]))
+            buf = np.zeros(460, dtype=np.uint8)
+            for i in range(n):
+                buf[:] = 0
+                row = np.ascontiguousarray(a["rx"][i])
+                ln = L.orc_trxd_pack(buf.ctypes.data, ver, int(a["fn"][i]), int(a["tn"][i]), float(a["rssi"][i]),
+                                     float(a["toa"][i]), int(a["idle"][i]), int(a["modulation"][i]), int(a["tss"][i]),
+                                     int(a["tsc"][i]), float(a["ci"][i]), row.ctypes.data, 0 if a["idle"][i] else int(a["nbits"][i]))
+                assert got["len"][i] == ln
+                assert np.array_equal(got["pkt"][i][:ln], buf[:ln]), (ver, i)
