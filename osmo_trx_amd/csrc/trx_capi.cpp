@@ -16,6 +16,7 @@ extern "C" int trx_launch_pull(const void *d_iq, int cf32, const trxhip_burst_pa
 			       trxhip_burst_result *d_results, float *d_soft, const trx_tables *d_tab, const float *d_ebp_in,
 			       size_t n_bursts, int L, int sps, float thresh, float full_scale,
 			       int soft_stride, int slice, int n_cu, hipStream_t stream);
+extern "C" int trx_unit_masks_match(const trx_tables *t);       /* trx_kernel4.hip: compiled-in sign masks vs the tables */
 extern "C" int trx_launch_pack_trxd(const trxhip_burst_result *d_results, const float *d_soft, int soft_stride,
 				    uint8_t *d_pkt, size_t n_bursts, float rssi_offset, hipStream_t stream);
 extern "C" int trx_launch_pack_trxd_wire(const trxhip_burst_result *d_results, const trxhip_burst_params *d_params,
@@ -46,6 +47,9 @@ extern "C" int trx_launch_va_demod(const float *d_iq, const trxhip_burst_params 
 extern "C" int trx_launch_vector_slicer(float *d_dst, const float *d_src, size_t len, hipStream_t stream);
 
 #include "trx_ctx.h"
+
+#define TRXHIP_FLAG_DIAG_MASK 0x7fffff00   /* phase-ablation bits of the -DTRX_DIAG profiling build (tools/) */
+#define TRXHIP_IFLAG_NO_UNIT  0x40         /* internal: see trx_device.h */
 
 extern "C" {
 
@@ -114,6 +118,7 @@ int trxhip_create_from_tables(trxhip_ctx **out, int device, const void *h_blob, 
 	ctx->device = device;
 	ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 	ctx->d_tables = nullptr;
+	ctx->no_unit = trx_unit_masks_match(t) ? 0 : 1;
 	if (hipMalloc(reinterpret_cast<void **>(&ctx->d_tables), sizeof(trx_tables)) != hipSuccess) {
 		delete ctx;
 		return TRXHIP_ENOMEM;
@@ -179,6 +184,10 @@ static int pull_common(trxhip_ctx *ctx, const void *d_iq, int cf32, const trxhip
 		return TRXHIP_EINVAL;
 	if (with_device(ctx))
 		return TRXHIP_EIO;
+	if (flags & ~(TRXHIP_FLAG_SLICE | TRXHIP_FLAG_EXACT_DEMOD | TRXHIP_FLAG_IDLE_DUMMY | TRXHIP_FLAG_DIAG_MASK))
+		return TRXHIP_EINVAL;
+	if (ctx->no_unit)
+		flags |= TRXHIP_IFLAG_NO_UNIT;
 	return trx_launch_pull(d_iq, cf32, d_params, d_results, d_soft, ctx->d_tables, d_ebp_in, n_bursts, burst_len, sps,
 			       threshold, full_scale, soft_stride, flags, ctx->n_cu, static_cast<hipStream_t>(stream));
 }

@@ -9,6 +9,7 @@ struct trxhip_ctx {
 	int device;
 	int n_cu;
 	trx_tables *d_tables;
+	int no_unit;        /* tables do not have the compiled-in unit structure: keep the multiplying correlation */
 };
 
 static inline int with_device(const trxhip_ctx *ctx)

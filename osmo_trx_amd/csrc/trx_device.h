@@ -197,6 +197,108 @@ __device__ __forceinline__ trx_v2f pk_fma_tap(trx_v2f x, trx_v2f hpair, trx_v2f 
 __device__ __forceinline__ float norm2(c32 v) { return v.y * v.y + v.x * v.x; }
 
 // ------------------------------------------------------------------------------------------------
+// Correlation against a GMSK training sequence without multiplications -- and still bit-identical to
+// convolve_complex() (convolve_base.c:34-38, :72-85).
+//
+// Every GMSK correlation sequence of the reference (TSC 0..7, RACH TS0..2, dummy) is conj(+-1 rotated by k*pi/2) with
+// the rotation table's fp64 phase residue left in: tap k is (+-1, e) for even k and (e, +-1) for odd k with
+// |e| <= 4.6e-14 (checked when the tables are generated: trx_tables.unit_neg / unit_ok).  mac_cmplx() evaluates
+//     y0 += x0*h0 - x1*h1;   y1 += x0*h1 + x1*h0;
+// For an even tap h = (s, e): fl(s*x0) = +-x0 exactly and |fl(x1*e)| <= |x1| * 4.6e-14, which is below a quarter ulp
+// of x0 -- so that fl(+-x0 - fl(x1*e)) == +-x0 -- whenever |x1| <= 2^17 |x0| (2^17 * 4.6e-14 = 6.0e-9 < 2^-26);
+// likewise for y1 and for odd taps with the roles of x0 and x1 swapped.  Under that guard (TRX_UNIT_RATIO, evaluated
+// once per decimated sample; it fails for about one burst in 3000, which then takes the multiplying path) each tap
+// contributes +-x0 / +-x1 exactly and the reference's fl(y + t) is ONE v_pk_add_f32 with the swap / sign carried by
+// op_sel / neg modifiers -- 16 VALU instructions for a normal-burst correlation instead of 64.
+// The sign patterns are compile-time constants (3GPP TS 45.002 training sequences); trxhip_create*() refuses the fast
+// path when they do not match what the table generator derived from the taps.
+// ------------------------------------------------------------------------------------------------
+#define TRX_UNIT_RATIO_LOG2 17
+#define TRX_IFLAG_NO_UNIT 0x40      // bit of the kernels' `slice` argument set by the C ABI when the tables lack the unit structure
+// bit k set: the +-1 component of tap k is -1 (from the generated tables; tests/test_capi_cpu.py pins them)
+#define TRX_UNIT_NEG_TSC0   0x447bull
+#define TRX_UNIT_NEG_TSC1   0xc5bbull
+#define TRX_UNIT_NEG_TSC2   0x7488ull
+#define TRX_UNIT_NEG_TSC3   0x7709ull
+#define TRX_UNIT_NEG_TSC4   0xa75cull
+#define TRX_UNIT_NEG_TSC5   0xf60dull
+#define TRX_UNIT_NEG_TSC6   0x4eb9ull
+#define TRX_UNIT_NEG_TSC7   0xdc21ull
+#define TRX_UNIT_NEG_RACH0  0xa5cc00674bull
+#define TRX_UNIT_NEG_RACH1  0xfd6df886b3ull
+#define TRX_UNIT_NEG_RACH2  0x4429f37d6eull
+#define TRX_UNIT_NEG_DUMMY  0x1212ull
+
+// acc += x * u for the unit tap u of parity ODD and sign NEG:  even: +-(x0, x1);  odd: h = (e, s): (-s*x1, s*x0)
+template <bool ODD, bool NEG>
+__device__ __forceinline__ trx_v2f unit_mac(trx_v2f acc, trx_v2f x)
+{
+	if (!ODD && !NEG) asm("v_pk_add_f32 %0, %0, %1" : "+v"(acc) : "v"(x));
+	if (!ODD && NEG)  asm("v_pk_add_f32 %0, %0, %1 neg_lo:[0,1] neg_hi:[0,1]" : "+v"(acc) : "v"(x));
+	if (ODD && !NEG)  asm("v_pk_add_f32 %0, %0, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "+v"(acc) : "v"(x));
+	if (ODD && NEG)   asm("v_pk_add_f32 %0, %0, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,0] neg_hi:[0,1]" : "+v"(acc) : "v"(x));
+	return acc;
+}
+
+// one tap, parity and sign folded from constants once the caller's loops are unrolled
+__device__ __forceinline__ trx_v2f unit_mac_k(trx_v2f acc, trx_v2f x, unsigned long long negmask, int k)
+{
+	const bool odd = (k & 1) != 0, neg = ((negmask >> k) & 1ull) != 0;
+	if (!odd && !neg) return unit_mac<false, false>(acc, x);
+	if (!odd && neg)  return unit_mac<false, true>(acc, x);
+	if (odd && !neg)  return unit_mac<true, false>(acc, x);
+	return unit_mac<true, true>(acc, x);
+}
+
+// N taps in blocks of 8 reads followed by 8 adds (the register footprint of the multiplying loop it replaces)
+template <unsigned long long NEGMASK, int N>
+struct UnitCorr {
+	static __device__ __forceinline__ trx_v2f run(trx_v2f acc, const c32 *p)
+	{
+		static_assert(N % 8 == 0, "blocks of 8 taps");
+#pragma unroll
+		for (int k0 = 0; k0 < N; k0 += 8) {
+			c32 x[8];
+#pragma unroll
+			for (int u = 0; u < 8; u++)
+				x[u] = lds_c32(p + k0 + u);
+#pragma unroll
+			for (int u = 0; u < 8; u++)
+				acc = unit_mac_k(acc, (trx_v2f){ x[u].x, x[u].y }, NEGMASK, k0 + u);
+			__builtin_amdgcn_sched_barrier(0);
+		}
+		return acc;
+	}
+};
+
+// corr value for the sequence in LDS slot `slot` (0..7 TSC, 8..10 RACH, 19 dummy), p = &sig[i + start - (N-1)]
+__device__ __forceinline__ trx_v2f corr_unit(int slot, const c32 *p)
+{
+	const trx_v2f z = { 0.0f, 0.0f };
+	switch (slot) {                                                 // wave-uniform: a scalar jump
+	case 0: return UnitCorr<TRX_UNIT_NEG_TSC0, 16>::run(z, p);
+	case 1: return UnitCorr<TRX_UNIT_NEG_TSC1, 16>::run(z, p);
+	case 2: return UnitCorr<TRX_UNIT_NEG_TSC2, 16>::run(z, p);
+	case 3: return UnitCorr<TRX_UNIT_NEG_TSC3, 16>::run(z, p);
+	case 4: return UnitCorr<TRX_UNIT_NEG_TSC4, 16>::run(z, p);
+	case 5: return UnitCorr<TRX_UNIT_NEG_TSC5, 16>::run(z, p);
+	case 6: return UnitCorr<TRX_UNIT_NEG_TSC6, 16>::run(z, p);
+	case 7: return UnitCorr<TRX_UNIT_NEG_TSC7, 16>::run(z, p);
+	case 8: return UnitCorr<TRX_UNIT_NEG_RACH0, 40>::run(z, p);
+	case 9: return UnitCorr<TRX_UNIT_NEG_RACH1, 40>::run(z, p);
+	case 10: return UnitCorr<TRX_UNIT_NEG_RACH2, 40>::run(z, p);
+	default: return UnitCorr<TRX_UNIT_NEG_DUMMY, 16>::run(z, p);
+	}
+}
+
+// the guard above for one (decimated) sample: true = a component is more than 2^17 times the other
+__device__ __forceinline__ bool unit_unsafe(c32 v)
+{
+	const float lo = fminf(fabsf(v.x), fabsf(v.y)), hi = fmaxf(fabsf(v.x), fabsf(v.y));
+	return ldexpf(lo, TRX_UNIT_RATIO_LOG2) < hi;
+}
+
+// ------------------------------------------------------------------------------------------------
 // interpolatePoint() for one candidate position per lane (sigProcLib.cpp:1100-1118)
 //   cz    = zero-padded correlation in LDS: cz[i] = corr[i] for 0 <= i < size-1, 0 elsewhere in
 //           [-TRX_CZ_PAD, size + TRX_CZ_PAD).  The reference sums i in [max(0,fl-10), min(size-1,fl+11)):
@@ -448,7 +550,8 @@ __device__ __forceinline__ int detect_tail(const c32 *sig, int sig_len, c32 *cz,
 		}
 	}
 
-	*amp_out = cmul(xcorr, make_float2(hdr[2], hdr[3]));   // xcorr / sync->gain  (:1701)
+	const c32 a = cmul(xcorr, make_float2(hdr[2], hdr[3]));  // xcorr / sync->gain  (:1701)
+	*amp_out = make_float2(unif(a.x), unif(a.y));            // wave-uniform: lives in scalar registers from here on
 	*toa_out = unif(toa - hdr[5]);                           // :1704
 	*ci_out = ci;
 	DIAG_MARK(7);
@@ -464,10 +567,12 @@ __device__ __forceinline__ int detect_tail(const c32 *sig, int sig_len, c32 *cz,
 //   NARROW: sig[] and cz[] are the TRX_DEC_NARROW / TRX_CORR_NARROW buffers: a window that does not fit them
 //           (max_toa > 64) is correlated without storing it and only the 25 values around the peak are
 //           recomputed for the tail, exactly as the SCH buffer search does (trx_sch.hip)
+//   unit_slot >= 0: the sequence is the GMSK one of that LDS slot and every sample the window reads passed
+//           unit_unsafe(): correlate with corr_unit() (additions only, same bits); < 0: multiply as written
 template <bool PADDED, bool NARROW>
 __device__ __forceinline__ int detect_burst(const c32 *sig, int sig_len, c32 *cz, const c32 *taps, const float *hdr,
 					     int N, float thresh, int start, int len, const float *sincv, const PeakConst &pc, int lane,
-					     float *toa_out, c32 *amp_out, float *ci_out, int slice DIAG_ARG)
+					     float *toa_out, c32 *amp_out, float *ci_out, int slice, int unit_slot DIAG_ARG)
 {
 	const bool wide = NARROW && (len > TRX_CORR_NARROW || start + len > TRX_DEC_NARROW);
 	// corr[i] with range-checked reads, taps in order (cold: wide windows only)
@@ -493,6 +598,16 @@ __device__ __forceinline__ int detect_burst(const c32 *sig, int sig_len, c32 *cz
 			const float v = norm2(corr_at(i));
 			if (v > best) { best = v; bidx = i; }
 		}
+	} else if (PADDED && unit_slot >= 0) {
+		for (int i = lane; i < len; i += WAVE) {
+			const trx_v2f acc = corr_unit(unit_slot, sig + (i + start - (N - 1)));
+			const c32 y = make_float2(acc.x, acc.y);
+			cz[i] = y;
+			const float v = norm2(y);
+			if (v > best) { best = v; bidx = i; }
+		}
+		if (lane < TRX_CZ_PAD)
+			cz[len + lane] = make_float2(0.0f, 0.0f);
 	} else {
 		for (int i = lane; i < len; i += WAVE) {
 			// (yr, yi) += (xr*hr - xi*hi, xr*hi + xi*hr) as four packed ops per tap: two v_pk_mul, one v_pk_add with
@@ -570,11 +685,13 @@ __device__ __forceinline__ int detect_burst(const c32 *sig, int sig_len, c32 *cz
 // ------------------------------------------------------------------------------------------------
 struct DetectOut { float toa; c32 amp; float ci; int tsc; };
 
+//   unit_bad        : set by decimate() when a sample it produced fails unit_unsafe() (or -1-initialised to disable
+//                     the addition-only correlation altogether: 1-SPS kernel, table mismatch)
 template <bool PADDED, bool NARROW, typename DecimateFn>
 __device__ __forceinline__ int detect_any_burst(int type, int tsc, int max_toa, int clip, DecimateFn decimate,
 						 const c32 *sig, int sig_len, c32 *cz, const c32 *lseq, const float *lhdr,
 						 float thresh, const float *sincv, const PeakConst &pkc, int lane, int slice,
-						 DetectOut *out DIAG_ARG)
+						 const int &unit_bad, DetectOut *out DIAG_ARG)
 {
 	int ncand = 0;
 	if (type == TRXHIP_TSC || type == TRXHIP_EDGE) {
@@ -615,7 +732,9 @@ __device__ __forceinline__ int detect_any_burst(int type, int tsc, int max_toa, 
 		}
 		DIAG_MARK(2);
 		float t; c32 a; float cc;
-		const int hit = detect_burst<PADDED, NARROW>(sig, sig_len, cz, taps, hdr, N, thresh, start, len, sincv, pkc, lane, &t, &a, &cc, slice DIAG_PASS);
+		const int unit_slot = (PADDED && !unit_bad && (slot < 11 || slot == 19)) ? slot : -1;
+		const int hit = detect_burst<PADDED, NARROW>(sig, sig_len, cz, taps, hdr, N, thresh, start, len, sincv, pkc, lane, &t, &a, &cc,
+							     slice, unit_slot DIAG_PASS);
 		wave_sync();
 		if (hit) {
 			out->toa = t - (float)head;                      // :1768

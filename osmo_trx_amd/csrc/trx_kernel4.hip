@@ -30,7 +30,8 @@
 #define K4_CZ_LEN (TRX_CZ_PAD + TRX_CORR_NARROW + TRX_CZ_PAD)
 #define K4_SLICE (K4_XS + TRX_DEC_NARROW + K4_CZ_LEN)
 #define K4_DROWS (TRX_DELAY_FILTS + 1)                         // + identity row (no fractional filter)
-#define K4_TABLES_FLOATS (TRX_SINCV_LDS + K4_DROWS * TRX_DELAY_HLEN + 2 * 160 + 16 + 2 * LSEQ_TAPS + 8 * LSEQ_NHDR + K4_DROWS * 36)
+#define K4_PKC_INTS (5 * WAVE)                                  // lane constants of the TOA bisection (PeakConst), one copy per CU
+#define K4_TABLES_FLOATS (TRX_SINCV_LDS + K4_DROWS * TRX_DELAY_HLEN + 2 * 160 + 16 + 2 * LSEQ_TAPS + 8 * LSEQ_NHDR + K4_DROWS * 36 + K4_PKC_INTS)
 #define K4_TABLES_BYTES (K4_TABLES_FLOATS * 4)
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -97,6 +98,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 	c32 *lseq = reinterpret_cast<c32 *>(gdec + 16);                // [376] training sequences
 	float *lhdr = reinterpret_cast<float *>(lseq + LSEQ_TAPS);     // [20][8] sequence headers
 	float *comp = lhdr + 8 * LSEQ_NHDR;                            // [65][36] composite delay-o-decimate filters
+	int *pkcl = reinterpret_cast<int *>(comp + K4_DROWS * 36);     // [5][64] PeakConst fields by lane
 	c32 *wbase = reinterpret_cast<c32 *>(smem + K4_TABLES_BYTES) + (size_t)wave * K4_SLICE;
 	c32 *const P = wbase;                                          // polyphase burst: P[r*PH_A + PH_M0 + m] = x[4m + r]
 	c32 *const dec = wbase + K4_XS;                                // 1-SPS (decimated) burst, zero tail
@@ -127,12 +129,21 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 		const int s = (slot < 8) ? TRX_SEQ_TSC0 + slot : (slot < 11) ? TRX_SEQ_RACH0 + (slot - 8) : (slot < 19) ? TRX_SEQ_EDGE0 + (slot - 11) : TRX_SEQ_DUMMY;
 		lhdr[i] = reinterpret_cast<const float *>(&tab->seq[s].gain)[i % 8];
 	}
+	if (threadIdx.x < WAVE) {
+		// functions of the lane id only: kept in LDS and re-read per burst (5 ds_read_b32) rather than in 5 VGPRs that
+		// would be live across the whole burst loop (the demodulator's main filter has no registers to spare)
+		const PeakConst pc0 = peak_const(threadIdx.x);
+		pkcl[0 * WAVE + threadIdx.x] = pc0.flA;
+		pkcl[1 * WAVE + threadIdx.x] = pc0.loA;
+		pkcl[2 * WAVE + threadIdx.x] = pc0.hiA;
+		pkcl[3 * WAVE + threadIdx.x] = pc0.offB;
+		pkcl[4 * WAVE + threadIdx.x] = pc0.ratio_off;
+	}
 	for (int i = lane; i < K4_SLICE; i += WAVE)
 		wbase[i] = make_float2(0.0f, 0.0f);
 	__syncthreads();
 
 	const float fs_db = 6.02059991f * __log2f(full_scale);          // 20*log10(full_scale)
-	const PeakConst pkc = peak_const(threadIdx.x & (WAVE - 1));      // lane constants of the TOA bisection
 	const unsigned total_waves = gridDim.x * waves_per_block;
 	const unsigned first = blockIdx.x * waves_per_block + wave;
 
@@ -222,7 +233,12 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 			} else if ((type != TRXHIP_IDLE || (slice & TRXHIP_FLAG_IDLE_DUMMY)) && !ABL(3)) {   // Transceiver.cpp:754-755
 				// ---- detectAnyBurst (:1926-1957); decimation on the polyphase layout:
 				// dec[i] = sum_k x[4i-15+k] * g[k];  x[4(i-4) + k'] with k' = k+1 -> phase k'&3, m = i-4 + k'>>2
+				PeakConst pkc;
+				pkc.flA = pkcl[0 * WAVE + lane]; pkc.loA = pkcl[1 * WAVE + lane]; pkc.hiA = pkcl[2 * WAVE + lane];
+				pkc.offB = pkcl[3 * WAVE + lane]; pkc.ratio_off = pkcl[4 * WAVE + lane];
+				int unit_bad = (slice & TRX_IFLAG_NO_UNIT) ? 1 : 0;     // guard of the addition-only correlation (corr_unit())
 				auto decimate = [&](int lo, int hi) {
+					bool bad = false;
 					for (int i = lo + lane; i < hi; i += WAVE) {
 						const c32 *pd = P + PH_M0 + i - 4;
 						float yr = 0.0f, yi = 0.0f;
@@ -233,14 +249,49 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 							yr += x.x * g;
 							yi += x.y * g;
 						}
-						dec[i] = make_float2(yr, yi);
+						const c32 y = make_float2(yr, yi);
+						dec[i] = y;
+						bad |= unit_unsafe(y);
 					}
+					unit_bad |= (__ballot(bad) != 0ull) ? 1 : 0;
 					wave_sync();
 				};
-				DetectOut d;
-				rc = detect_any_burst<true, true>(type, tsc, max_toa, clip, decimate, dec, 156, cz, lseq, lhdr, thresh, sincv, pkc,
-							    lane, slice, &d DIAG_PASS);
-				if (rc > 0) { toa = d.toa; amp = d.amp; ci = d.ci; out_tsc = d.tsc; }
+				if (type == TRXHIP_TSC && tsc < 8 && max_toa <= 33) {
+					// The common slot, straight-line: a normal burst is ONE detectGeneralBurst() window (analyzeTrafficBurst,
+					// :1887-1904: target 82, head 10, tail 6 + max_toa -> start 71, len 16 + max_toa <= 49), whose 31 + max_toa
+					// <= 64 decimated samples dec[56 ..] are one round with lane = sample.  Same functions as the general
+					// dispatch below with the constants folded; every lane decimates (samples past the window are real burst
+					// samples, written to dec[] entries nothing reads before the demodulator overwrites them).
+					const int len = 16 + max_toa;
+					__builtin_assume(len >= 16 && len <= 49);
+					{
+						const c32 *pd = P + PH_M0 + (56 + lane) - 4;
+						float yr = 0.0f, yi = 0.0f;
+#pragma unroll
+						for (int k = 0; k < 16; k++) {
+							const c32 x = lds_c32(pd + ((k + 1) & 3) * PH_A + ((k + 1) >> 2));
+							const float g = gdec[k];
+							yr += x.x * g;
+							yi += x.y * g;
+						}
+						const c32 y = make_float2(yr, yi);
+						dec[56 + lane] = y;
+						unit_bad |= (__ballot(unit_unsafe(y) && lane < 15 + len) != 0ull) ? 1 : 0;
+						wave_sync();
+					}
+					DIAG_MARK(2);
+					const int hit = detect_burst<true, true>(dec, 156, cz, lseq + LSEQ_TSC(tsc), lhdr + 8 * tsc, 16, thresh, 71, len, sincv,
+										 pkc, lane, &toa, &amp, &ci, slice, unit_bad ? -1 : tsc DIAG_PASS);
+					wave_sync();
+					rc = hit ? TRXHIP_TSC : (clip ? -TRXHIP_SIGERR_CLIP : 0);                 // :1764, :1953-1954
+					toa -= 10.0f;                                                              // :1768
+					out_tsc = tsc;
+				} else {
+					DetectOut d;
+					rc = detect_any_burst<true, true>(type, tsc, max_toa, clip, decimate, dec, 156, cz, lseq, lhdr, thresh, sincv, pkc,
+								    lane, slice, unit_bad, &d DIAG_PASS);
+					if (rc > 0) { toa = d.toa; amp = d.amp; ci = d.ci; out_tsc = d.tsc; }
+				}
 			}
 		}
 
@@ -385,6 +436,23 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 				const bool need_lo = (n_hi >= n_lo) && (i0l < i_full_lo) && (i0l < nwrite);
 				const bool need_hi = (n_hi >= n_lo) && (i0h <= fdiv(n_hi + 15, 4)) && (i0h < nwrite);
 
+				// Low-side partial outputs from the truncated-composite table (trx_tables.edge_lo): output i0l + e on the 16
+				// lanes of row e, lane t of the row taking taps t, t+16, t+32; the table values are fetched HERE, before the
+				// main filter, so that their latency is covered by it.  Requires that no high-side truncation touches
+				// these outputs (bursts shorter than the window: generic edge_round() below).
+				const bool lo_tab = need_lo && (n_hi >= 4 * (i_full_lo - 1)) && (so || is_edge) && !ABL(6);
+				float ct0 = 0.0f, ct1 = 0.0f, ct2 = 0.0f;
+				const int le = lane >> 4, lt = lane & 15;
+				const int li = i0l + le;                                    // this row's output
+				const int lt0 = n_lo + 15 - 4 * li;                         // first decimator tap that sees an existing sample
+				const bool lact = lt0 >= 1;                                 // (fewer than 4 partial outputs: surplus rows idle)
+				if (lo_tab) {
+					const float *row = &tab->edge_lo[fidx][(lact ? lt0 : 1) - 1][lt];
+					ct0 = row[0];
+					ct1 = row[16];
+					ct2 = (lt < 4) ? row[32] : 0.0f;
+				}
+
 				if (so || is_edge) {
 					// ---- main filter.  Lane l owns the three ADJACENT outputs 3l, 3l+1, 3l+2 (52 lanes): their 35-tap
 					// windows overlap in 27 samples, so the lane reads 44 samples from LDS instead of 3 x 36 (sample
@@ -471,9 +539,21 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 							dec[i0 + e] = cmul(make_float2(sr, si), scale);
 					};
 					DIAG_MARK(8);
-					if (need_lo || need_hi)
+					if (lo_tab) {
+						// X(4 li - 24 - w + lt + 16 j), j = 0..2: one phase array, 4 entries apart
+						const int s0 = 4 * li - 24 - w + lt;
+						const c32 *pp = P + ((s0 & 3) * PH_A + PH_M0 + (s0 >> 2));
+						const c32 x0 = lds_c32(pp), x1 = lds_c32(pp + 4), x2 = lds_c32(pp + 8);
+						float ar = x0.x * ct0, ai = x0.y * ct0;
+						ar = fmaf(x1.x, ct1, ar); ai = fmaf(x1.y, ct1, ai);
+						ar = fmaf(x2.x, ct2, ar); ai = fmaf(x2.y, ct2, ai);
+						const float sr = row_sum(ar), si = row_sum(ai);
+						if (lt == 0 && lact)
+							dec[li] = cmul(make_float2(sr, si), scale);
+					}
+					if ((need_lo && !lo_tab) || need_hi)
 						load_hh();                                          // only now: 20 registers the main filter does not carry
-					if (need_lo && !ABL(6)) edge_round(i0l);
+					if (need_lo && !lo_tab && !ABL(6)) edge_round(i0l);
 					if (need_hi && !ABL(6)) edge_round(i0h);
 					DIAG_MARK(9);
 					wave_sync();
@@ -526,6 +606,18 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 		DIAG_MARK(12);
 	}
 	DIAG_FLUSH();
+}
+
+// the sign patterns compiled into corr_unit() against what the table generator derived from the taps (host side)
+extern "C" int trx_unit_masks_match(const trx_tables *t)
+{
+	static const unsigned long long want[12] = { TRX_UNIT_NEG_TSC0, TRX_UNIT_NEG_TSC1, TRX_UNIT_NEG_TSC2, TRX_UNIT_NEG_TSC3,
+						     TRX_UNIT_NEG_TSC4, TRX_UNIT_NEG_TSC5, TRX_UNIT_NEG_TSC6, TRX_UNIT_NEG_TSC7,
+						     TRX_UNIT_NEG_RACH0, TRX_UNIT_NEG_RACH1, TRX_UNIT_NEG_RACH2, TRX_UNIT_NEG_DUMMY };
+	for (int s = 0; s < 12; s++)                                    // TRX_SEQ_TSC0.. = 0..7, RACH 8..10, dummy 11
+		if (!((t->unit_ok >> s) & 1u) || t->unit_neg[s] != want[s])
+			return 0;
+	return 1;
 }
 
 extern "C" int trx_launch_pull4(const void *d_iq, int cf32, const trxhip_burst_params *d_params,

@@ -211,11 +211,11 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 						wave_sync();
 					};
 					rc = detect_any_burst<true, false>(type, tsc, max_toa, clip, decimate, dec, 156, cz, lseq, lhdr, thresh, sincv,
-								    pkc, lane, slice, &d DIAG_PASS);
+								    pkc, lane, slice, 1 /* multiplying correlation */, &d DIAG_PASS);
 				} else {
 					auto nothing = [](int, int) {};
 					rc = detect_any_burst<false, false>(type, tsc, max_toa, clip, nothing, xs, L, cz, lseq, lhdr, thresh, sincv,
-								     pkc, lane, slice, &d DIAG_PASS);
+								     pkc, lane, slice, 1, &d DIAG_PASS);
 				}
 				if (rc > 0) { toa = d.toa; amp = d.amp; ci = d.ci; out_tsc = d.tsc; }
 			}

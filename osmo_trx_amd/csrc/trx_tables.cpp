@@ -86,7 +86,31 @@ public:
 		for (int i = 0; i < 5; i++) t_->c0_inv[i] = (float)inv[i];
 		sincv_table();
 		composite_filters();
+		edge_lo_filters();
 		edge_constants();
+		unit_structure();
+	}
+
+	// Which sequences are "+-1 rotated by k*pi/2 with an fp64 phase residue" tap by tap (the premise of corr_unit(),
+	// trx_device.h): even taps (+-1, e), odd taps (e, +-1), |e| <= 5e-14.
+	void unit_structure()
+	{
+		t_->unit_ok = 0;
+		for (int s = 0; s < TRX_NSEQ; s++) {
+			const trx_seq &q = t_->seq[s];
+			bool ok = q.n > 0 && q.n <= 64;
+			uint64_t neg = 0;
+			for (int k = 0; ok && k < q.n; k++) {
+				const float one = (k & 1) ? q.taps[k].im : q.taps[k].re;
+				const float eps = (k & 1) ? q.taps[k].re : q.taps[k].im;
+				ok = (one == 1.0f || one == -1.0f) && std::fabs(eps) <= 5e-14f;
+				if (one < 0.0f)
+					neg |= 1ull << k;
+			}
+			t_->unit_neg[s] = ok ? neg : 0;
+			if (ok)
+				t_->unit_ok |= 1u << s;
+		}
 	}
 
 private:
@@ -389,6 +413,24 @@ private:
 				t_->comp_filt[f][u] = (u < 35) ? (float)acc : 0.0f;
 			}
 		}
+	}
+
+	// composite filters of the low-side partial outputs (decimator truncated to taps t >= t0), as composite_filters()
+	void edge_lo_filters()
+	{
+		for (int f = 0; f <= TRX_DELAY_FILTS; f++)
+			for (int t0 = 1; t0 <= 15; t0++)
+				for (int u = 0; u < 36; u++) {
+					double acc = 0.0;
+					for (int t = t0; t < 16; t++) {
+						const int k = u - t;
+						if (k < 0 || k >= TRX_DELAY_HLEN)
+							continue;
+						const double h = (f < TRX_DELAY_FILTS) ? (double)t_->delay_filt[f][k] : (k == 9 ? 1.0 : 0.0);
+						acc += (double)t_->dec_taps[t] * h;
+					}
+					t_->edge_lo[f][t0 - 1][u] = (u < 35) ? (float)acc : 0.0f;
+				}
 	}
 
 	// EDGE 8-PSK demodulator constants, with the float/double steps of the reference

@@ -57,10 +57,19 @@ struct trx_tables {
 	trx_c32  edge_rot2[2];                              // rotateBurst2 phasors for -M_PI/8 and -M_PI/4
 	float    edge_step;                                 // 2.0f * M_PI_F / 8.0f
 	float    edge_pad;
+	// unit structure of the GMSK correlation sequences (trx_device.h, corr_unit()): bit s of unit_ok is set when every
+	// tap k of seq[s] is (+-1, e) for even k / (e, +-1) for odd k with |e| <= 5e-14; bit k of unit_neg[s] = that +-1 is -1
+	uint64_t unit_neg[TRX_NSEQ];
+	uint32_t unit_ok;
+	uint32_t unit_pad;
+	// fused demodulator, low-side partial outputs: the reference's decimator starts on zero history, so output i only
+	// sees the delayed samples n >= n_lo, i.e. decimator taps t >= t0 = n_lo + 15 - 4i (1..15).  Composite of delay
+	// filter f with the decimator truncated to t >= t0:  edge_lo[f][t0-1][u] = sum_{t>=t0, t+k=u} g[t]*h_f[k], u < 35
+	float    edge_lo[TRX_DELAY_FILTS + 1][15][36];
 };
 
 #define TRX_TABLES_MAGIC   0x54585254u
-#define TRX_TABLES_VERSION 3u
+#define TRX_TABLES_VERSION 4u
 
 // XOR swizzle of the sincv index: conflict-free LDS gathers both for lanes whose positions differ
 // by multiples of 16/512 (coarse bisection levels) and by 1/512 steps (fine levels).

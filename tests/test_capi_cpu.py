@@ -43,7 +43,9 @@ BLOB = np.dtype([("magic", "<u4"), ("version", "<u4"), ("dec_taps", "<f4", 16), 
                  ("rrot1", "<c8", 160), ("c0_inv", "<f4", 8), ("seq", SEQ, 21), ("sincv", "<f4", 4096),
                  ("chan_taps", "<f4", (4, 16)), ("rs6548_taps", "<f4", (65, 16)),
                  ("comp_filt", "<f4", (65, 36)), ("edge_derot", "<c8", 16), ("edge_ideal", "<c8", 9),
-                 ("edge_rot2", "<c8", 2), ("edge_step", "<f4"), ("edge_pad", "<f4")])
+                 ("edge_rot2", "<c8", 2), ("edge_step", "<f4"), ("edge_pad", "<f4"),
+                 ("unit_neg", "<u8", 21), ("unit_ok", "<u4"), ("unit_pad", "<u4"),
+                 ("edge_lo", "<f4", (65, 15, 36))])
 
 
 def test_tables_bit_identical_to_oracle(lib):
@@ -84,6 +86,15 @@ def test_tables_bit_identical_to_oracle(lib):
         np.testing.assert_allclose(t["comp_filt"][f][:35], ref, rtol=1e-7, atol=1e-12)   # products in double, one float rounding
         assert t["comp_filt"][f][35] == 0
     assert np.array_equal(t["comp_filt"][64][9:25], o["dec_taps"]) and not t["comp_filt"][64][:9].any()
+    # truncated composites of the low-side partial outputs: decimator taps t >= t0 only
+    for f in (0, 17, 63):
+        for t0 in (1, 3, 7, 11, 15):
+            g = o["dec_taps"].astype(np.float64).copy()
+            g[:t0] = 0.0
+            ref = np.convolve(g, o["delay_filt"][f].astype(np.float64))
+            np.testing.assert_allclose(t["edge_lo"][f][t0 - 1][:35], ref, rtol=1e-7, atol=1e-12)
+            assert t["edge_lo"][f][t0 - 1][35] == 0
+    assert np.array_equal(t["edge_lo"][64][6][9 + 7:25], o["dec_taps"][7:]) and not t["edge_lo"][64][6][:16].any()
     # resampler / channelizer partitions against the oracle's restatements
     L = O.lib()
     r = L.orc_resampler_new(65, 48, 16, 1.0)
@@ -148,3 +159,31 @@ def test_trxarch_exports_the_reference_seam():
         L.convolve_real.restype = C.c_int
         assert L.convolve_real(x.ctypes.data, 32, x.ctypes.data, 4, y.ctypes.data, 8, 3, 8) == -1
         assert (y == 7.0).all()
+
+
+def test_unit_tap_structure_of_gmsk_sequences(lib):
+    """The premise of corr_unit() (csrc/trx_device.h): every tap of the GMSK correlation sequences is (+-1, e) for even k,
+    (e, +-1) for odd k, |e| <= 5e-14 -- checked here against the ORACLE's tables -- and the sign patterns compiled into
+    the kernels are the ones the tables have."""
+    t = np.frombuffer(trxhip.generate_tables_host(), dtype=BLOB)[0]
+    o = O.tables()
+    hdr = open(os.path.join(ROOT, "osmo_trx_amd", "csrc", "trx_device.h")).read()
+    compiled = {m.group(1): int(m.group(2), 16) for m in re.finditer(r"#define TRX_UNIT_NEG_(\w+)\s+0x([0-9a-f]+)ull", hdr)}
+    seqs = [("TSC%d" % i, i, o["midamble"][i]) for i in range(8)] + [("RACH%d" % i, 8 + i, o["rach"][i]) for i in range(3)] + \
+        [("DUMMY", 11, o["dummy"])]
+    for name, s, ref in seqs:
+        taps = ref["seq"]
+        neg = 0
+        for k, h in enumerate(taps):
+            one, eps = (h.imag, h.real) if k & 1 else (h.real, h.imag)
+            assert abs(one) == 1.0 and abs(eps) <= 5e-14, (name, k, h)
+            if one < 0:
+                neg |= 1 << k
+        assert (int(t["unit_ok"]) >> s) & 1
+        assert int(t["unit_neg"][s]) == neg == compiled[name], name
+    # 2^17 * max|e| stays below a quarter ulp (2^-26): the guard of the exactness argument
+    emax = max(max(abs(h.real) if k & 1 else abs(h.imag) for k, h in enumerate(ref["seq"])) for _, _, ref in seqs)
+    assert (1 << 17) * emax < 2.0 ** -26
+    # 8-PSK midambles do not have the structure and must not be flagged
+    for i in range(8):
+        assert not (int(t["unit_ok"]) >> (12 + i)) & 1

@@ -407,3 +407,22 @@ def test_dummy_burst_detection_on_idle_slots(trx):
     # without the flag IDLE slots are skipped (Transceiver.cpp:754-755)
     res2, _ = trx.detect_demod(iq.to("cuda:0"), trx.params_tensor(params), sps=4)
     assert (trx.results_to_numpy(res2)["rc"] == 0).all()
+
+
+def test_unit_correlation_guard_and_fallback(trx):
+    """corr_unit() (trx_device.h) replaces the 4-operation complex MAC by one exact addition per tap when no decimated
+    sample has a component more than 2^17 times the other; bursts that break that guard must take the multiplying
+    path and still be bit-identical.  Real-only IQ (Q = 0: every decimated sample has an exactly zero imaginary part),
+    imaginary-only IQ, a burst with a single tiny Q, and ordinary bursts interleaved in one batch, NB and RACH."""
+    from osmo_trx_amd import synth
+    n = 1024
+    for make in (synth.make_normal_bursts, synth.make_access_bursts):
+        iq, params, _ = make(n, "cpu", seed=77) if make is synth.make_access_bursts else make(n, "cpu", 4, seed=77)
+        iq = iq.clone()
+        iq[0::4, :, 1] = 0                      # real only
+        iq[1::4, :, 0] = 0                      # imaginary only
+        iq[2::4, :, 1] = (iq[2::4, :, 1].to(torch.int32) // 4096).to(torch.int16)    # Q = -8..7: ratios up to 2^15 .. inf
+        o_res, o_soft = O.pull_batch(iq.numpy(), 4, params)
+        g_res, g_soft = run_gpu(trx, iq, params, 4)
+        check_parity(g_res, g_soft, o_res, o_soft)
+        assert (o_res["rc"][3::4] > 0).sum() > 200          # the untouched quarter detects as usual

@@ -5,7 +5,7 @@ export TRXHIP_LIB=$R/osmo_trx_amd/lib/libtrxhip_diag.so
 export DIAG_MASKS=0,0x1,0x2,0x8,0x200,0x80,0x40,0x20,0x10,0x4
 timeout 420 rocprofv3 --output-format csv --kernel-include-regex burst_pull4 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS -d $R/gpurun_out/pmc_phase -o ph -- python3 $R/tools/pmc_phase.py > $R/gpurun_out/pmc_phase.log 2>&1
 cd $R/gpurun_out/pmc_phase && find . -name "*counter_collection.csv" | head -3
-python3 - <<'PY'
+python3 - > $R/gpurun_out/pmc_phase_summary.txt <<'PY'
 import csv, glob, collections
 f = glob.glob("**/*counter_collection.csv", recursive=True)[0]
 rows = collections.OrderedDict()
