@@ -447,6 +447,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 				const int lt0 = n_lo + 15 - 4 * li;                         // first decimator tap that sees an existing sample
 				const bool lact = lt0 >= 1;                                 // (fewer than 4 partial outputs: surplus rows idle)
 				if (lo_tab) {
+					// all 35 taps here: a truncated decimator no longer cancels the delay filter's tails (taps u < 8 reach 4e-5)
 					const float *row = &tab->edge_lo[fidx][(lact ? lt0 : 1) - 1][lt];
 					ct0 = row[0];
 					ct1 = row[16];
@@ -458,9 +459,15 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 					// windows overlap in 27 samples, so the lane reads 44 samples from LDS instead of 3 x 36 (sample
 					// v = u + 4j serves tap u of output j); stride-3 lanes stay bank-conflict-free.  Taps outer, a ring
 					// of 16 samples loaded D ahead of use; one sched_barrier per tap keeps order and register footprint.
-					const float4 *c4 = reinterpret_cast<const float4 *>(comp + fidx * 36);   // 35 taps (+ zero pad), broadcast reads
-					const int c = -24 - w;
-					const int i_min = cdiv(-36 - c, 4), i_max = fdiv(L + 1 - c, 4);
+					// Of the 35 composite taps only u = 9 .. 27 matter: the decimator's passband sees the fractional-delay
+					// filter as a pure delay, so comp_f is the decimator shifted by 9 + frac and the taps outside carry
+					// < 1.1e-6 (u < 8) of the filter's absolute sum in every one of the 65 rows (tests/test_capi_cpu.py).
+					// The filter runs over u = K4_U0 .. K4_U0 + K4_NT - 1 = 8 .. 31: 24 taps instead of 36.
+					constexpr int K4_U0 = 8, K4_NT = 24;
+					const float4 *c4 = reinterpret_cast<const float4 *>(comp + fidx * 36 + K4_U0);   // broadcast reads
+					const int c_full = -24 - w;                                 // sample of tap 0 of output i: 4i + c_full
+					const int c = c_full + K4_U0;
+					const int i_min = cdiv(-36 - c_full, 4), i_max = fdiv(L + 1 - c_full, 4);
 					// lanes holding a full output never need the clamp (i_min + 6 <= i_full_lo, i_full_hi + 6 <= i_max):
 					// it only keeps the reads of lanes whose outputs are discarded inside the padded arrays
 					int ic = 3 * lane;
@@ -469,7 +476,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 					const PhBase pb = ph_bases(P, c & 3, ic + (c >> 2));
 					v2f acc[3] = { { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f } };
 					if (!ABL(5)) {
-						constexpr int D = 4, NV = 36 + 8;                       // samples v = 0 .. 43
+						constexpr int D = 4, NV = K4_NT + 8;                    // samples v = 0 .. 31
 						c32 xw[16];
 						float4 cq[2];
 						cq[0] = c4[0];
@@ -477,8 +484,8 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 						for (int v = 0; v < 8 + D; v++)
 							xw[v] = lds_c32(pb.p[v & 3] + (v >> 2));
 #pragma unroll
-						for (int u = 0; u < 36; u++) {
-							if ((u & 3) == 0 && u + 4 < 36)
+						for (int u = 0; u < K4_NT; u++) {
+							if ((u & 3) == 0 && u + 4 < K4_NT)
 								cq[((u >> 2) + 1) & 1] = c4[(u >> 2) + 1];
 							if (u + 8 + D < NV)
 								xw[(u + 8 + D) & 15] = lds_c32(pb.p[(u + 8 + D) & 3] + ((u + 8 + D) >> 2));

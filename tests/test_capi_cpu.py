@@ -86,6 +86,9 @@ def test_tables_bit_identical_to_oracle(lib):
         np.testing.assert_allclose(t["comp_filt"][f][:35], ref, rtol=1e-7, atol=1e-12)   # products in double, one float rounding
         assert t["comp_filt"][f][35] == 0
     assert np.array_equal(t["comp_filt"][64][9:25], o["dec_taps"]) and not t["comp_filt"][64][:9].any()
+    # the fused demodulator runs taps 8 .. 31 only (trx_kernel4.hip, K4_U0 / K4_NT): what it leaves out is below 1.1e-6 of a
+    # filter whose taps sum to 1, in every row.  (Not so for the truncated rows of the low-edge table, which keep all taps.)
+    assert np.abs(t["comp_filt"][:, :8]).sum(axis=1).max() < 1.1e-6 and not t["comp_filt"][:, 32:].any()
     # truncated composites of the low-side partial outputs: decimator taps t >= t0 only
     for f in (0, 17, 63):
         for t0 in (1, 3, 7, 11, 15):
