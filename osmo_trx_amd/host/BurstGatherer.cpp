@@ -60,6 +60,7 @@ int trxdPackBurstInd(uint8_t *buf, const BurstIndication *bi, unsigned version)
 
 namespace {
 typedef std::chrono::steady_clock Clock;
+inline int64_t now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(Clock::now().time_since_epoch()).count(); }
 
 struct Route {
 	uint16_t chan;
@@ -67,53 +68,67 @@ struct Route {
 	uint8_t tn;
 	uint32_t fn;
 };
-struct Done {
-	BurstIndication bi;
-	int code;
-	uint16_t pkt_len;
-	uint8_t pkt[TRXD_MAX_PKT_LEN + 1];
+struct Slot {                                   /* routing of one gathered burst + its "copied in" flag */
+	Route r;
+	std::atomic<uint32_t> ready;                /* == the batch's epoch once the producer has finished writing the slot */
+};
+/* one delivered burst in a channel's ring: the C ABI's result record, routing fields and the payload the consumer
+ * asked for (soft floats or the TRXD datagram) -- a few hundred bytes, not a whole BurstIndication */
+struct Entry {
+	trxhip_burst_result res;
+	Route route;
+	int32_t code;
+	uint32_t pkt_len;
 };
 struct Chan {
 	std::mutex mu;
 	std::condition_variable cv;
-	std::vector<Done> ring;
+	std::vector<uint8_t> ring;                  /* fifo_depth x (sizeof(Entry) + payload) */
 	size_t head = 0, count = 0;
-	std::atomic<size_t> outstanding{0};
+	std::atomic<size_t> outstanding{0};         /* pushed and not yet pulled: the reference's FIFO occupancy */
 };
+const uint32_t CLOSED = 1u << 30;
 struct Batch {
+	/* the one word every push touches sits alone in its cache line */
+	alignas(64) std::atomic<uint32_t> reserved{0};      /* slots handed out; >= CLOSED once the batch is closed */
+	alignas(64) std::atomic<int64_t> first_ns{0};       /* arrival of the first burst (0 = none yet) */
 	trxhip_hostpipe_slot h;
-	uint32_t reserved = 0;                  /* indices handed to producers (under Impl::mu) */
-	std::atomic<uint32_t> written{0};       /* producers done copying */
-	uint32_t count = 0;                     /* final size once closed */
-	Clock::time_point first;
-	std::vector<Route> route;
+	uint32_t count = 0;                         /* final size once closed */
+	uint32_t epoch = 1;                         /* bumped per reuse: what Slot::ready must equal */
+	std::vector<Slot> slot;
 };
 }  // namespace
 
 struct BurstGatherer::Impl {
 	BurstGathererConfig cfg;
 	trxhip_hostpipe *pipe = nullptr;
-	size_t stride = 0;
+	size_t payload = 0, entry_bytes = 0, stride = 0;
 	std::vector<Batch> batch;
 	std::vector<Chan> chan;
-	std::mutex mu;
+	std::mutex mu;                              /* queues and batch roll-over; NOT taken on the per-burst path */
 	std::condition_variable cv_work, cv_space, cv_done;
-	int filling = -1;
+	alignas(64) std::atomic<int> filling{-1};   /* read by every push, written at roll-over only */
+	alignas(64) int pad_ = 0;
 	std::deque<int> free_q, closed_q, flight_q;
-	std::atomic<bool> stopping{false}, running{false}, failed{false};
+	std::atomic<bool> stopping{false}, running{false};
 	std::thread submitter, completer;
 	std::atomic<uint64_t> n_batches{0}, n_dropped{0};
 
-	void close_filling_locked()
+	/* close batch f (full, or its first burst timed out) and make the next free one the filling batch; idempotent */
+	void close_locked(int f)
 	{
-		Batch &b = batch[filling];
-		b.count = b.reserved;
-		closed_q.push_back(filling);
-		filling = -1;
+		if (filling.load(std::memory_order_relaxed) != f)
+			return;
+		Batch &b = batch[f];
+		const uint32_t old = b.reserved.exchange(CLOSED, std::memory_order_acq_rel);
+		b.count = old < cfg.max_batch ? old : (uint32_t)cfg.max_batch;
+		closed_q.push_back(f);
+		int next = -1;
 		if (!free_q.empty()) {
-			filling = free_q.front();
+			next = free_q.front();
 			free_q.pop_front();
 		}
+		filling.store(next, std::memory_order_release);
 		cv_work.notify_all();
 	}
 
@@ -126,44 +141,39 @@ struct BurstGatherer::Impl {
 				closed_q.pop_front();
 				Batch &b = batch[s];
 				lk.unlock();
-				while (b.written.load(std::memory_order_acquire) < b.count)   /* a producer is still inside its memcpy */
-					std::this_thread::yield();
-				const int rc = trxhip_hostpipe_submit(pipe, s, b.count);
+				for (uint32_t i = 0; i < b.count; i++)                       /* a producer may still be inside its memcpy */
+					while (b.slot[i].ready.load(std::memory_order_acquire) != b.epoch)
+						std::this_thread::yield();
+				(void)trxhip_hostpipe_submit(pipe, s, b.count);               /* a failure surfaces in wait() */
 				lk.lock();
-				if (rc != TRXHIP_OK)
-					failed = true;
 				n_batches++;
 				flight_q.push_back(s);
 				cv_done.notify_all();
 				continue;
 			}
-			if (filling >= 0 && batch[filling].reserved > 0) {
-				const Clock::time_point deadline = batch[filling].first + std::chrono::microseconds(cfg.timeout_us);
-				if (Clock::now() >= deadline) {
-					close_filling_locked();
+			const int f = filling.load(std::memory_order_acquire);
+			const int64_t first = f >= 0 ? batch[f].first_ns.load(std::memory_order_acquire) : 0;
+			if (f >= 0 && first != 0) {
+				const int64_t deadline = first + (int64_t)cfg.timeout_us * 1000;
+				const int64_t now = now_ns();
+				if (now >= deadline) {
+					close_locked(f);
 					continue;
 				}
-				cv_work.wait_until(lk, deadline);
+				cv_work.wait_for(lk, std::chrono::nanoseconds(deadline - now));
 			} else {
-				cv_work.wait(lk);
+				/* nothing gathered: a push of a first burst does not take `mu`, so poll at the timeout's granularity */
+				cv_work.wait_for(lk, std::chrono::microseconds(cfg.timeout_us ? cfg.timeout_us : 1));
 			}
 		}
 	}
 
-	void deliver(size_t c, const Done &d)
-	{
-		Chan &ch = chan[c];
-		std::lock_guard<std::mutex> g(ch.mu);
-		/* cannot overflow: outstanding <= fifo_depth = ring size */
-		ch.ring[(ch.head + ch.count) % ch.ring.size()] = d;
-		ch.count++;
-		ch.cv.notify_one();
-	}
+	uint8_t *entry(Chan &ch, size_t k) { return ch.ring.data() + (k % cfg.fifo_depth) * entry_bytes; }
 
 	void complete_loop()
 	{
+		std::vector<uint32_t> order, first, fill;
 		std::unique_lock<std::mutex> lk(mu);
-		Done d;
 		for (;;) {
 			cv_done.wait(lk, [&] { return stopping || !flight_q.empty(); });
 			if (flight_q.empty())
@@ -173,35 +183,51 @@ struct BurstGatherer::Impl {
 			Batch &b = batch[s];
 			lk.unlock();
 			const bool ok = trxhip_hostpipe_wait(pipe, s) == TRXHIP_OK;
-			for (uint32_t i = 0; i < b.count; i++) {
-				const Route &r = b.route[i];
-				BurstRequest rq;
-				memset(&rq, 0, sizeof(rq));
-				rq.type = (CorrType)r.type;
-				rq.fn = r.fn;
-				rq.tn = r.tn;
-				d.code = !ok ? -EIO : (r.type == OFF ? -ENOENT : 0);
-				d.pkt_len = 0;
-				if (ok) {
-					trxsigproc_fill_indication(d.bi, rq, b.h.results[i], b.h.soft ? b.h.soft + i * stride : NULL, stride,
-								   cfg.rssi_offset);
-					if (b.h.pkt) {
-						d.pkt_len = b.h.pkt_len[i];
-						memcpy(d.pkt, b.h.pkt + (size_t)i * stride, d.pkt_len);
+			/* counting sort of the batch by channel (stable: arrival order within a channel is kept), then one lock and
+			 * one wake-up per channel */
+			const size_t nch = chan.size();
+			order.resize(b.count);
+			first.assign(nch + 1, 0);
+			for (uint32_t i = 0; i < b.count; i++)
+				first[b.slot[i].r.chan + 1]++;
+			for (size_t c = 0; c < nch; c++)
+				first[c + 1] += first[c];
+			fill = first;
+			for (uint32_t i = 0; i < b.count; i++)
+				order[fill[b.slot[i].r.chan]++] = i;
+			for (size_t c = 0; c < nch; c++) {
+				if (first[c] == first[c + 1])
+					continue;
+				Chan &ch = chan[c];
+				{
+					std::lock_guard<std::mutex> g(ch.mu);
+					for (uint32_t k = first[c]; k < first[c + 1]; k++) {
+						const uint32_t i = order[k];
+						const Route &r = b.slot[i].r;
+						/* cannot overflow: outstanding <= fifo_depth = ring size */
+						uint8_t *e = entry(ch, ch.head + ch.count);
+						Entry hd;
+						if (ok) hd.res = b.h.results[i]; else memset(&hd.res, 0, sizeof(hd.res));
+						hd.route = r;
+						hd.code = !ok ? -EIO : (r.type == OFF ? -ENOENT : 0);
+						hd.pkt_len = (ok && b.h.pkt) ? b.h.pkt_len[i] : 0;
+						memcpy(e, &hd, sizeof(hd));
+						if (ok && b.h.pkt)
+							memcpy(e + sizeof(Entry), b.h.pkt + (size_t)i * stride, hd.pkt_len);
+						else if (ok && b.h.soft && !hd.res.idle)
+							memcpy(e + sizeof(Entry), b.h.soft + (size_t)i * stride, 4u * hd.res.nbits_div4 * sizeof(float));
+						ch.count++;
 					}
-				} else {
-					memset(&d.bi, 0, sizeof(d.bi));
-					d.bi.fn = r.fn;
-					d.bi.tn = r.tn;
 				}
-				deliver(r.chan, d);
+				ch.cv.notify_one();
 			}
 			lk.lock();
-			b.reserved = 0;
-			b.written.store(0, std::memory_order_relaxed);
 			b.count = 0;
-			if (filling < 0)
-				filling = s;
+			b.epoch++;
+			b.first_ns.store(0, std::memory_order_relaxed);
+			b.reserved.store(0, std::memory_order_release);
+			if (filling.load(std::memory_order_relaxed) < 0)
+				filling.store(s, std::memory_order_release);
 			else
 				free_q.push_back(s);
 			cv_space.notify_all();
@@ -240,12 +266,15 @@ bool BurstGatherer::start()
 	if (m.cfg.trxd_version < 0) {
 		c.soft_stride = m.cfg.egprs ? EDGE_BURST_NBITS : NORMAL_BURST_NBITS;
 		m.stride = c.soft_stride;
+		m.payload = m.stride * sizeof(float);
 	} else {
 		if (m.cfg.trxd_version > 1)
 			return false;
 		c.pkt_stride = m.cfg.egprs ? 456 : 160;
 		m.stride = c.pkt_stride;
+		m.payload = m.stride;
 	}
+	m.entry_bytes = (sizeof(Entry) + m.payload + 15) & ~(size_t)15;
 	c.flags = TRXHIP_FLAG_SLICE;
 	c.threshold = BURST_THRESH;
 	c.full_scale = (float)m.cfg.rxFullScale;
@@ -253,17 +282,20 @@ bool BurstGatherer::start()
 	if (trxhip_hostpipe_create(trxsigproc_context(), &c, &m.pipe) != TRXHIP_OK)
 		return false;
 	m.batch = std::vector<Batch>(m.cfg.depth);
+	m.free_q.clear(); m.closed_q.clear(); m.flight_q.clear();
 	for (int s = 0; s < m.cfg.depth; s++) {
 		trxhip_hostpipe_slot_buffers(m.pipe, s, &m.batch[s].h);
-		m.batch[s].route.resize(m.cfg.max_batch);
+		m.batch[s].slot = std::vector<Slot>(m.cfg.max_batch);
+		for (size_t k = 0; k < m.cfg.max_batch; k++)
+			m.batch[s].slot[k].ready.store(0, std::memory_order_relaxed);
 		if (s)
 			m.free_q.push_back(s);
 	}
-	m.filling = 0;
 	m.chan = std::vector<Chan>(m.cfg.chans);
 	for (size_t c2 = 0; c2 < m.cfg.chans; c2++)
-		m.chan[c2].ring.resize(m.cfg.fifo_depth);
+		m.chan[c2].ring.resize(m.cfg.fifo_depth * m.entry_bytes);
 	m.stopping = false;
+	m.filling.store(0);
 	m.running = true;
 	m.submitter = std::thread([&m] { m.submit_loop(); });
 	m.completer = std::thread([&m] { m.complete_loop(); });
@@ -293,55 +325,102 @@ void BurstGatherer::stop()
 
 bool BurstGatherer::push(size_t c, const BurstRequest &rq)
 {
+	return pushSlot(&c, &rq, 1, NULL) == 1;
+}
+
+size_t BurstGatherer::pushSlot(const size_t *chans, const BurstRequest *rqs, size_t n, bool *accepted)
+{
 	Impl &m = *impl_;
-	if (c >= m.chan.size() || !rq.iq)
-		return false;
-	Batch *b;
-	uint32_t idx;
-	{
-		std::unique_lock<std::mutex> lk(m.mu);
-		if (m.stopping || !m.running)
-			return false;
-		if (m.chan[c].outstanding.load(std::memory_order_relaxed) >= m.cfg.fifo_depth) {
-			m.n_dropped++;                                         /* radioInterface.cpp:277-280: FIFO full, burst deleted */
-			return false;
-		}
-		/* all staging batches closed or in flight: only possible when depth * max_batch < chans * fifo_depth */
-		m.cv_space.wait(lk, [&] { return m.stopping || m.filling >= 0; });
-		if (m.stopping)
-			return false;
-		b = &m.batch[m.filling];
-		idx = b->reserved++;
-		if (idx == 0) {
-			b->first = Clock::now();
-			m.cv_work.notify_all();                                /* arm the timeout */
-		}
-		Route &r = b->route[idx];
-		r.chan = (uint16_t)c;
-		r.type = (uint8_t)rq.type;
-		r.tn = rq.tn;
-		r.fn = rq.fn;
-		m.chan[c].outstanding.fetch_add(1, std::memory_order_relaxed);
-		if (b->reserved == m.cfg.max_batch)
-			m.close_filling_locked();
+	if (!chans || !rqs || m.stopping || !m.running)
+		return 0;
+	/* the FIFO rule first, per channel (radioInterface.cpp:277-280: FIFO full, burst deleted) */
+	enum { STACK = 64 };
+	uint16_t ok_idx_stack[STACK];
+	std::vector<uint16_t> ok_idx_heap;
+	uint16_t *ok_idx = ok_idx_stack;
+	if (n > STACK) {
+		ok_idx_heap.resize(n);
+		ok_idx = ok_idx_heap.data();
 	}
-	/* outside the lock: the burst goes straight into the pinned slot the DMA engine reads from */
-	memcpy(b->h.iq + (size_t)idx * m.cfg.burst_len * 2, rq.iq, m.cfg.burst_len * 2 * sizeof(int16_t));
-	trxhip_burst_params &p = b->h.params[idx];
-	p.type = (uint8_t)rq.type;
-	p.tsc = (uint8_t)rq.tsc;
-	p.max_toa = (uint16_t)rq.max_toa;
-	p.reserved = 0;
-	if (b->h.meta) {
-		trxhip_trxd_meta &mt = b->h.meta[idx];
-		mt.fn = rq.fn;
-		mt.tn = rq.tn;
-		mt.version = (uint8_t)m.cfg.trxd_version;
-		mt.tss = 0;
-		mt.reserved = 0;
+	size_t n_ok = 0;
+	for (size_t k = 0; k < n; k++) {
+		bool ok = chans[k] < m.chan.size() && rqs[k].iq;
+		if (ok) {
+			Chan &ch = m.chan[chans[k]];
+			if (ch.outstanding.fetch_add(1, std::memory_order_acq_rel) >= m.cfg.fifo_depth) {
+				ch.outstanding.fetch_sub(1, std::memory_order_relaxed);
+				m.n_dropped++;
+				ok = false;
+			}
+		}
+		if (accepted)
+			accepted[k] = ok;
+		if (ok)
+			ok_idx[n_ok++] = (uint16_t)k;
 	}
-	b->written.fetch_add(1, std::memory_order_release);
-	return true;
+	/* then one reservation of consecutive staging slots for all of them (two when the batch rolls over in between) */
+	size_t done = 0;
+	while (done < n_ok) {
+		const int f = m.filling.load(std::memory_order_acquire);
+		if (f < 0) {
+			/* all staging batches closed or in flight: only possible when depth * max_batch < chans * fifo_depth */
+			std::unique_lock<std::mutex> lk(m.mu);
+			m.cv_space.wait(lk, [&] { return m.stopping || m.filling.load(std::memory_order_acquire) >= 0; });
+			if (m.stopping) {
+				for (size_t k = done; k < n_ok; k++) {
+					m.chan[chans[ok_idx[k]]].outstanding.fetch_sub(1, std::memory_order_relaxed);
+					if (accepted) accepted[ok_idx[k]] = false;
+				}
+				return done;
+			}
+			continue;
+		}
+		Batch &b = m.batch[f];
+		const uint32_t want = (uint32_t)(n_ok - done);
+		const uint32_t idx0 = b.reserved.fetch_add(want, std::memory_order_acq_rel);   /* the only shared write of a push */
+		if (idx0 >= m.cfg.max_batch) {                             /* full or closed: wait for the roll-over */
+			if (m.filling.load(std::memory_order_acquire) == f)
+				std::this_thread::yield();
+			continue;
+		}
+		const uint32_t got = (idx0 + want <= m.cfg.max_batch) ? want : (uint32_t)m.cfg.max_batch - idx0;
+		if (idx0 == 0) {
+			b.first_ns.store(now_ns(), std::memory_order_release);     /* arms the timeout */
+			m.cv_work.notify_one();
+		}
+		for (uint32_t j = 0; j < got; j++) {
+			const size_t k = ok_idx[done + j];
+			const BurstRequest &rq = rqs[k];
+			const uint32_t idx = idx0 + j;
+			Route &r = b.slot[idx].r;
+			r.chan = (uint16_t)chans[k];
+			r.type = (uint8_t)rq.type;
+			r.tn = rq.tn;
+			r.fn = rq.fn;
+			/* the burst goes straight into the pinned slot the DMA engine reads from */
+			memcpy(b.h.iq + (size_t)idx * m.cfg.burst_len * 2, rq.iq, m.cfg.burst_len * 2 * sizeof(int16_t));
+			trxhip_burst_params &p = b.h.params[idx];
+			p.type = (uint8_t)rq.type;
+			p.tsc = (uint8_t)rq.tsc;
+			p.max_toa = (uint16_t)rq.max_toa;
+			p.reserved = 0;
+			if (b.h.meta) {
+				trxhip_trxd_meta &mt = b.h.meta[idx];
+				mt.fn = rq.fn;
+				mt.tn = rq.tn;
+				mt.version = (uint8_t)m.cfg.trxd_version;
+				mt.tss = 0;
+				mt.reserved = 0;
+			}
+			b.slot[idx].ready.store(b.epoch, std::memory_order_release);
+		}
+		done += got;
+		if (idx0 + want >= m.cfg.max_batch) {                      /* took the last slot: roll the batch over */
+			std::lock_guard<std::mutex> g(m.mu);
+			m.close_locked(f);
+		}
+	}
+	return n_ok;
 }
 
 int BurstGatherer::pull(size_t c, BurstIndication *bi, uint8_t *pkt, size_t *pkt_len)
@@ -354,21 +433,25 @@ int BurstGatherer::pull(size_t c, BurstIndication *bi, uint8_t *pkt, size_t *pkt
 	ch.cv.wait(lk, [&] { return ch.count > 0 || m.stopping || !m.running; });
 	if (ch.count == 0)
 		return -EIO;
-	const Done &d = ch.ring[ch.head];
-	if (m.cfg.trxd_version < 0 || !pkt) {
-		*bi = d.bi;
-	} else {                                                       /* header fields only: the soft bits are in the datagram */
-		memcpy(reinterpret_cast<char *>(bi) + sizeof(bi->rx_burst), reinterpret_cast<const char *>(&d.bi) + sizeof(bi->rx_burst),
-		       sizeof(*bi) - sizeof(bi->rx_burst));
-		memcpy(pkt, d.pkt, d.pkt_len);
-	}
+	const uint8_t *e = m.entry(ch, ch.head);
+	Entry hd;
+	memcpy(&hd, e, sizeof(hd));
+	BurstRequest rq;
+	memset(&rq, 0, sizeof(rq));
+	rq.type = (CorrType)hd.route.type;
+	rq.fn = hd.route.fn;
+	rq.tn = hd.route.tn;
+	const bool floats = m.cfg.trxd_version < 0;
+	trxsigproc_fill_indication(*bi, rq, hd.res, floats ? reinterpret_cast<const float *>(e + sizeof(Entry)) : NULL, m.stride,
+				   m.cfg.rssi_offset);
+	if (!floats && pkt)
+		memcpy(pkt, e + sizeof(Entry), hd.pkt_len);
 	if (pkt_len)
-		*pkt_len = d.pkt_len;
-	const int code = d.code;
-	ch.head = (ch.head + 1) % ch.ring.size();
+		*pkt_len = hd.pkt_len;
+	ch.head = (ch.head + 1) % m.cfg.fifo_depth;
 	ch.count--;
-	ch.outstanding.fetch_sub(1, std::memory_order_relaxed);
-	return code;
+	ch.outstanding.fetch_sub(1, std::memory_order_release);
+	return hd.code;
 }
 
 uint64_t BurstGatherer::batches() const { return impl_->n_batches.load(); }

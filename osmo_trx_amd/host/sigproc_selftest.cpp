@@ -228,21 +228,24 @@ int main(int argc, char **argv)
 		return 0;
 	}
 
-	// gather <iq.s16> <params.bin> <n> <chans> <max_batch> <timeout_us> <trxd_version|-1> <out.bin> [repeat]
-	// `chans` producer threads push their share of the n bursts (burst i belongs to channel i % chans, fn = i / chans),
-	// `chans` consumer threads pull them back (pullRadioVector's role).  out.bin: per burst, in input order,
+	// gather <iq.s16> <params.bin> <n> <chans> <max_batch> <timeout_us> <trxd_version|-1> <out.bin> [repeat [producers [fifo_depth]]]
+	// `producers` threads (default: one per channel; the reference has one RxLower thread per radio device feeding all its
+	// channels) push the n bursts (burst i belongs to channel i % chans, fn = i / chans; channel c is fed by producer
+	// c % producers), `chans` consumer threads pull them back (pullRadioVector's role).  out.bin: per burst, in input order,
 	// {int32 code, int32 rc, float toa, float ci, float rssi, uint32 fn, uint32 tn|idle<<8|nbits<<16, uint32 pkt_len}
 	// followed by 456 bytes: the TRXD datagram (trxd_version >= 0) or the first 114 soft floats (-1).
-	if (!strcmp(argv[1], "gather") && (argc == 10 || argc == 11)) {
+	if (!strcmp(argv[1], "gather") && argc >= 10 && argc <= 13) {
 		std::vector<char> iq = slurp(argv[2]), pr = slurp(argv[3]);
 		const size_t n = atol(argv[4]), chans = atol(argv[5]);
-		const int repeat = argc == 11 ? atoi(argv[10]) : 1;
+		const int repeat = argc >= 11 ? atoi(argv[10]) : 1;
+		const size_t producers = argc >= 12 ? (size_t)atol(argv[11]) : chans;
+		const size_t fifo_depth = argc >= 13 ? (size_t)atol(argv[12]) : 32;
 		BurstGathererConfig cfg;
 		memset(&cfg, 0, sizeof(cfg));
 		cfg.chans = chans;
 		cfg.max_batch = atol(argv[6]);
 		cfg.timeout_us = atoi(argv[7]);
-		cfg.fifo_depth = 32;
+		cfg.fifo_depth = fifo_depth;                     /* 32 = the reference's rule (radioInterface.cpp:277) */
 		cfg.sps = 4;
 		cfg.burst_len = 625;
 		cfg.rxFullScale = 32767.0;
@@ -259,24 +262,42 @@ int main(int argc, char **argv)
 		std::atomic<uint64_t> retries{0};
 		const auto t0 = std::chrono::steady_clock::now();
 		std::vector<std::thread> th;
-		for (size_t c = 0; c < chans; c++) {
-			th.emplace_back([&, c] {                         /* RxLower's role for channel c (radioInterface.cpp:272-291) */
+		for (size_t pr_i = 0; pr_i < producers; pr_i++)
+			th.emplace_back([&, pr_i] {                      /* RxLower's role (radioInterface.cpp:272-291) for its channels */
+				std::vector<size_t> my, cs;
+				for (size_t c = pr_i; c < chans; c += producers) my.push_back(c);
+				std::vector<BurstRequest> rq(my.size());
+				std::vector<char> acc(my.size());
 				for (int rep = 0; rep < repeat; rep++)
-					for (size_t i = c; i < n; i += chans) {
-						const unsigned char *p = reinterpret_cast<const unsigned char *>(pr.data()) + 8 * i;
-						BurstRequest rq;
-						rq.iq = s16 + i * 625 * 2;
-						rq.type = (CorrType)p[0];
-						rq.tsc = p[1];
-						rq.max_toa = p[2] | (p[3] << 8);
-						rq.fn = (uint32_t)(i / chans);
-						rq.tn = (uint8_t)(i & 7);
-						while (!g.push(c, rq)) {             /* a real radio would drop; the test wants every burst back */
-							retries++;
-							std::this_thread::yield();
+					for (size_t base = 0; base < n; base += chans) {     /* one "timeslot": a burst per channel */
+						cs.clear();
+						size_t m = 0;
+						for (size_t c : my) {
+							const size_t i = base + c;
+							if (i >= n) break;
+							const unsigned char *p = reinterpret_cast<const unsigned char *>(pr.data()) + 8 * i;
+							rq[m].iq = s16 + i * 625 * 2;
+							rq[m].type = (CorrType)p[0];
+							rq[m].tsc = p[1];
+							rq[m].max_toa = p[2] | (p[3] << 8);
+							rq[m].fn = (uint32_t)(i / chans);
+							rq[m].tn = (uint8_t)(i & 7);
+							cs.push_back(c);
+							m++;
+						}
+						/* a real radio would drop what does not fit; the test wants every burst back: retry the refused ones */
+						size_t left = m;
+						while (left) {
+							g.pushSlot(cs.data(), rq.data(), left, reinterpret_cast<bool *>(acc.data()));
+							size_t w = 0;
+							for (size_t k = 0; k < left; k++)
+								if (!acc[k]) { cs[w] = cs[k]; rq[w] = rq[k]; w++; }
+							if (w) { retries += w; std::this_thread::yield(); }
+							left = w;
 						}
 					}
 			});
+		for (size_t c = 0; c < chans; c++) {
 			th.emplace_back([&, c] {                         /* RxUpper<c>'s role (Transceiver.cpp:1229-1253) */
 				BurstIndication bi;
 				uint8_t pkt[TRXD_MAX_PKT_LEN + 1];
@@ -295,9 +316,9 @@ int main(int argc, char **argv)
 		}
 		for (auto &t : th) t.join();
 		const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-		printf("gather bursts %zu seconds %.6f mbursts_per_s %.3f batches %llu push_retries %llu dropped %llu\n", n * repeat, dt,
-		       n * repeat / dt * 1e-6, (unsigned long long)g.batches(), (unsigned long long)retries.load(),
-		       (unsigned long long)g.dropped());
+		printf("gather bursts %zu seconds %.6f mbursts_per_s %.3f batches %llu push_retries %llu producers %zu consumers %zu fifo_depth %zu\n",
+		       n * repeat, dt, n * repeat / dt * 1e-6, (unsigned long long)g.batches(), (unsigned long long)retries.load(), producers,
+		       chans, fifo_depth);
 		g.stop();
 		FILE *o = fopen(argv[9], "wb");
 		fwrite(rec.data(), sizeof(Rec), n, o);

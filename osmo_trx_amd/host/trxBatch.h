@@ -95,6 +95,10 @@ public:
 	void stop();                                    /* wakes every blocked pull() with -EIO */
 	/* producer: false = dropped (channel FIFO full, radioInterface.cpp:277-280) */
 	bool push(size_t chan, const BurstRequest &req);
+	/* producer, one timeslot of driveReceiveRadio() (radioInterface.cpp:272-281: one burst per channel): n bursts for
+	 * the channels chans[0..n), gathered with a single reservation.  accepted[k] (optional) = false where the channel's
+	 * FIFO was full; returns the number accepted. */
+	size_t pushSlot(const size_t *chans, const BurstRequest *reqs, size_t n, bool *accepted = NULL);
 	/* consumer, blocking: 0 = *bi filled (maybe bi->idle), -ENOENT = slot OFF (fn/tn filled), -EIO = stopped or GPU
 	 * error -- pullRadioVector()'s contract (Transceiver.cpp:658-664).  With trxd_version >= 0, pkt (>= TRXD_MAX_PKT_LEN
 	 * bytes) receives the datagram and *pkt_len its length (0 = nothing to send); rx_burst is then left untouched. */
