@@ -75,10 +75,11 @@ __device__ __forceinline__ PhBase ph_bases(const c32 *P, int ph0, int m0)
 // slices = 158.2 KB of the 160 KB LDS, which is why the per-wave buffers are the NARROW ones).  Measured 12 -> 16
 // waves: 378 -> 420 Mbursts/s; the kernel is latency bound per wave (profiles/).  Exact: 168 VGPRs.
 #define K4_WPB_FUSED 16
-#define K4_WPB_EXACT 12
+#define K4_WPB_EXACT 16            // int16 input; the complex64-input exact kernel (20 prefetch registers) stays at 12
+#define K4_WPB(CF_, EX_) (((CF_) && (EX_)) ? 12 : 16)
 
 template <bool CF32, bool EXACT>
-__global__ void __launch_bounds__((EXACT ? K4_WPB_EXACT : K4_WPB_FUSED) * WAVE)
+__global__ void __launch_bounds__(K4_WPB(CF32, EXACT) * WAVE)
 burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__restrict__ params,
 		   trxhip_burst_result *__restrict__ results, float *__restrict__ soft,
 		   const trx_tables *__restrict__ tab, const float4 *__restrict__ ebp_in,
@@ -286,6 +287,38 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 					rc = hit ? TRXHIP_TSC : (clip ? -TRXHIP_SIGERR_CLIP : 0);                 // :1764, :1953-1954
 					toa -= 10.0f;                                                              // :1768
 					out_tsc = tsc;
+				} else if (type == TRXHIP_RACH && max_toa <= 64) {
+					// Access bursts, straight-line as well: detectRACHBurst (:1782-1803) with TS0 only is one window -- target 48,
+					// head 8, tail 8 + max_toa -> start 39, len 16 + max_toa <= 80, 40 taps -- over dec[0 .. 39 + len): two
+					// decimation rounds (lane, lane + 64), two correlation rounds inside detect_burst().
+					const int len = 16 + max_toa;
+					__builtin_assume(len >= 16 && len <= 80);
+					bool bad = false;
+#pragma unroll
+					for (int r = 0; r < 2; r++) {
+						const int i = lane + r * WAVE;                          // < 128 <= TRX_DEC_NARROW
+						const c32 *pd = P + PH_M0 + i - 4;
+						float yr = 0.0f, yi = 0.0f;
+#pragma unroll
+						for (int k = 0; k < 16; k++) {
+							const c32 x = lds_c32(pd + ((k + 1) & 3) * PH_A + ((k + 1) >> 2));
+							const float g = gdec[k];
+							yr += x.x * g;
+							yi += x.y * g;
+						}
+						const c32 y = make_float2(yr, yi);
+						dec[i] = y;
+						bad |= unit_unsafe(y) && i < 39 + len;
+					}
+					unit_bad |= (__ballot(bad) != 0ull) ? 1 : 0;
+					wave_sync();
+					DIAG_MARK(2);
+					const int hit = detect_burst<true, true>(dec, 156, cz, lseq + LSEQ_RACH(0), lhdr + 8 * 8, 40, thresh, 39, len, sincv,
+										 pkc, lane, &toa, &amp, &ci, slice, unit_bad ? -1 : 8 DIAG_PASS);
+					wave_sync();
+					rc = hit ? TRXHIP_RACH : (clip ? -TRXHIP_SIGERR_CLIP : 0);                // :1764, :1797-1800
+					toa -= 8.0f;                                                               // :1768
+					out_tsc = 0;                                                               // ebp->tsc = i (:1797)
 				} else {
 					DetectOut d;
 					rc = detect_any_burst<true, true>(type, tsc, max_toa, clip, decimate, dec, 156, cz, lseq, lhdr, thresh, sincv, pkc,
@@ -349,7 +382,6 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 			};
 
 			if (EXACT) {
-				load_hh();
 				// ================= EXACT: two FIR stages in the reference's operand order =================
 				constexpr int R = 12;                                       // outputs per lane: 12*l .. 12*l+11 (52 lanes)
 				const int c0 = -w - 9;                                      // sample of tap 0 of output n: n + c0
@@ -361,25 +393,36 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 				c32 yv[R];
 				{
 					// fshift[m] = sum_k X(m - 9 + k) * h[k]  (convolve NO_DELAY, 20 real taps; :1060): tap-outer /
-					// output-inner with a sliding window; each output still accumulates k = 0..19 in order
-					constexpr int D = 3;
+					// output-inner with a sliding window; each output still accumulates k = 0..19 in order.  The taps are
+					// broadcast LDS reads, a pair per two taps, and the window runs D samples ahead: the footprint is
+					// R accumulators + R + D samples + one tap pair, which keeps this kernel at 16 waves per CU like the
+					// fused one (it used to hold all 20 taps and ran at 12).
+					// Taps 0, 17, 18, 19 are exactly 0.0f in all 64 filters and in the identity row (the sinc LUT is zero beyond
+					// 8 pi, sigProcLib.cpp:990-998; tests/test_capi_cpu.py): fl(x * 0) = +-0 and y + (+-0) == y for every finite
+					// x (y starts at +0 and can never become -0), so those four steps of the reference's loop change nothing and
+					// are skipped: 16 multiply-adds per output instead of 20, same bits.
+					constexpr int D = 1, K0 = 1, K1 = 17;
+					const float2 *hp2 = reinterpret_cast<const float2 *>(dfilt + fidx * TRX_DELAY_HLEN);
 					c32 xr[R + 19];
 #pragma unroll
 					for (int j = 0; j < R; j++)
 						yv[j] = make_float2(0.0f, 0.0f);
 #pragma unroll
-					for (int j = 0; j < R - 1 + D; j++)
-						xr[j] = pb.p[j & 3][j >> 2];
+					for (int j = K0; j < K0 + R - 1 + D; j++)
+						xr[j] = lds_c32(pb.p[j & 3] + (j >> 2));
+					float2 hq = hp2[K0 >> 1];
 #pragma unroll
-					for (int k = 0; k < 20; k++) {
-						const float h = hh[k];
-						if (R - 1 + D + k < R + 19)
-							xr[R - 1 + D + k] = pb.p[(R - 1 + D + k) & 3][(R - 1 + D + k) >> 2];
+					for (int k = K0; k < K1; k++) {
+						const float h = (k & 1) ? hq.y : hq.x;
+						if (R - 1 + D + k < R + K1 - 1)
+							xr[R - 1 + D + k] = lds_c32(pb.p[(R - 1 + D + k) & 3] + ((R - 1 + D + k) >> 2));
 #pragma unroll
 						for (int j = 0; j < R; j++) {
 							yv[j].x += xr[j + k].x * h;
 							yv[j].y += xr[j + k].y * h;
 						}
+						if ((k & 1) && k + 1 < K1)
+							hq = hp2[(k + 1) >> 1];
 						__builtin_amdgcn_sched_barrier(0);
 					}
 				}
@@ -635,7 +678,7 @@ extern "C" int trx_launch_pull4(const void *d_iq, int cf32, const trxhip_burst_p
 	if (n_bursts == 0)
 		return 0;
 	const bool exact = (flags & TRXHIP_FLAG_EXACT_DEMOD) != 0;      // two kernels: the demodulator is a compile-time choice
-	int wpb = exact ? K4_WPB_EXACT : K4_WPB_FUSED;
+	int wpb = K4_WPB(cf32 != 0, exact);
 #ifdef TRX_DIAG
 	if (const char *e = getenv("TRXHIP_WPB")) { const int v = atoi(e); if (v >= 1 && v <= wpb) wpb = v; }   // occupancy scan
 #endif
@@ -656,7 +699,7 @@ extern "C" int trx_launch_pull4(const void *d_iq, int cf32, const trxhip_burst_p
 		const unsigned long long bit = 1ull << (dev & 63);                                              \
 		if (!(armed.load(std::memory_order_acquire) & bit)) {                                           \
 			if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize,        \
-						(int)(K4_TABLES_BYTES + (size_t)(EX_ ? K4_WPB_EXACT : K4_WPB_FUSED) * K4_SLICE * sizeof(c32))) != hipSuccess) \
+						(int)(K4_TABLES_BYTES + (size_t)K4_WPB(CF_, EX_) * K4_SLICE * sizeof(c32))) != hipSuccess) \
 				return TRXHIP_EIO;                                                                  \
 			armed.fetch_or(bit, std::memory_order_release);                                             \
 		}                                                                                               \
