@@ -388,7 +388,24 @@ __device__ __forceinline__ int walk_tree(float nv, int inc0, bool &tie)
 	const unsigned long long lt = __ballot(nv < other);            // even bits: early < late
 	const unsigned long long gt = __ballot(nv > other);            // even bits: early > late
 	const unsigned long long eq = ~(lt | gt);                      // neither (":1170 else break")
-	// branch-free scalar walk: ~10 SALU ops per level.  After a tie the offset stops changing, as in the reference.
+	// Fast walk: with no tie anywhere in the tree (exact equality of two interpolated powers: practically never) the
+	// path is its decision bits p = b0 b1 ... (MSB first), node (L, p) sits at ballot bit 2 * ((1 << L) - 1 + p), and
+	//     off = sum_L (b_L ? +s_L : -s_L) = 2 * s_last * p - (2 * inc0 - s_last),  s_L = inc0 >> L.
+	// Three scalar instructions per level: bit position, s_bitcmp1 -> SCC, p = 2p + SCC.
+	constexpr unsigned long long NODES = (LEVELS == 5) ? 0x1555555555555555ull : 0x15555555ull;   // even bits of 31 / 15 nodes
+	if (!tie && (eq & NODES) == 0ull) {
+		unsigned p = 0, pos;
+#pragma unroll
+		for (int Lw = 0; Lw < LEVELS; Lw++)
+			asm volatile("s_lshl1_add_u32 %1, %0, %3\n\t"
+				     "s_bitcmp1_b64 %2, %1\n\t"
+				     "s_addc_u32 %0, %0, %0"
+				     : "+s"(p), "=&s"(pos) : "s"(lt), "n"(2 * ((1 << Lw) - 1)) : "scc");
+		const int s_last = inc0 >> (LEVELS - 1);
+		return 2 * s_last * (int)p - (2 * inc0 - s_last);
+	}
+	// careful walk (a tie on the path, or carried in): ~10 SALU ops per level.  After a tie the offset stops changing,
+	// as in the reference.
 	unsigned node = 0, stop = tie ? 1u : 0u;
 	int off = 0;
 #pragma unroll

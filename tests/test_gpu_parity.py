@@ -426,3 +426,39 @@ def test_unit_correlation_guard_and_fallback(trx):
         g_res, g_soft = run_gpu(trx, iq, params, 4)
         check_parity(g_res, g_soft, o_res, o_soft)
         assert (o_res["rc"][3::4] > 0).sum() > 200          # the untouched quarter detects as usual
+
+
+def test_full_size_mixed(trx):
+    """BASELINE.json configs[4], one GPU's share at full size: 1M bursts, 7:1 NB:RACH interleaved (every 8th slot an access
+    burst, RACH max_toa 63), through the straight-line NB / RACH paths of the 4-SPS kernel.  Size-independent properties
+    (detection statistics per type, TOA statistics, batch-position independence) + a 2048-burst sample against the oracle."""
+    from osmo_trx_amd import synth
+    n = 1 << 20
+    iq, params = synth.make_mixed_bursts(n, "cuda:0")
+    d_p = trx.params_tensor(params)
+    res, soft = trx.detect_demod(iq, d_p, sps=4)
+    res_x, soft_x = trx.detect_demod(iq, d_p, sps=4, exact=True)
+    torch.cuda.synchronize()
+    r = trx.results_to_numpy(res)
+    is_rach = params["type"] == O.RACH
+    assert is_rach.sum() == n // 8 and (params["type"][~is_rach] == O.TSC).all()
+    # 5 % of either kind are noise-only, 1 % of the normal bursts clipped: detections carry the slot's own type
+    assert 0.94 < (r["rc"][is_rach] == O.RACH).mean() < 0.96 and 0.93 < (r["rc"][~is_rach] == O.TSC).mean() < 0.96
+    assert not ((r["rc"][is_rach] > 0) & (r["rc"][is_rach] != O.RACH)).any()
+    assert not ((r["rc"][~is_rach] > 0) & (r["rc"][~is_rach] != O.TSC)).any()
+    det = r["rc"] > 0
+    assert (r["nbits_div4"][det] == 37).all() and (r["idle"][det] == 0).all() and (r["idle"][~det] == 1).all()
+    # TOA stays inside the search window (:1683 edge gate, "- head"): NB peak index 3..16 minus head 10, RACH 3..76 minus 8
+    assert -7.6 < r["toa"][det & ~is_rach].min() and r["toa"][det & ~is_rach].max() < 6.6
+    assert -5.6 < r["toa"][det & is_rach].min() and r["toa"][det & is_rach].max() < 68.6
+    assert np.median(r["toa"][det & ~is_rach]) < 4.0 and 20.0 < np.median(r["toa"][det & is_rach]) < 45.0
+    assert torch.equal(res, res_x) and float((soft - soft_x).abs().max()) <= FUSED_SOFT_ATOL
+    # position independence: an unaligned slice processed alone (different wave <-> burst assignment)
+    sl = slice(123_457, 123_457 + 8191)
+    res2, soft2 = trx.detect_demod(iq[sl].contiguous(), d_p[sl].contiguous(), sps=4)
+    assert torch.equal(res[sl], res2) and torch.equal(soft[sl], soft2)
+    sel = np.sort(np.random.default_rng(11).choice(n, 2048, replace=False))
+    tsel = torch.from_numpy(sel).to("cuda:0")
+    o_res, o_soft = O.pull_batch(iq[tsel].cpu().numpy(), 4, params[sel])
+    check_parity(r[sel], soft[tsel].cpu().numpy(), o_res, o_soft, soft_atol=FUSED_SOFT_ATOL)
+    check_parity(trx.results_to_numpy(res_x)[sel], soft_x[tsel].cpu().numpy(), o_res, o_soft)
