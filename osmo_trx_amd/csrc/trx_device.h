@@ -492,12 +492,9 @@ __device__ __forceinline__ int detect_tail(const c32 *sig, int sig_len, c32 *cz,
 		for (int i = 1; i < 8; i++)
 			asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(pwr));
 		const float avg = lane_val(acc, 7);
-		int num = 0;
-#pragma unroll
-		for (int i = 2; i <= 5; i++)
-			num += (bidx - i >= 0) + (bidx + i < len);
-		if (num < 5)
-			return 0;
+		// number of in-range terms (:1555-1562).  The edge gate above left 3 <= bidx <= len - 3, so the four terms at
+		// distance 2 and 3 always exist except peak + 3 == len: 7 or 8 >= 5 ("num < 5: return 0" can never fire here)
+		const int num = 3 + (bidx + 3 < len) + (bidx >= 4) + (bidx + 4 < len) + (bidx >= 5) + (bidx + 5 < len);
 		// The gate "|amp| / (sqrtf(avg/num) + 1e-5) < thresh" is a decision, so it must round as the reference
 		// does -- but two IEEE divisions, two correctly rounded square roots and an fp64 add cost ~45 VALU ops.
 		// A 1-ulp-per-op estimate (total error < 1e-6) decides every burst whose ratio is not within 4e-6 of

@@ -54,6 +54,9 @@ extern "C" int trxhip_diag_read(unsigned long long *out, int reset)
 
 __device__ __forceinline__ int fdiv(int a, int b) { const int q = a / b; return (a % b != 0 && a < 0) ? q - 1 : q; }   // b > 0
 __device__ __forceinline__ int cdiv(int a, int b) { return -fdiv(-a, b); }
+// floor / ceiling of a / 4 for any sign: one or two scalar instructions instead of the generic sequence
+__device__ __forceinline__ int fdiv4(int a) { return a >> 2; }
+__device__ __forceinline__ int cdiv4(int a) { return (a + 3) >> 2; }
 
 // four per-lane base pointers for a run of consecutive samples s0, s0+1, ... : sample s0+t lives at
 // pb[t & 3][t >> 2].  ph0 = s0 & 3, m0 = s0 >> 2 (arithmetic).
@@ -473,11 +476,11 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 			} else {
 				// ================= FUSED: one 35-tap composite filter at the symbol instants =================
 				// dec[i] = scale * sum_u comp[u] * X(4i - 24 - w + u) for outputs whose 16 decimator inputs all exist
-				const int i_full_lo = cdiv(n_lo + 15, 4), i_full_hi = fdiv(n_hi, 4);
-				const int i0l = cdiv(n_lo, 4);                              // low-side partial outputs: [i0l, i_full_lo)
+				const int i_full_lo = cdiv4(n_lo + 15), i_full_hi = fdiv4(n_hi);
+				const int i0l = cdiv4(n_lo);                              // low-side partial outputs: [i0l, i_full_lo)
 				const int i0h = i_full_hi + 1;                              // high-side partial outputs: [i0h, fdiv(n_hi+15,4)]
 				const bool need_lo = (n_hi >= n_lo) && (i0l < i_full_lo) && (i0l < nwrite);
-				const bool need_hi = (n_hi >= n_lo) && (i0h <= fdiv(n_hi + 15, 4)) && (i0h < nwrite);
+				const bool need_hi = (n_hi >= n_lo) && (i0h <= fdiv4(n_hi + 15)) && (i0h < nwrite);
 
 				// Low-side partial outputs from the truncated-composite table (trx_tables.edge_lo): output i0l + e on the 16
 				// lanes of row e, lane t of the row taking taps t, t+16, t+32; the table values are fetched HERE, before the
@@ -510,7 +513,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 					const float4 *c4 = reinterpret_cast<const float4 *>(comp + fidx * 36 + K4_U0);   // broadcast reads
 					const int c_full = -24 - w;                                 // sample of tap 0 of output i: 4i + c_full
 					const int c = c_full + K4_U0;
-					const int i_min = cdiv(-36 - c_full, 4), i_max = fdiv(L + 1 - c_full, 4);
+					const int i_min = cdiv4(-36 - c_full), i_max = fdiv4(L + 1 - c_full);
 					// lanes holding a full output never need the clamp (i_min + 6 <= i_full_lo, i_full_hi + 6 <= i_max):
 					// it only keeps the reads of lanes whose outputs are discarded inside the padded arrays
 					int ic = 3 * lane;
