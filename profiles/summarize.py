@@ -60,5 +60,43 @@ def main(tag, bursts=1 << 20):
     print(json.dumps(out, indent=1))
 
 
+def sq_counters(tag, bursts=1 << 20, waves_per_simd=4, waves_per_cu=16):
+    """profiles/<tag>_sq_counters.json from the three SQ passes of tools/run_profiles.sh (per-burst averages)."""
+    per = {}
+    for i in (1, 2, 3):
+        path = os.path.join(G, f"prof_sq{i}", f"{tag}_counter_collection.csv")
+        if not os.path.exists(path):
+            continue
+        acc = {}
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                if KERNEL in row["Kernel_Name"]:
+                    acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+        for k, v in acc.items():
+            per[k] = round(sum(v) / len(v) / bursts, 2)
+    if not per:
+        return
+    d = {}
+    if "SQ_WAVE_CYCLES" in per:
+        d["wave_cycles_per_burst"] = round(4 * per["SQ_WAVE_CYCLES"], 1)              # quad-cycles -> cycles
+    if "SQ_ACTIVE_INST_VALU" in per and "SQ_WAVE_CYCLES" in per:
+        d["valu_cycles_per_burst"] = round(4 * per["SQ_ACTIVE_INST_VALU"], 1)
+        d[f"valu_busy_at_{waves_per_simd}_waves_per_simd"] = round(waves_per_simd * per["SQ_ACTIVE_INST_VALU"] / per["SQ_WAVE_CYCLES"], 3)
+        d[f"salu_busy_at_{waves_per_simd}_waves_per_simd"] = round(waves_per_simd * per.get("SQ_ACTIVE_INST_SCA", 0) / per["SQ_WAVE_CYCLES"], 3)
+        d[f"lds_busy_at_{waves_per_cu}_waves_per_cu"] = round(waves_per_cu * per.get("SQ_LDS_IDX_ACTIVE", 0) / (4 * per["SQ_WAVE_CYCLES"]), 3)
+        for k in ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"):
+            if k in per:
+                d["wave_time_share_" + k[3:].lower()] = round(per[k] / per["SQ_WAVE_CYCLES"], 3)
+    out = {"tag": tag, "kernel": KERNEL, "bursts_per_launch": bursts, "per_burst": per, "derived": d,
+           "note": "rocprofv3 --pmc, three separate passes (tools/run_profiles.sh), bench.py --main-only --steps 2; "
+                   "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are quad-cycles (MI355X_MICROARCH.md)"}
+    json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_sq_counters.json"), "w"), indent=1)
+    print(json.dumps(d, indent=1))
+
+
 if __name__ == "__main__":
     main(sys.argv[1])
+    sq_counters(sys.argv[1])
+    bj = os.path.join(G, f"{sys.argv[1]}_bench.json")
+    if os.path.exists(bj):
+        shutil.copyfile(bj, os.path.join(ROOT, "profiles", f"{sys.argv[1]}_bench.json"))
