@@ -248,7 +248,7 @@ def main():
                 "bursts_per_gpu": n, "global_bursts": n * world, "sps": 4, "burst_len": 625,
                 "parallelism": f"batch-sharded x{world} (no data-path collective; tables RCCL-broadcast once)",
                 "detected_fraction": round(detected / n, 4),
-                "demodulator": "fused 35-tap delay-o-decimate (default); detection bit-exact, soft bits <= 1e-5",
+                "demodulator": "fused delay-o-decimate composite filter, 24 of 35 taps (default); rc, TOA, amp bit-exact; soft bits <= 1e-5 absolute (full scale 1)",
                 "exact_demod_mbursts_per_gpu": round(n / exact_ms / 1e3, 2) if side else None,
                 "mixed_7to1_nb_rach": ({"workload": "BASELINE.json configs[4] per-GPU share: 7:1 NB:RACH, RACH max_toa 63",
                                         "mbursts_per_s_all_gpus": round(5 * n * world / mixed_s / 1e6, 3),

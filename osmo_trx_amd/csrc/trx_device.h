@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <atomic>
 
 #include "trx_tables.h"
 #include "../../include/trxhip.h"
@@ -34,6 +35,23 @@
 #define TRX_TABLES_LDS_BYTES (TRX_TABLES_LDS_FLOATS * 4)
 
 typedef float2 c32;
+
+// The > 64 KB dynamic-LDS opt-in is a per-kernel, per-device attribute: arm it ONCE with the kernel's maximum (160 KB)
+// instead of the size of the current call -- concurrent callers with different sizes (the C ABI allows calls from
+// several host threads) would otherwise race between one thread's hipFuncSetAttribute and another's launch.
+#define TRX_ARM_DYNAMIC_LDS(kernel_ptr)                                                                          \
+	do {                                                                                                     \
+		static std::atomic<unsigned long long> armed_{0ull};                                             \
+		int dev_ = 0;                                                                                    \
+		if (hipGetDevice(&dev_) != hipSuccess) return TRXHIP_EIO;                                        \
+		const unsigned long long bit_ = 1ull << (dev_ & 63);                                             \
+		if (!(armed_.load(std::memory_order_acquire) & bit_)) {                                          \
+			if (hipFuncSetAttribute((const void *)(kernel_ptr), hipFuncAttributeMaxDynamicSharedMemorySize, \
+						160 * 1024) != hipSuccess)                                        \
+				return TRXHIP_EIO;                                                               \
+			armed_.fetch_or(bit_, std::memory_order_release);                                        \
+		}                                                                                                \
+	} while (0)
 
 // Diagnostic build only (-DTRX_DIAG, libtrxhip_diag.so): the upper bits of `slice` carry a phase-ablation
 // mask so that per-phase cost can be measured on the GPU.  The product library is built without it.

@@ -419,9 +419,7 @@ extern "C" int trx_launch_pull(const void *d_iq, int cf32, const trxhip_burst_pa
 #define LAUNCH(SPS_, CF_, NLD_)                                                                                 \
 	do {                                                                                                    \
 		auto k = burst_pull_kernel<SPS_, CF_, NLD_>;                                                    \
-		if (lds > 64 * 1024 &&                                                                           \
-		    hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
-			return TRXHIP_EIO;                                                                      \
+		TRX_ARM_DYNAMIC_LDS(k);                                                                         \
 		hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(wpb * WAVE), lds, stream, d_iq, d_params, d_results, \
 				   d_soft, d_tab, reinterpret_cast<const float4 *>(d_ebp_in), (unsigned)n_bursts, L, thresh,     \
 				   full_scale, soft_stride, slice);                                             \

@@ -146,8 +146,7 @@ extern "C" int trx_launch_sch_detect(const float *d_iq, size_t buf_stride, trxhi
 			   (size_t)(SCH_N + SCH_WIN + 1 + len) * sizeof(c32);
 	if (lds > 160 * 1024)
 		return TRXHIP_EINVAL;
-	if (hipFuncSetAttribute((const void *)sch_detect_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-		return TRXHIP_EIO;
+	TRX_ARM_DYNAMIC_LDS(sch_detect_kernel);
 	hipLaunchKernelGGL(sch_detect_kernel, dim3((unsigned)n_bufs), dim3(SCH_THREADS), lds, stream,
 			   reinterpret_cast<const c32 *>(d_iq), buf_stride, d_results, d_tab, len, start, toa_sub, thresh);
 	return hipGetLastError() == hipSuccess ? 0 : TRXHIP_EIO;

@@ -302,8 +302,7 @@ extern "C" int trx_launch_va_demod(const float *d_iq, const trxhip_burst_params 
 	const size_t lds = trx_va_lds_bytes(L);
 	if (lds > 160 * 1024)
 		return TRXHIP_EINVAL;
-	if (hipFuncSetAttribute((const void *)va_demod_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-		return TRXHIP_EIO;
+	TRX_ARM_DYNAMIC_LDS(va_demod_kernel);
 	const size_t grid = (n_bursts + VA_WPB - 1) / VA_WPB;
 	hipLaunchKernelGGL(va_demod_kernel, dim3((unsigned)grid), dim3(VA_WPB * WAVE), lds, stream,
 			   reinterpret_cast<const c32 *>(d_iq), d_params, d_detected, d_soft, d_starts, (unsigned)n_bursts, L, scale, soft_stride,
