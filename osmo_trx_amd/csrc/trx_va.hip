@@ -3,7 +3,11 @@
 // receiver in Transceiver52M/grgsm_vitac/: channel impulse response from the training sequence at 4 samples per
 // symbol (grgsm_vitac.cpp:147-232, :244-272), matched filter (:168-181), 16-state MLSE (viterbi_detector.cc:62-392).
 //
-// Mapping: ONE WAVEFRONT PER BURST, four waves per workgroup, everything in that wave's LDS slice.
+// Mapping: ONE WAVEFRONT PER FOUR BURSTS.  The front end (channel estimate, matched filter) runs burst after burst with
+// all 64 lanes; the 16-state trellis and its traceback then run for the four bursts AT ONCE, one burst per DPP row of 16
+// lanes -- the add-compare-select butterfly only ever talks to lanes of its own row, and the traceback, the reference's
+// serial walk, is carried by the vector lanes of each row instead of the scalar unit (a scalar instruction costs a wave
+// the same issue slot as a vector one, and the scalar walk could serve one burst only).
 //   * the 59 training-sequence correlations: one lag per lane; |.|^2 the way libstdc++/glibc evaluate
 //     std::pow(abs(c), 2): hypot in double, rounded to float, squared in double, rounded to float
 //   * the sliding 20-sample energy window and its first maximum: the reference's serial float recurrence, kept
@@ -17,13 +21,22 @@
 // Operand order follows the reference statement by statement (-ffp-contract=off): the +-127 outputs are bit-exact.
 #include "trx_device.h"
 
-#define VA_WPB 4
-#define VA_SLICE_BYTES(xs_len) ((size_t)((xs_len) + 64 + VA_FL + VA_NB + 32 + 8) * sizeof(c32) + (size_t)(64 + 192) * sizeof(float))
+#define VA_WPB 2                       // waves per workgroup (11.4 KB of LDS per wave: 14 waves per CU)
+#define VA_BPW 4                       // bursts per wave: one per DPP row
 #define VA_OSR 4
 #define VA_CIR 5
 #define VA_FL (VA_CIR * VA_OSR)
 #define VA_NB 148
 #define VA_AB 88
+#define VA_FSTRIDE 152                 // c32 per burst of matched-filter output (148 + pad: read two symbols per ds_read_b128)
+// per-wave LDS slice, every region 16-byte aligned:
+//   scratch of the burst in the front end: xs[xs_len] | corr[64] | cir[20] | seq[32] : c32;  power[64] : float
+//   kept for the trellis, per burst:       filt[4][152] | rhh[4][8] : c32;  meta[4] : int4 {nbits, start state, start, -}
+//   decision words of the four trellises:  words[148] : uint4 {pos lo, pos hi, nz lo, nz hi} -- over xs[], which the
+//                                          front end no longer needs by then (the region holds at least 296 samples)
+#define VA_XS_CAP(xs_len) ((xs_len) > 296 ? (xs_len) : 296)
+#define VA_SLICE_BYTES(xs_len) ((size_t)(VA_XS_CAP(xs_len) + 64 + VA_FL + 32) * sizeof(c32) + 64 * sizeof(float) +                  \
+				(size_t)VA_BPW * (VA_FSTRIDE + 8) * sizeof(c32) + VA_BPW * 16)
 
 // The training sequences after gmsk_mapper() and conj() (grgsm_vitac.cpp:57-79, :122-145) are walks over
 // {1, j, -1, -j}: out[i] = (+-j) * out[i-1] from the start point 1 / -1 (normal burst, first bit 0 / 1) or -j (access),
@@ -46,135 +59,159 @@ va_demod_kernel(const c32 *__restrict__ iq, const trxhip_burst_params *__restric
 	const int lane = threadIdx.x & (WAVE - 1);
 	const int wave = uni((int)(threadIdx.x >> 6));
 	const int xs_len = (L + 1) & ~1;
-	// per-wave slice: xs[L] | corr[64] | cir[20] | filt[148] | seq[32] | rhh[8] : c32;  power[64] : float (+ 192 spare words)
 	const size_t slice_bytes = VA_SLICE_BYTES(xs_len);
 	char *base = smem + (size_t)wave * slice_bytes;
 	c32 *xs = reinterpret_cast<c32 *>(base);
-	c32 *corr = xs + xs_len;
+	c32 *corr = xs + VA_XS_CAP(xs_len);
 	c32 *cir = corr + 64;
-	c32 *filt = cir + VA_FL;
-	c32 *seq = filt + VA_NB;
-	c32 *rhh = seq + 32;
-	float *power = reinterpret_cast<float *>(rhh + 8);
+	c32 *seq = cir + VA_FL;
+	float *power = reinterpret_cast<float *>(seq + 32);
+	c32 *filt_all = reinterpret_cast<c32 *>(power + 64);
+	c32 *rhh_all = filt_all + VA_BPW * VA_FSTRIDE;
+	int4 *meta = reinterpret_cast<int4 *>(rhh_all + VA_BPW * 8);
+	uint4 *words = reinterpret_cast<uint4 *>(xs);                  // 148 x 16 bytes over the first 296 samples of xs[]
 
-	const unsigned b = blockIdx.x * VA_WPB + wave;
-	if (b >= n_bursts)
+	const unsigned q0 = (blockIdx.x * VA_WPB + wave) * VA_BPW;     // first burst of this wave
+	if (q0 >= n_bursts)
 		return;
-	const unsigned prm = reinterpret_cast<const uint32_t *>(params)[2 * (size_t)b];
-	int type = prm & 0xff;
-	const int tsc = (prm >> 8) & 0xff, max_toa = prm >> 16;
-	float *so = soft + (size_t)b * soft_stride;
-	bool skip = false;
-	if (detected) {                                                // chained behind detection: rc is the CorrType (Transceiver.cpp:784)
-		const int rc = uni(detected[b].rc);
-		skip = rc <= 0;
-		type = rc;
-	}
-	if (tsc > 7 || skip) {                                                 // train_seq has 8 entries (+ dummy): reject
-		for (int i = lane; i < soft_stride; i += WAVE) so[i] = 0.0f;
-		if (starts && lane == 0) starts[b] = -1;
-		return;
-	}
-	const bool nb = (type == TRXHIP_TSC);                          // Transceiver.cpp:629: TSC, else the access branch
-	const int nbits = nb ? VA_NB : VA_AB;
 
-	// ---- scaleVector (sigProcLib.cpp:1198-1205): x * (scale, 0) with Complex.h:74's operand order
-	const c32 *src = iq + (size_t)b * L;
-	for (int i = lane; i < L; i += WAVE)
-		xs[i] = va_cmul(src[i], make_float2(scale, 0.0f));
-
-	// ---- training sequence: element `lane` from its quarter-turn code
-	const int tlen = nb ? 26 : 41, tseqlen = tlen - 10;
-	if (lane < 32) {
-		const unsigned long long codes = nb ? (unsigned long long)va_tsc_codes[tsc] : VA_ACC_CODES;
-		const int qc = (int)((codes >> (2 * lane)) & 3ull);
-		seq[lane] = make_float2(qc == 0 ? 1.0f : qc == 2 ? -1.0f : 0.0f, qc == 1 ? 1.0f : qc == 3 ? -1.0f : 0.0f);
-	}
-	wave_sync();
-
-	// ---- get_chan_imp_resp (grgsm_vitac.cpp:183-232)
-	const int center = nb ? (3 + 58 + 5) : (8 + 5);
-	const int start_pos = (center - 5) * VA_OSR + 1, stop_pos = (center + 5 + VA_CIR) * VA_OSR;   // max_delay = 0 (:631)
-	const int nw = stop_pos - start_pos;                           // 59
-	if (lane < nw) {
-		float rr = 0.0f, ri = 0.0f;
-		for (int ii = 0; ii < tseqlen; ii++) {                     // correlate_sequence :147-155
-			const int j = start_pos + lane + ii * VA_OSR;
-			const c32 xv = (j < L) ? xs[j] : make_float2(0.0f, 0.0f);
-			const c32 t = va_cmul(seq[ii], xv);
-			rr += t.x;
-			ri += t.y;
+	// =================== front end, one burst at a time (all 64 lanes) ===================
+	for (int qb = 0; qb < VA_BPW; qb++) {
+		const unsigned b = q0 + qb;
+		c32 *filt = filt_all + qb * VA_FSTRIDE;
+		c32 *rhh = rhh_all + qb * 8;
+		if (b >= n_bursts) {                                       // batch tail: an idle row
+			if (lane == 0) meta[qb] = make_int4(0, 0, -1, 0);
+			continue;
 		}
-		const float fl = (float)tseqlen;
-		const c32 c = make_float2(rr / fl, -ri / fl);              // conj(result) / (length + 0j)
-		corr[lane] = c;
-		const float h = (float)sqrt((double)c.x * (double)c.x + (double)c.y * (double)c.y);   // abs(): hypotf
-		power[lane] = (float)((double)h * (double)h);              // std::pow(float, int)
-	}
-	wave_sync();
-	// sliding 20-sample window energy (:199-214): ws = p[0] + ... + p[19], then ws += p[i] - p[i-20].  With q[i] = p[i]
-	// (i < 20) or p[i] - p[i-20], the window sums are the left-to-right prefix sums of q: a serial DPP scan along the
-	// lanes reproduces the reference's additions one for one (lane 19 + j ends with window j's energy).
-	int best;
-	{
-		const float pw = (lane < nw) ? power[lane] : 0.0f;
-		const float pp = (lane >= VA_FL && lane < nw) ? power[lane - VA_FL] : 0.0f;
-		const float q = (lane < VA_FL) ? pw : pw - pp;
-		float acc = q;
+		const unsigned prm = reinterpret_cast<const uint32_t *>(params)[2 * (size_t)b];
+		int type = prm & 0xff;
+		const int tsc = (prm >> 8) & 0xff, max_toa = prm >> 16;
+		float *so = soft + (size_t)b * soft_stride;
+		bool skip = false;
+		if (detected) {                                            // chained behind detection: rc is the CorrType (Transceiver.cpp:784)
+			const int rc = uni(detected[b].rc);
+			skip = rc <= 0;
+			type = rc;
+		}
+		if (tsc > 7 || skip) {                                     // train_seq has 8 entries (+ dummy): reject
+			for (int i = lane; i < soft_stride; i += WAVE) so[i] = 0.0f;
+			if (starts && lane == 0) starts[b] = -1;
+			if (lane == 0) meta[qb] = make_int4(0, 0, -1, 0);
+			continue;
+		}
+		const bool nb = (type == TRXHIP_TSC);                      // Transceiver.cpp:629: TSC, else the access branch
+		const int nbits = nb ? VA_NB : VA_AB;
+
+		// ---- scaleVector (sigProcLib.cpp:1198-1205): x * (scale, 0) with Complex.h:74's operand order
+		const c32 *src = iq + (size_t)b * L;
+		for (int i = lane; i < L; i += WAVE)
+			xs[i] = va_cmul(src[i], make_float2(scale, 0.0f));
+
+		// ---- training sequence: element `lane` from its quarter-turn code
+		const int tlen = nb ? 26 : 41, tseqlen = tlen - 10;
+		if (lane < 32) {
+			const unsigned long long codes = nb ? (unsigned long long)va_tsc_codes[tsc] : VA_ACC_CODES;
+			const int qc = (int)((codes >> (2 * lane)) & 3ull);
+			seq[lane] = make_float2(qc == 0 ? 1.0f : qc == 2 ? -1.0f : 0.0f, qc == 1 ? 1.0f : qc == 3 ? -1.0f : 0.0f);
+		}
+		wave_sync();
+
+		// ---- get_chan_imp_resp (grgsm_vitac.cpp:183-232)
+		const int center = nb ? (3 + 58 + 5) : (8 + 5);
+		const int start_pos = (center - 5) * VA_OSR + 1, stop_pos = (center + 5 + VA_CIR) * VA_OSR;   // max_delay = 0 (:631)
+		const int nw = stop_pos - start_pos;                       // 59
+		if (lane < nw) {
+			float rr = 0.0f, ri = 0.0f;
+			for (int ii = 0; ii < tseqlen; ii++) {                 // correlate_sequence :147-155
+				const int j = start_pos + lane + ii * VA_OSR;
+				const c32 xv = (j < L) ? xs[j] : make_float2(0.0f, 0.0f);
+				const c32 t = va_cmul(seq[ii], xv);
+				rr += t.x;
+				ri += t.y;
+			}
+			const float fl = (float)tseqlen;
+			const c32 c = make_float2(rr / fl, -ri / fl);          // conj(result) / (length + 0j)
+			corr[lane] = c;
+			const float h = (float)sqrt((double)c.x * (double)c.x + (double)c.y * (double)c.y);   // abs(): hypotf
+			power[lane] = (float)((double)h * (double)h);          // std::pow(float, int)
+		}
+		wave_sync();
+		// sliding 20-sample window energy (:199-214): ws = p[0] + ... + p[19], then ws += p[i] - p[i-20].  With q[i] = p[i]
+		// (i < 20) or p[i] - p[i-20], the window sums are the left-to-right prefix sums of q: a serial DPP scan along the
+		// lanes reproduces the reference's additions one for one (lane 19 + j ends with window j's energy).
+		int best;
+		{
+			const float pw = (lane < nw) ? power[lane] : 0.0f;
+			const float pp = (lane >= VA_FL && lane < nw) ? power[lane - VA_FL] : 0.0f;
+			const float q = (lane < VA_FL) ? pw : pw - pp;
+			float acc = q;
 #pragma unroll
-		for (int i = 1; i < 59; i++)                               // nw = 59 for both burst types
-			asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(q));
-		const bool inwin = (lane >= VA_FL - 1) && (lane < nw);
-		const float e = inwin ? acc : -3.0e38f;
-		const float m = wave_max(e);
-		const unsigned long long hit = __ballot(inwin && e == m);  // std::max_element: the first largest
-		best = hit ? (int)__ffsll((unsigned long long)hit) - 1 - (VA_FL - 1) : 0;
+			for (int i = 1; i < 59; i++)                           // nw = 59 for both burst types
+				asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(q));
+			const bool inwin = (lane >= VA_FL - 1) && (lane < nw);
+			const float e = inwin ? acc : -3.0e38f;
+			const float m = wave_max(e);
+			const unsigned long long hit = __ballot(inwin && e == m);  // std::max_element: the first largest
+			best = hit ? (int)__ffsll((unsigned long long)hit) - 1 - (VA_FL - 1) : 0;
+		}
+		if (lane < VA_FL)
+			cir[lane] = corr[best + lane];
+		int start = start_pos + best - center * VA_OSR;
+		if (start < 0) start = 0;                                  // Transceiver.cpp:631, :635
+		wave_sync();
+
+		// ---- detect_burst_generic (grgsm_vitac.cpp:82-108): rhh = conj(autocorrelation at multiples of 4), mafi
+		if (lane < VA_CIR) {
+			const int k = lane * VA_OSR;
+			float ar = 0.0f, ai = 0.0f;
+			for (int i = k; i < VA_FL; i++) {
+				const c32 t = va_cmul(cir[i], make_float2(cir[i - k].x, -cir[i - k].y));
+				ar += t.x;
+				ai += t.y;
+			}
+			rhh[lane] = make_float2(ar, -ai);
+		}
+		for (int m = lane; m < nbits; m += WAVE) {
+			float ar = 0.0f, ai = 0.0f;
+			const int a = m * VA_OSR;
+			for (int ii = 0; ii < VA_FL; ii++) {
+				if (a + ii >= nbits * VA_OSR)
+					break;
+				const int j = start + a + ii;
+				const c32 xv = (j < L) ? xs[j] : make_float2(0.0f, 0.0f);
+				const c32 t = va_cmul(xv, cir[ii]);
+				ar += t.x;
+				ai += t.y;
+			}
+			filt[m] = make_float2(ar, ai);
+		}
+		if (lane == 0)                                             // Transceiver.cpp:633: rach_max_toa as the start state
+			meta[qb] = make_int4(nbits, nb ? 3 : max_toa, start, 0);
+		wave_sync();                                               // xs / corr / cir / seq are the next burst's scratch
 	}
-	if (lane < VA_FL)
-		cir[lane] = corr[best + lane];
-	int start = start_pos + best - center * VA_OSR;
-	if (start < 0) start = 0;                                      // Transceiver.cpp:631, :635
 	wave_sync();
 
-	// ---- detect_burst_generic (grgsm_vitac.cpp:82-108): rhh = conj(autocorrelation at multiples of 4), mafi
-	if (lane < VA_CIR) {
-		const int k = lane * VA_OSR;
-		float ar = 0.0f, ai = 0.0f;
-		for (int i = k; i < VA_FL; i++) {
-			const c32 t = va_cmul(cir[i], make_float2(cir[i - k].x, -cir[i - k].y));
-			ar += t.x;
-			ai += t.y;
-		}
-		rhh[lane] = make_float2(ar, -ai);
-	}
-	for (int m = lane; m < nbits; m += WAVE) {
-		float ar = 0.0f, ai = 0.0f;
-		const int a = m * VA_OSR;
-		for (int ii = 0; ii < VA_FL; ii++) {
-			if (a + ii >= nbits * VA_OSR)
-				break;
-			const int j = start + a + ii;
-			const c32 xv = (j < L) ? xs[j] : make_float2(0.0f, 0.0f);
-			const c32 t = va_cmul(xv, cir[ii]);
-			ar += t.x;
-			ai += t.y;
-		}
-		filt[m] = make_float2(ar, ai);
-	}
-	wave_sync();
-
-	// ---- viterbi_detector (viterbi_detector.cc:62-392), add-compare-select as a DPP butterfly.
-	// New state n comes from old states p = n >> 1 and p + 8, i.e. the pair (S, S ^ 8) feeds the pair rotl4(S),
-	// rotl4(S ^ 8).  So a lane holding old state S computes new state rotl4(S) from its own metric and the metric
-	// of the lane holding S ^ 8: lane l holds state rotl4^k(l) at step k (identity again every 4 steps) and its
-	// partner is lane l ^ (8 >> (k & 3)) -- one or two DPP moves instead of two ds_bpermute round trips per step.
+	// =================== viterbi_detector (viterbi_detector.cc:62-392) for the four bursts, row = burst ===================
+	// Add-compare-select as a DPP butterfly.  New state n comes from old states p = n >> 1 and p + 8, i.e. the pair
+	// (S, S ^ 8) feeds the pair rotl4(S), rotl4(S ^ 8).  So a lane holding old state S computes new state rotl4(S) from its
+	// own metric and the metric of the lane holding S ^ 8: lane l of a row holds state rotl4^k(l) at step k (identity again
+	// every 4 steps) and its partner is lane l ^ (8 >> (k & 3)) of the same row -- one or two row-local DPP moves.
+	const int row = lane >> 4, l4 = lane & 15;
+	const int4 mt = meta[row];
+	const int nbits_row = mt.x;
+	const c32 *myfilt = filt_all + row * VA_FSTRIDE;
+	const c32 *rhh = rhh_all + row * 8;
 	float inc[8];
+	{
+		const float r1 = rhh[1].y, r2 = rhh[2].x, r3 = rhh[3].y, r4 = rhh[4].x;
 #pragma unroll
-	for (int m = 0; m < 8; m++) {
-		float v = (m & 1) ? rhh[1].y : -rhh[1].y;
-		v = (m & 2) ? v + rhh[2].x : v - rhh[2].x;
-		v = (m & 4) ? v + rhh[3].y : v - rhh[3].y;
-		inc[m] = v + rhh[4].x;
+		for (int m = 0; m < 8; m++) {
+			float v = (m & 1) ? r1 : -r1;
+			v = (m & 2) ? v + r2 : v - r2;
+			v = (m & 4) ? v + r3 : v - r3;
+			inc[m] = v + r4;
+		}
 	}
 	// per layout r = k & 3: the state this lane holds, and for the state n = rotl4(S) it produces (p = S & 7,
 	// odd = S >> 3) the signed reference levels and the sign of the input symbol:
@@ -185,7 +222,6 @@ va_demod_kernel(const c32 *__restrict__ iq, const trxhip_burst_params *__restric
 	bool oddr[4];
 #pragma unroll
 	for (int r = 0; r < 4; r++) {
-		const int l4 = lane & 15;
 		const int S = ((l4 << r) | (l4 >> (4 - r))) & 15;          // rotl4^r(lane)
 		const int p = S & 7;
 		const bool odd = (S >> 3) != 0;
@@ -201,90 +237,102 @@ va_demod_kernel(const c32 *__restrict__ iq, const trxhip_burst_params *__restric
 		sflip[r] = plus ? 0u : 0x80000000u;
 		oddr[r] = odd;
 	}
-	const unsigned start_state = nb ? 3u : (unsigned)max_toa;      // Transceiver.cpp:633: rach_max_toa as start state
 	float pm = (-10e30);
-	if ((unsigned)(lane & 15) == start_state)
+	if (l4 == mt.y)                                                // start state (>= 16 selects none, as in the reference's quirk)
 		pm = 0.0f;
+	const int nmax = max(max(uni(meta[0].x), uni(meta[1].x)), max(uni(meta[2].x), uni(meta[3].x)));
 	// Only two bits of every path-metric difference survive into the +-127 output: d > 0 (the decision) and d != 0
-	// (an output of +-0 is "not > 0").  Per step the 16 lanes' bits are one ballot word, nz << 16 | pos,
-	// bit l = the new state rotl4^(k+1)(l).
-	// the matched-filter outputs are read once (lane l holds symbols l, l + 64, l + 128) and fetched per step with
-	// v_readlane; the decision words are collected in three registers (lane = step): no LDS traffic inside the trellis
-	c32 fr[3];
-	fr[0] = filt[lane];
-	fr[1] = (lane + 64 < nbits) ? filt[lane + 64] : make_float2(0.0f, 0.0f);
-	fr[2] = (lane + 128 < nbits) ? filt[lane + 128] : make_float2(0.0f, 0.0f);
-	unsigned wv[3] = { 0u, 0u, 0u };
+	// (an output of +-0 is "not > 0").  Per step the 64 lanes' bits are two ballot words (row r = bits 16r .. 16r + 15,
+	// bit l = the new state rotl4^(k+1)(l)), parked in LDS for the traceback.
+	for (int k0 = 0; k0 < nmax; k0 += 4) {                         // 148 and 88 are multiples of 4
+		const float4 fa = *reinterpret_cast<const float4 *>(myfilt + k0);         // symbols k0, k0 + 1
+		const float4 fb = *reinterpret_cast<const float4 *>(myfilt + k0 + 2);     // symbols k0 + 2, k0 + 3
+		const bool act = k0 < nbits_row;                           // this row's burst is still running (rows may differ in length)
 #pragma unroll
-	for (int blk = 0; blk < 3; blk++) {
-		const int kend = (nbits - blk * 64 < 64) ? nbits - blk * 64 : 64;
-		for (int k0 = 0; k0 < kend; k0 += 4) {                     // 148, 88 and 64 are multiples of 4
-#pragma unroll
-			for (int r = 0; r < 4; r++) {
-				const int kk = k0 + r;                             // step blk * 64 + kk
-				const float sym = __int_as_float(__builtin_amdgcn_readlane(__float_as_int((r & 1) ? fr[blk].x : fr[blk].y), kk));
-				const int pmi = __float_as_int(pm);
-				int other;
-				if (r == 0)      other = __builtin_amdgcn_update_dpp(pmi, pmi, 0x128, 0xf, 0xf, false);   // row_ror:8   (l ^ 8)
-				else if (r == 1) {                                                                           // l ^ 4
-					other = __builtin_amdgcn_update_dpp(pmi, pmi, 0x104, 0xf, 0x5, false);                   // row_shl:4 into banks 0, 2
-					other = __builtin_amdgcn_update_dpp(other, pmi, 0x114, 0xf, 0xa, false);                 // row_shr:4 into banks 1, 3
-				}
-				else if (r == 2) other = __builtin_amdgcn_update_dpp(pmi, pmi, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1] (l ^ 2)
-				else             other = __builtin_amdgcn_update_dpp(pmi, pmi, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2] (l ^ 1)
-				const float po = __int_as_float(other);
-				const float o1 = oddr[r] ? po : pm, o2 = oddr[r] ? pm : po;
-				const float ss = __int_as_float(__float_as_int(sym) ^ (int)sflip[r]);
-				const float c1 = (o1 + ss) + a1[r];
-				const float c2 = (o2 + ss) + a2[r];
-				const float d = c2 - c1;
-				pm = (d < 0) ? c1 : c2;
-				const unsigned word = (((unsigned)__ballot(d != 0) & 0xffffu) << 16) | ((unsigned)__ballot(d > 0) & 0xffffu);
-				wv[blk] = (lane == kk) ? word : wv[blk];           // (v_writelane cannot take two SGPRs on gfx9)
+		for (int r = 0; r < 4; r++) {
+			const float sym = (r == 0) ? fa.y : (r == 1) ? fa.z : (r == 2) ? fb.y : fb.z;   // imaginary part on even, real on odd steps
+			const int pmi = __float_as_int(pm);
+			int other;
+			if (r == 0)      other = __builtin_amdgcn_update_dpp(pmi, pmi, 0x128, 0xf, 0xf, false);   // row_ror:8   (l ^ 8)
+			else if (r == 1) {                                                                           // l ^ 4
+				other = __builtin_amdgcn_update_dpp(pmi, pmi, 0x104, 0xf, 0x5, false);                   // row_shl:4 into banks 0, 2
+				other = __builtin_amdgcn_update_dpp(other, pmi, 0x114, 0xf, 0xa, false);                 // row_shr:4 into banks 1, 3
 			}
+			else if (r == 2) other = __builtin_amdgcn_update_dpp(pmi, pmi, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1] (l ^ 2)
+			else             other = __builtin_amdgcn_update_dpp(pmi, pmi, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2] (l ^ 1)
+			const float po = __int_as_float(other);
+			const float o1 = oddr[r] ? po : pm, o2 = oddr[r] ? pm : po;
+			const float ss = __int_as_float(__float_as_int(sym) ^ (int)sflip[r]);
+			const float c1 = (o1 + ss) + a1[r];
+			const float c2 = (o2 + ss) + a2[r];
+			const float d = c2 - c1;
+			const float npm = (d < 0) ? c1 : c2;
+			pm = act ? npm : pm;
+			const unsigned long long pos = __ballot(d > 0), nz = __ballot(d != 0);
+			if (lane == 0)
+				words[k0 + r] = make_uint4((unsigned)pos, (unsigned)(pos >> 32), (unsigned)nz, (unsigned)(nz >> 32));
 		}
 	}
-	unsigned long long ones[3] = { 0ull, 0ull, 0ull };             // bit k of word k >> 6: output k is > 0
-	{
-		// best of the stop states {4, 12}; traceback with differential decoding (viterbi_detector.cc:340-392).
-		// out[k] = +-d with the sign flipped when decision != out_bit, so out[k] > 0 <=> out_bit && d != 0.
-		const float m4 = lane_val(pm, 4), m12 = lane_val(pm, 12);      // after a multiple of 4 steps lane l holds state l again
-		unsigned state = (m12 > m4) ? 12u : 4u;
-		unsigned out_bit = 0u, real_imag = (nbits & 1) ? 1u : 0u;  // type of the last step processed
-		// lane l of wv[blk] holds the word of step blk * 64 + l; the serial walk is scalar
+	wave_sync();
+
+	// ---- best of the stop states {4, 12}; traceback with differential decoding (viterbi_detector.cc:340-392), every
+	// lane of a row walking its row's path.  out[k] = +-d with the sign flipped when decision != out_bit, so
+	// out[k] > 0 <=> out_bit && d != 0.  After a multiple of 4 steps lane l of a row holds state l again.
+	const float m4 = __int_as_float(__builtin_amdgcn_ds_bpermute(((lane & ~15) | 4) << 2, __float_as_int(pm)));
+	const float m12 = __int_as_float(__builtin_amdgcn_ds_bpermute(((lane & ~15) | 12) << 2, __float_as_int(pm)));
+	unsigned state = (m12 > m4) ? 12u : 4u;
+	unsigned out_bit = 0u;
+	unsigned ones[5] = { 0u, 0u, 0u, 0u, 0u };                     // bit k & 31 of word k >> 5: output k is > 0
+	const bool hi_row = row >= 2;
+	const unsigned fsh = (row & 1) ? 16u : 0u;
 #pragma unroll
-		for (int blk = 2; blk >= 0; blk--) {
-			unsigned long long acc = 0ull;
-			const int hi = (nbits - 1 < blk * 64 + 63) ? nbits - 1 - blk * 64 : 63;
-			for (int kk = hi; kk >= 0; kk--) {
-				const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)wv[blk], kk);
-				// the bit of new state n at step k sits at lane rotr4^(k+1)(n); k = blk * 64 + kk and 64 = 0 mod 4
-				const unsigned rr = (unsigned)(kk + 1) & 3u;
-				const unsigned bit = ((state >> rr) | (state << (4u - rr))) & 15u;
-				const unsigned decision = (w >> bit) & 1u, nonzero = (w >> (16 + bit)) & 1u;
-				acc |= (unsigned long long)(out_bit & nonzero) << kk;
+	for (int wq = 4; wq >= 0; wq--) {
+		if (32 * wq >= nmax)
+			continue;
+		const int khi = (nmax - 1 < 32 * wq + 31) ? nmax - 1 - 32 * wq : 31;
+		unsigned acc = 0u;
+		for (int kk = khi; kk >= 0; kk--) {
+			const int k = 32 * wq + kk;
+			const uint4 wd = words[k];                             // wave-uniform address: a broadcast read
+			if (k < nbits_row) {
+				// type of step k: the last step processed is step nbits - 1 with real_imag = nbits & 1 = 0 (148 and 88 are
+				// even) and the flag alternates, so real_imag(k) = (nbits - 1 - k) & 1 = (k + 1) & 1
+				const unsigned real_imag = (unsigned)(k + 1) & 1u;
+				// the bit of new state n at step k sits at lane rotr4^(k+1)(n) of the row
+				const unsigned rr = (unsigned)(k + 1) & 3u;
+				const unsigned bit = (((state >> rr) | (state << (4u - rr))) & 15u) + fsh;
+				const unsigned pw = hi_row ? wd.y : wd.x, nw2 = hi_row ? wd.w : wd.z;
+				const unsigned decision = (pw >> bit) & 1u, nonzero = (nw2 >> bit) & 1u;
+				acc |= (out_bit & nonzero) << kk;
 				const unsigned parity = ((state >> 1) ^ state) & 1u;
 				out_bit = out_bit ^ real_imag ^ parity;
 				state = (state >> 1) + (decision << 3);
-				real_imag ^= 1u;
 			}
-			ones[blk] = acc;
 		}
+		ones[wq] = acc;
 	}
 
-	// ---- "pre flip" (:107), "* -1" (Transceiver.cpp:638), zeros behind the burst (:640-641); optional vectorSlicer
-	for (int i = lane; i < soft_stride; i += WAVE) {
-		float v = 0.0f;
-		if (i < nbits) {
-			const unsigned long long m = (i < 64) ? ones[0] : (i < 128) ? ones[1] : ones[2];
-			v = ((m >> (i & 63)) & 1ull) ? 127.0f : -127.0f;
+	// ---- "pre flip" (:107), "* -1" (Transceiver.cpp:638), zeros behind the burst (:640-641); optional vectorSlicer.
+	// Lane l of a row writes outputs l, l + 16, ... of its burst.
+	const unsigned bme = q0 + row;
+	if (bme < n_bursts && nbits_row > 0) {
+		float *so = soft + (size_t)bme * soft_stride;
+#pragma unroll
+		for (int t = 0; t < 10; t++) {                             // outputs 0 .. 159; bit (16 t + l4) of the 160-bit string
+			const int i = 16 * t + l4;
+			float v = 0.0f;
+			if (i < nbits_row)
+				v = ((ones[t >> 1] >> (16 * (t & 1) + l4)) & 1u) ? 127.0f : -127.0f;
+			if (slice & 1)
+				v = (i < 148) ? __builtin_amdgcn_fmed3f(0.5f * (v + 1.0f), 0.0f, 1.0f) : 0.0f;
+			if (i < soft_stride)
+				so[i] = v;
 		}
-		if (slice & 1)
-			v = (i < 148) ? __builtin_amdgcn_fmed3f(0.5f * (v + 1.0f), 0.0f, 1.0f) : 0.0f;
-		so[i] = v;
+		for (int i = 160 + l4; i < soft_stride; i += 16)
+			so[i] = (slice & 1) ? 0.0f : 0.0f;
+		if (starts && l4 == 0)
+			starts[bme] = mt.z;
 	}
-	if (starts && lane == 0)
-		starts[b] = start;
 }
 
 extern "C" size_t trx_va_lds_bytes(int L)
@@ -303,7 +351,8 @@ extern "C" int trx_launch_va_demod(const float *d_iq, const trxhip_burst_params 
 	if (lds > 160 * 1024)
 		return TRXHIP_EINVAL;
 	TRX_ARM_DYNAMIC_LDS(va_demod_kernel);
-	const size_t grid = (n_bursts + VA_WPB - 1) / VA_WPB;
+	const size_t per_block = VA_WPB * VA_BPW;
+	const size_t grid = (n_bursts + per_block - 1) / per_block;
 	hipLaunchKernelGGL(va_demod_kernel, dim3((unsigned)grid), dim3(VA_WPB * WAVE), lds, stream,
 			   reinterpret_cast<const c32 *>(d_iq), d_params, d_detected, d_soft, d_starts, (unsigned)n_bursts, L, scale, soft_stride,
 			   flags);
