@@ -29,14 +29,20 @@
 #define VA_NB 148
 #define VA_AB 88
 #define VA_FSTRIDE 152                 // c32 per burst of matched-filter output (148 + pad: read two symbols per ds_read_b128)
+// The scaled burst is kept in a POLYPHASE layout, xs[ph * XA + i / 4] = x[i] with ph = i % 4: the matched filter walks
+// the burst in steps of 4 samples per lane (one output symbol per lane), so consecutive lanes read consecutive words of
+// one phase array (the linear layout was an 8-way bank conflict: 32-byte lane stride), and the training-sequence
+// correlation (consecutive samples per lane) sees the four arrays 16 banks apart (XA = 8 mod 32).  Everything from x[L]
+// to the end of the arrays is zero, which replaces the reference's "j < L" checks, and the arrays reach the last sample
+// any stage can touch (start + 4 * 147 + 19 + 4 < 640) whatever L is.
+#define VA_XA(L) (((((L) > 640 ? (L) : 640) + 3) / 4 + 31) / 32 * 32 + 8)
 // per-wave LDS slice, every region 16-byte aligned:
-//   scratch of the burst in the front end: xs[xs_len] | corr[64] | cir[20] | seq[32] : c32;  power[64] : float
+//   scratch of the burst in the front end: xs[4][XA] | corr[64] | cir[20] | seq[32] : c32;  power[64] : float
 //   kept for the trellis, per burst:       filt[4][152] | rhh[4][8] : c32;  meta[4] : int4 {nbits, start state, start, -}
 //   decision words of the four trellises:  words[148] : uint4 {pos lo, pos hi, nz lo, nz hi} -- over xs[], which the
-//                                          front end no longer needs by then (the region holds at least 296 samples)
-#define VA_XS_CAP(xs_len) ((xs_len) > 296 ? (xs_len) : 296)
-#define VA_SLICE_BYTES(xs_len) ((size_t)(VA_XS_CAP(xs_len) + 64 + VA_FL + 32) * sizeof(c32) + 64 * sizeof(float) +                  \
-				(size_t)VA_BPW * (VA_FSTRIDE + 8) * sizeof(c32) + VA_BPW * 16)
+//                                          front end no longer needs by then
+#define VA_SLICE_BYTES(L) ((size_t)(4 * VA_XA(L) + 64 + VA_FL + 32) * sizeof(c32) + 64 * sizeof(float) +                  \
+			   (size_t)VA_BPW * (VA_FSTRIDE + 8) * sizeof(c32) + VA_BPW * 16)
 
 // The training sequences after gmsk_mapper() and conj() (grgsm_vitac.cpp:57-79, :122-145) are walks over
 // {1, j, -1, -j}: out[i] = (+-j) * out[i-1] from the start point 1 / -1 (normal burst, first bit 0 / 1) or -j (access),
@@ -44,11 +50,46 @@
 // estimate uses, i = 5 .. 20 of the 26 TSC bits and i = 5 .. 35 of the 41 access bits (TRAIN_BEGINNING = 5), element
 // k at bits 2k, 2k+1 -- computed from the 3GPP TS 45.002 bit strings by the same walk (tests compare with the oracle,
 // which maps the bits at run time).
-__constant__ unsigned int va_tsc_codes[8] = { 0x131319b9u, 0x9311b9b9u, 0x1913b3b3u, 0x191933b1u,
-					      0xbb191193u, 0x991b3391u, 0x139bb9b1u, 0x91933b31u };
+#define VA_TSC_CODES0 0x131319b9ull
+#define VA_TSC_CODES1 0x9311b9b9ull
+#define VA_TSC_CODES2 0x1913b3b3ull
+#define VA_TSC_CODES3 0x191933b1ull
+#define VA_TSC_CODES4 0xbb191193ull
+#define VA_TSC_CODES5 0x991b3391ull
+#define VA_TSC_CODES6 0x139bb9b1ull
+#define VA_TSC_CODES7 0x91933b31ull
 #define VA_ACC_CODES 0x464e4ccccc6c644ull
 
-__device__ __forceinline__ c32 va_cmul(c32 a, c32 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// correlate_sequence() (grgsm_vitac.cpp:147-155) for one lag: sum_ii seq[ii] * x[j0 + 4 ii], seq[ii] a quarter turn.
+// std::complex's a * b with a in {1, j, -1, -j} is b with its parts swapped / negated exactly (the products with 0 only
+// contribute +-0), so every term of the reference's sum is ONE v_pk_add_f32 whose op_sel / neg modifiers carry the
+// quarter turn (unit_mac<>, trx_device.h): code 0: (x, y), 1: (-y, x), 2: (-x, -y), 3: (y, -x).  p = the lane's address of
+// x[j0] inside its phase array: the taps are 4 samples = 1 entry apart.
+template <unsigned long long CODES, int N>
+__device__ __forceinline__ trx_v2f va_corr(const c32 *p)
+{
+	trx_v2f acc = { 0.0f, 0.0f };
+#pragma unroll
+	for (int k0 = 0; k0 < N; k0 += 8) {
+		c32 x[8];
+#pragma unroll
+		for (int u = 0; u < 8; u++)
+			if (k0 + u < N)
+				x[u] = lds_c32(p + k0 + u);
+#pragma unroll
+		for (int u = 0; u < 8; u++)
+			if (k0 + u < N) {
+				const unsigned c = (unsigned)((CODES >> (2 * (k0 + u))) & 3ull);
+				const trx_v2f xv = { x[u].x, x[u].y };
+				if (c == 0) acc = unit_mac<false, false>(acc, xv);
+				if (c == 1) acc = unit_mac<true, false>(acc, xv);
+				if (c == 2) acc = unit_mac<false, true>(acc, xv);
+				if (c == 3) acc = unit_mac<true, true>(acc, xv);
+			}
+		__builtin_amdgcn_sched_barrier(0);
+	}
+	return acc;
+}
 
 __global__ void __launch_bounds__(VA_WPB * WAVE)
 va_demod_kernel(const c32 *__restrict__ iq, const trxhip_burst_params *__restrict__ params,
@@ -58,18 +99,18 @@ va_demod_kernel(const c32 *__restrict__ iq, const trxhip_burst_params *__restric
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const int lane = threadIdx.x & (WAVE - 1);
 	const int wave = uni((int)(threadIdx.x >> 6));
-	const int xs_len = (L + 1) & ~1;
-	const size_t slice_bytes = VA_SLICE_BYTES(xs_len);
+	const int XA = uni(VA_XA(L));
+	const size_t slice_bytes = VA_SLICE_BYTES(L);
 	char *base = smem + (size_t)wave * slice_bytes;
-	c32 *xs = reinterpret_cast<c32 *>(base);
-	c32 *corr = xs + VA_XS_CAP(xs_len);
+	c32 *xs = reinterpret_cast<c32 *>(base);                       // polyphase: sample i at xs[(i & 3) * XA + (i >> 2)]
+	c32 *corr = xs + 4 * XA;
 	c32 *cir = corr + 64;
 	c32 *seq = cir + VA_FL;
 	float *power = reinterpret_cast<float *>(seq + 32);
 	c32 *filt_all = reinterpret_cast<c32 *>(power + 64);
 	c32 *rhh_all = filt_all + VA_BPW * VA_FSTRIDE;
 	int4 *meta = reinterpret_cast<int4 *>(rhh_all + VA_BPW * 8);
-	uint4 *words = reinterpret_cast<uint4 *>(xs);                  // 148 x 16 bytes over the first 296 samples of xs[]
+	uint4 *words = reinterpret_cast<uint4 *>(xs);                  // 148 x 16 bytes over the head of xs[] (4 * XA >= 672 entries)
 
 	const unsigned q0 = (blockIdx.x * VA_WPB + wave) * VA_BPW;     // first burst of this wave
 	if (q0 >= n_bursts)
@@ -103,38 +144,44 @@ va_demod_kernel(const c32 *__restrict__ iq, const trxhip_burst_params *__restric
 		const bool nb = (type == TRXHIP_TSC);                      // Transceiver.cpp:629: TSC, else the access branch
 		const int nbits = nb ? VA_NB : VA_AB;
 
-		// ---- scaleVector (sigProcLib.cpp:1198-1205): x * (scale, 0) with Complex.h:74's operand order
+		// ---- scaleVector (sigProcLib.cpp:1198-1205): x * (scale, 0).  Complex.h:74 evaluates (x.r*s - x.i*0, x.r*0 + x.i*s);
+		// the products with 0 are +-0 and only ever decide the sign of a zero result, which nothing downstream can see
+		// (sums, comparisons, |.|^2): two multiplies per sample instead of four and two additions.
 		const c32 *src = iq + (size_t)b * L;
-		for (int i = lane; i < L; i += WAVE)
-			xs[i] = va_cmul(src[i], make_float2(scale, 0.0f));
-
-		// ---- training sequence: element `lane` from its quarter-turn code
-		const int tlen = nb ? 26 : 41, tseqlen = tlen - 10;
-		if (lane < 32) {
-			const unsigned long long codes = nb ? (unsigned long long)va_tsc_codes[tsc] : VA_ACC_CODES;
-			const int qc = (int)((codes >> (2 * lane)) & 3ull);
-			seq[lane] = make_float2(qc == 0 ? 1.0f : qc == 2 ? -1.0f : 0.0f, qc == 1 ? 1.0f : qc == 3 ? -1.0f : 0.0f);
+		for (int i = lane; i < L; i += WAVE) {
+			const c32 v = src[i];
+			xs[(i & 3) * XA + (i >> 2)] = make_float2(v.x * scale, v.y * scale);
 		}
+		for (int i = L + lane; i < 4 * XA; i += WAVE)              // zero behind the burst (the reference's "j < L ? x[j] : 0")
+			xs[(i & 3) * XA + (i >> 2)] = make_float2(0.0f, 0.0f);
 		wave_sync();
 
 		// ---- get_chan_imp_resp (grgsm_vitac.cpp:183-232)
 		const int center = nb ? (3 + 58 + 5) : (8 + 5);
 		const int start_pos = (center - 5) * VA_OSR + 1, stop_pos = (center + 5 + VA_CIR) * VA_OSR;   // max_delay = 0 (:631)
 		const int nw = stop_pos - start_pos;                       // 59
-		if (lane < nw) {
-			float rr = 0.0f, ri = 0.0f;
-			for (int ii = 0; ii < tseqlen; ii++) {                 // correlate_sequence :147-155
-				const int j = start_pos + lane + ii * VA_OSR;
-				const c32 xv = (j < L) ? xs[j] : make_float2(0.0f, 0.0f);
-				const c32 t = va_cmul(seq[ii], xv);
-				rr += t.x;
-				ri += t.y;
+		{
+			const int j0 = start_pos + (lane < nw ? lane : 0);
+			const c32 *p = xs + (j0 & 3) * XA + (j0 >> 2);
+			trx_v2f r;
+			switch (nb ? tsc : 8) {                                // wave-uniform: one specialised loop per training sequence
+			case 0: r = va_corr<VA_TSC_CODES0, 16>(p); break;
+			case 1: r = va_corr<VA_TSC_CODES1, 16>(p); break;
+			case 2: r = va_corr<VA_TSC_CODES2, 16>(p); break;
+			case 3: r = va_corr<VA_TSC_CODES3, 16>(p); break;
+			case 4: r = va_corr<VA_TSC_CODES4, 16>(p); break;
+			case 5: r = va_corr<VA_TSC_CODES5, 16>(p); break;
+			case 6: r = va_corr<VA_TSC_CODES6, 16>(p); break;
+			case 7: r = va_corr<VA_TSC_CODES7, 16>(p); break;
+			default: r = va_corr<VA_ACC_CODES, 31>(p); break;
 			}
-			const float fl = (float)tseqlen;
-			const c32 c = make_float2(rr / fl, -ri / fl);          // conj(result) / (length + 0j)
-			corr[lane] = c;
-			const float h = (float)sqrt((double)c.x * (double)c.x + (double)c.y * (double)c.y);   // abs(): hypotf
-			power[lane] = (float)((double)h * (double)h);          // std::pow(float, int)
+			const float fl = nb ? 16.0f : 31.0f;                   // tseqlen = 26 - 10 / 41 - 10
+			const c32 c = make_float2(r.x / fl, -r.y / fl);        // conj(result) / (length + 0j)
+			if (lane < nw) {
+				corr[lane] = c;
+				const float h = (float)sqrt((double)c.x * (double)c.x + (double)c.y * (double)c.y);   // abs(): hypotf
+				power[lane] = (float)((double)h * (double)h);      // std::pow(float, int)
+			}
 		}
 		wave_sync();
 		// sliding 20-sample window energy (:199-214): ws = p[0] + ... + p[19], then ws += p[i] - p[i-20].  With q[i] = p[i]
@@ -159,32 +206,66 @@ va_demod_kernel(const c32 *__restrict__ iq, const trxhip_burst_params *__restric
 			cir[lane] = corr[best + lane];
 		int start = start_pos + best - center * VA_OSR;
 		if (start < 0) start = 0;                                  // Transceiver.cpp:631, :635
+		// the matched filter stops at sample start + 4 * nbits ("if (a + ii >= nbits * OSR) break", :99-100): the same
+		// condition for every output, i.e. the samples from there on do not exist -- zero them (adding +-0 changes no sum)
+		if (lane < VA_FL + 4) {
+			const int j = start + nbits * VA_OSR + lane;
+			xs[(j & 3) * XA + (j >> 2)] = make_float2(0.0f, 0.0f);
+		}
 		wave_sync();
 
-		// ---- detect_burst_generic (grgsm_vitac.cpp:82-108): rhh = conj(autocorrelation at multiples of 4), mafi
-		if (lane < VA_CIR) {
-			const int k = lane * VA_OSR;
-			float ar = 0.0f, ai = 0.0f;
-			for (int i = k; i < VA_FL; i++) {
-				const c32 t = va_cmul(cir[i], make_float2(cir[i - k].x, -cir[i - k].y));
-				ar += t.x;
-				ai += t.y;
+		// ---- detect_burst_generic (grgsm_vitac.cpp:82-108): rhh = conj(autocorrelation at multiples of 4), mafi.
+		// rhh[k] = conj(sum_{i >= 4k} cir[i] * conj(cir[i - 4k])): the products of one k in parallel (lane = i, zero for
+		// i < 4k: a leading +0 changes no sum), parked in this burst's filt[] (not written yet), then lane k adds its 20
+		// in order.
+		{
+#pragma unroll
+			for (int k = 0; k < VA_CIR; k++)
+				if (lane < VA_FL) {
+					c32 t = make_float2(0.0f, 0.0f);
+					if (lane >= k * VA_OSR) {
+						const c32 a = cir[lane], bb = cir[lane - k * VA_OSR];
+						t = cmul(a, make_float2(bb.x, -bb.y));
+					}
+					filt[k * VA_FL + lane] = t;
+				}
+			wave_sync();
+			if (lane < VA_CIR) {
+				float ar = 0.0f, ai = 0.0f;
+#pragma unroll
+				for (int i = 0; i < VA_FL; i++) {
+					const c32 t = filt[lane * VA_FL + i];
+					ar += t.x;
+					ai += t.y;
+				}
+				rhh[lane] = make_float2(ar, -ai);
 			}
-			rhh[lane] = make_float2(ar, -ai);
+			wave_sync();
 		}
-		for (int m = lane; m < nbits; m += WAVE) {
-			float ar = 0.0f, ai = 0.0f;
-			const int a = m * VA_OSR;
-			for (int ii = 0; ii < VA_FL; ii++) {
-				if (a + ii >= nbits * VA_OSR)
-					break;
-				const int j = start + a + ii;
-				const c32 xv = (j < L) ? xs[j] : make_float2(0.0f, 0.0f);
-				const c32 t = va_cmul(xv, cir[ii]);
-				ar += t.x;
-				ai += t.y;
+		{
+			// mafi: filt[m] = sum_{ii < 20} x[start + 4m + ii] * cir[ii]: tap ii of every lane is phase (start + ii) & 3,
+			// entry m + ((start + ii) >> 2) -- conflict-free, no range checks (zeros behind start + 4 nbits and behind L)
+			c32 hc[VA_FL];
+#pragma unroll
+			for (int ii = 0; ii < VA_FL; ii++)
+				hc[ii] = cir[ii];                                  // wave-uniform: broadcast reads, once per burst
+#pragma unroll
+			for (int rnd = 0; rnd < 3; rnd++) {
+				const int m = lane + rnd * WAVE;
+				if (rnd * WAVE < nbits) {                          // wave-uniform
+					const int mc = m < VA_NB ? m : VA_NB - 1;          // lanes past the last symbol recompute it (not stored)
+					trx_v2f acc = { 0.0f, 0.0f };
+#pragma unroll
+					for (int ii = 0; ii < VA_FL; ii++) {
+						const int sj = start + ii;
+						const c32 xv = lds_c32(xs + (sj & 3) * XA + (sj >> 2) + mc);
+						const c32 t = cmul(xv, hc[ii]);
+						acc = acc + (trx_v2f){ t.x, t.y };
+					}
+					if (m < nbits)
+						filt[m] = make_float2(acc.x, acc.y);
+				}
 			}
-			filt[m] = make_float2(ar, ai);
 		}
 		if (lane == 0)                                             // Transceiver.cpp:633: rach_max_toa as the start state
 			meta[qb] = make_int4(nbits, nb ? 3 : max_toa, start, 0);
@@ -337,8 +418,7 @@ va_demod_kernel(const c32 *__restrict__ iq, const trxhip_burst_params *__restric
 
 extern "C" size_t trx_va_lds_bytes(int L)
 {
-	const int xs_len = (L + 1) & ~1;
-	return VA_WPB * VA_SLICE_BYTES(xs_len);
+	return VA_WPB * VA_SLICE_BYTES(L);
 }
 
 extern "C" int trx_launch_va_demod(const float *d_iq, const trxhip_burst_params *d_params,
