@@ -79,7 +79,7 @@ __device__ __forceinline__ PhBase ph_bases(const c32 *P, int ph0, int m0)
 // waves: 378 -> 420 Mbursts/s; the kernel is latency bound per wave (profiles/).  Exact: 168 VGPRs.
 #define K4_WPB_FUSED 16
 #define K4_WPB_EXACT 16            // int16 input; the complex64-input exact kernel (20 prefetch registers) stays at 12
-#define K4_WPB(CF_, EX_) (((CF_) && (EX_)) ? 12 : 16)
+#define K4_WPB(CF_, EX_) ((CF_) ? 12 : 16)            // complex64 input (sigProcLib-signature calls): 20 prefetch registers
 
 template <bool CF32, bool EXACT>
 __global__ void __launch_bounds__(K4_WPB(CF32, EXACT) * WAVE)
@@ -611,22 +611,44 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 					DIAG_MARK(9);
 					wave_sync();
 
-					if (!is_edge) {
+					if (!is_edge && soft_stride >= 2 * WAVE) {
+						// symbols lane, lane + 64, lane + 128: the first two always exist and are always stored (rows of 128
+						// floats or more: 148 / 156 / 444 in practice), only the third needs its range checks; one pointer per lane
+						float *const sp = so + lane;
+						const c32 *const dp = dec + lane, *const rp = rrot + lane;
+#pragma unroll
+						for (int r = 0; r < 3; r++) {
+							const int i = lane + r * WAVE;
+							const int off = (r < 2 || lane < 32) ? r * WAVE : 159 - lane;    // symbol 128 + lane, capped at entry 159
+							const c32 d = dp[off];
+							const c32 rr = rp[off];
+							float sv = rr.x * d.x - rr.y * d.y;                     // real(rot * x)  (:2066-2068)
+							if (slice & 1)
+								sv = __builtin_amdgcn_fmed3f(0.5f * (sv + 1.0f), 0.0f, 1.0f);
+							if (r < 2) {
+								sp[r * WAVE] = sv;
+							} else {
+								sv = (i < nwrite) ? sv : 0.0f;
+								if (i < soft_stride)
+									sp[2 * WAVE] = sv;
+							}
+						}
+						for (int i = lane + 3 * WAVE; i < soft_stride; i += WAVE) // soft_stride > 192: zero tail
+							so[i] = 0.0f;
+					} else if (!is_edge) {                                          // short rows: truncated to soft_stride
 #pragma unroll
 						for (int r = 0; r < 3; r++) {
 							const int i = lane + r * WAVE;
 							const int ii = i < 159 ? i : 159;
 							const c32 d = dec[ii];
 							const c32 rr = rrot[ii];
-							float sv = rr.x * d.x - rr.y * d.y;                     // real(rot * x)  (:2066-2068)
+							float sv = rr.x * d.x - rr.y * d.y;
 							if (slice & 1)
 								sv = __builtin_amdgcn_fmed3f(0.5f * (sv + 1.0f), 0.0f, 1.0f);
 							sv = (i < nwrite) ? sv : 0.0f;
 							if (i < soft_stride)
 								so[i] = sv;
 						}
-						for (int i = lane + 3 * WAVE; i < soft_stride; i += WAVE) // soft_stride > 192: zero tail
-							so[i] = 0.0f;
 					}
 				}
 				if (is_edge) {

@@ -462,3 +462,15 @@ def test_full_size_mixed(trx):
     o_res, o_soft = O.pull_batch(iq[tsel].cpu().numpy(), 4, params[sel])
     check_parity(r[sel], soft[tsel].cpu().numpy(), o_res, o_soft, soft_atol=FUSED_SOFT_ATOL)
     check_parity(trx.results_to_numpy(res_x)[sel], soft_x[tsel].cpu().numpy(), o_res, o_soft)
+
+
+@pytest.mark.parametrize("stride", [64, 100, 130, 200])
+def test_soft_rows_shorter_and_longer_than_a_burst(trx, stride):
+    """include/trxhip.h: "the row is truncated to soft_stride"; unused tail zero-filled.  Both demodulators."""
+    from osmo_trx_amd import synth
+    iq, params, _ = synth.make_normal_bursts(512, "cpu", 4, seed=91)
+    o_res, o_soft = O.pull_batch(iq.numpy(), 4, params, soft_stride=stride)
+    for exact in (True, False):
+        g_res, g_soft = run_gpu(trx, iq, params, 4, soft_stride=stride, exact=exact)
+        check_parity(g_res, g_soft, o_res, o_soft, soft_atol=0.0 if exact else FUSED_SOFT_ATOL)
+    assert not o_soft[:, 148:].any()
