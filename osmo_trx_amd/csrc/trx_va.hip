@@ -28,7 +28,8 @@
 #define VA_FL (VA_CIR * VA_OSR)
 #define VA_NB 148
 #define VA_AB 88
-#define VA_FSTRIDE 152                 // c32 per burst of matched-filter output (148 + pad: read two symbols per ds_read_b128)
+#define VA_FSTRIDE 152                 // floats per burst of trellis input symbols (148 + pad): the imaginary part of matched-filter
+                                       // output k for even k, the real part for odd k -- all the trellis reads (one ds_read_b128 per 4 steps)
 // The scaled burst is kept in a POLYPHASE layout, xs[ph * XA + i / 4] = x[i] with ph = i % 4: the matched filter walks
 // the burst in steps of 4 samples per lane (one output symbol per lane), so consecutive lanes read consecutive words of
 // one phase array (the linear layout was an 8-way bank conflict: 32-byte lane stride), and the training-sequence
@@ -38,11 +39,11 @@
 #define VA_XA(L) (((((L) > 640 ? (L) : 640) + 3) / 4 + 31) / 32 * 32 + 8)
 // per-wave LDS slice, every region 16-byte aligned:
 //   scratch of the burst in the front end: xs[4][XA] | corr[64] | cir[20] | seq[32] : c32;  power[64] : float
-//   kept for the trellis, per burst:       filt[4][152] | rhh[4][8] : c32;  meta[4] : int4 {nbits, start state, start, -}
+//   kept for the trellis, per burst:       sym[4][152] : float | rhh[4][8] : c32;  meta[4] : int4 {nbits, start state, start, -}
 //   decision words of the four trellises:  words[148] : uint4 {pos lo, pos hi, nz lo, nz hi} -- over xs[], which the
 //                                          front end no longer needs by then
 #define VA_SLICE_BYTES(L) ((size_t)(4 * VA_XA(L) + 64 + VA_FL + 32) * sizeof(c32) + 64 * sizeof(float) +                  \
-			   (size_t)VA_BPW * (VA_FSTRIDE + 8) * sizeof(c32) + VA_BPW * 16)
+			   (size_t)VA_BPW * (VA_FSTRIDE * sizeof(float) + 8 * sizeof(c32)) + VA_BPW * 16)
 
 // The training sequences after gmsk_mapper() and conj() (grgsm_vitac.cpp:57-79, :122-145) are walks over
 // {1, j, -1, -j}: out[i] = (+-j) * out[i-1] from the start point 1 / -1 (normal burst, first bit 0 / 1) or -j (access),
@@ -107,8 +108,9 @@ va_demod_kernel(const c32 *__restrict__ iq, const trxhip_burst_params *__restric
 	c32 *cir = corr + 64;
 	c32 *seq = cir + VA_FL;
 	float *power = reinterpret_cast<float *>(seq + 32);
-	c32 *filt_all = reinterpret_cast<c32 *>(power + 64);
-	c32 *rhh_all = filt_all + VA_BPW * VA_FSTRIDE;
+	c32 *prod = seq;                                               // 64 c32 over seq[] + power[]: the autocorrelation products
+	float *sym_all = power + 64;
+	c32 *rhh_all = reinterpret_cast<c32 *>(sym_all + VA_BPW * VA_FSTRIDE);
 	int4 *meta = reinterpret_cast<int4 *>(rhh_all + VA_BPW * 8);
 	uint4 *words = reinterpret_cast<uint4 *>(xs);                  // 148 x 16 bytes over the head of xs[] (4 * XA >= 672 entries)
 
@@ -119,7 +121,7 @@ va_demod_kernel(const c32 *__restrict__ iq, const trxhip_burst_params *__restric
 	// =================== front end, one burst at a time (all 64 lanes) ===================
 	for (int qb = 0; qb < VA_BPW; qb++) {
 		const unsigned b = q0 + qb;
-		c32 *filt = filt_all + qb * VA_FSTRIDE;
+		float *sym = sym_all + qb * VA_FSTRIDE;
 		c32 *rhh = rhh_all + qb * 8;
 		if (b >= n_bursts) {                                       // batch tail: an idle row
 			if (lane == 0) meta[qb] = make_int4(0, 0, -1, 0);
@@ -215,56 +217,62 @@ va_demod_kernel(const c32 *__restrict__ iq, const trxhip_burst_params *__restric
 		wave_sync();
 
 		// ---- detect_burst_generic (grgsm_vitac.cpp:82-108): rhh = conj(autocorrelation at multiples of 4), mafi.
-		// rhh[k] = conj(sum_{i >= 4k} cir[i] * conj(cir[i - 4k])): the products of one k in parallel (lane = i, zero for
-		// i < 4k: a leading +0 changes no sum), parked in this burst's filt[] (not written yet), then lane k adds its 20
-		// in order.
+		// rhh[k] = conj(sum_{i >= 4k} cir[i] * conj(cir[i - 4k])): the 60 products in parallel (segment k = 20 - 4k of them,
+		// parked over seq[] / power[], both dead by now), then lane k adds its segment in order.
 		{
 #pragma unroll
 			for (int k = 0; k < VA_CIR; k++)
-				if (lane < VA_FL) {
-					c32 t = make_float2(0.0f, 0.0f);
-					if (lane >= k * VA_OSR) {
-						const c32 a = cir[lane], bb = cir[lane - k * VA_OSR];
-						t = cmul(a, make_float2(bb.x, -bb.y));
-					}
-					filt[k * VA_FL + lane] = t;
+				if (lane >= k * VA_OSR && lane < VA_FL) {
+					const c32 a = cir[lane], bb = cir[lane - k * VA_OSR];
+					prod[(20 * k - 2 * k * (k - 1)) + lane - k * VA_OSR] = cmul(a, make_float2(bb.x, -bb.y));   // offsets 0, 20, 36, 48, 56
 				}
 			wave_sync();
 			if (lane < VA_CIR) {
+				const int seg = 20 * lane - 2 * lane * (lane - 1), len = VA_FL - VA_OSR * lane;
 				float ar = 0.0f, ai = 0.0f;
 #pragma unroll
-				for (int i = 0; i < VA_FL; i++) {
-					const c32 t = filt[lane * VA_FL + i];
-					ar += t.x;
-					ai += t.y;
-				}
+				for (int i = 0; i < VA_FL; i++)
+					if (i < len) {
+						const c32 t = prod[seg + i];
+						ar += t.x;
+						ai += t.y;
+					}
 				rhh[lane] = make_float2(ar, -ai);
 			}
 			wave_sync();
 		}
 		{
 			// mafi: filt[m] = sum_{ii < 20} x[start + 4m + ii] * cir[ii]: tap ii of every lane is phase (start + ii) & 3,
-			// entry m + ((start + ii) >> 2) -- conflict-free, no range checks (zeros behind start + 4 nbits and behind L)
-			c32 hc[VA_FL];
+			// entry m + ((start + ii) >> 2) -- conflict-free, no range checks (zeros behind start + 4 nbits and behind L).
+			// Taps in two halves of ten (registers), the three symbol rounds inside: every output still adds ii = 0 .. 19
+			// in order.  Only one part of each output feeds the trellis: imaginary for even symbols, real for odd ones.
+			trx_v2f acc[3] = { { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f } };
 #pragma unroll
-			for (int ii = 0; ii < VA_FL; ii++)
-				hc[ii] = cir[ii];                                  // wave-uniform: broadcast reads, once per burst
+			for (int half = 0; half < 2; half++) {
+				c32 hc[VA_FL / 2];
+#pragma unroll
+				for (int u = 0; u < VA_FL / 2; u++)
+					hc[u] = cir[half * (VA_FL / 2) + u];           // wave-uniform: broadcast reads
+#pragma unroll
+				for (int rnd = 0; rnd < 3; rnd++) {
+					if (rnd * WAVE < nbits) {                      // wave-uniform
+						const int m = lane + rnd * WAVE;
+						const int mc = m < VA_NB ? m : VA_NB - 1;      // lanes past the last symbol recompute it (not stored)
+#pragma unroll
+						for (int u = 0; u < VA_FL / 2; u++) {
+							const int sj = start + half * (VA_FL / 2) + u;
+							const c32 xv = lds_c32(xs + (sj & 3) * XA + (sj >> 2) + mc);
+							const c32 t = cmul(xv, hc[u]);
+							acc[rnd] = acc[rnd] + (trx_v2f){ t.x, t.y };
+						}
+					}
+				}
+			}
 #pragma unroll
 			for (int rnd = 0; rnd < 3; rnd++) {
 				const int m = lane + rnd * WAVE;
-				if (rnd * WAVE < nbits) {                          // wave-uniform
-					const int mc = m < VA_NB ? m : VA_NB - 1;          // lanes past the last symbol recompute it (not stored)
-					trx_v2f acc = { 0.0f, 0.0f };
-#pragma unroll
-					for (int ii = 0; ii < VA_FL; ii++) {
-						const int sj = start + ii;
-						const c32 xv = lds_c32(xs + (sj & 3) * XA + (sj >> 2) + mc);
-						const c32 t = cmul(xv, hc[ii]);
-						acc = acc + (trx_v2f){ t.x, t.y };
-					}
-					if (m < nbits)
-						filt[m] = make_float2(acc.x, acc.y);
-				}
+				if (m < nbits)
+					sym[m] = (m & 1) ? acc[rnd].x : acc[rnd].y;
 			}
 		}
 		if (lane == 0)                                             // Transceiver.cpp:633: rach_max_toa as the start state
@@ -281,7 +289,7 @@ va_demod_kernel(const c32 *__restrict__ iq, const trxhip_burst_params *__restric
 	const int row = lane >> 4, l4 = lane & 15;
 	const int4 mt = meta[row];
 	const int nbits_row = mt.x;
-	const c32 *myfilt = filt_all + row * VA_FSTRIDE;
+	const float *mysym = sym_all + row * VA_FSTRIDE;
 	const c32 *rhh = rhh_all + row * 8;
 	float inc[8];
 	{
@@ -325,13 +333,14 @@ va_demod_kernel(const c32 *__restrict__ iq, const trxhip_burst_params *__restric
 	// Only two bits of every path-metric difference survive into the +-127 output: d > 0 (the decision) and d != 0
 	// (an output of +-0 is "not > 0").  Per step the 64 lanes' bits are two ballot words (row r = bits 16r .. 16r + 15,
 	// bit l = the new state rotl4^(k+1)(l)), parked in LDS for the traceback.
+	float4 f4 = *reinterpret_cast<const float4 *>(mysym);          // symbols 0 .. 3 of this row's burst
 	for (int k0 = 0; k0 < nmax; k0 += 4) {                         // 148 and 88 are multiples of 4
-		const float4 fa = *reinterpret_cast<const float4 *>(myfilt + k0);         // symbols k0, k0 + 1
-		const float4 fb = *reinterpret_cast<const float4 *>(myfilt + k0 + 2);     // symbols k0 + 2, k0 + 3
+		const float4 fc = f4;
+		f4 = *reinterpret_cast<const float4 *>(mysym + k0 + 4);    // next group in flight while this one runs (pad: 152 entries)
 		const bool act = k0 < nbits_row;                           // this row's burst is still running (rows may differ in length)
 #pragma unroll
 		for (int r = 0; r < 4; r++) {
-			const float sym = (r == 0) ? fa.y : (r == 1) ? fa.z : (r == 2) ? fb.y : fb.z;   // imaginary part on even, real on odd steps
+			const float sym = (r == 0) ? fc.x : (r == 1) ? fc.y : (r == 2) ? fc.z : fc.w;
 			const int pmi = __float_as_int(pm);
 			int other;
 			if (r == 0)      other = __builtin_amdgcn_update_dpp(pmi, pmi, 0x128, 0xf, 0xf, false);   // row_ror:8   (l ^ 8)
@@ -372,9 +381,11 @@ va_demod_kernel(const c32 *__restrict__ iq, const trxhip_burst_params *__restric
 			continue;
 		const int khi = (nmax - 1 < 32 * wq + 31) ? nmax - 1 - 32 * wq : 31;
 		unsigned acc = 0u;
+		uint4 wnext = words[32 * wq + khi];                        // wave-uniform address: a broadcast read, one step ahead
 		for (int kk = khi; kk >= 0; kk--) {
 			const int k = 32 * wq + kk;
-			const uint4 wd = words[k];                             // wave-uniform address: a broadcast read
+			const uint4 wd = wnext;
+			wnext = words[k > 0 ? k - 1 : 0];
 			if (k < nbits_row) {
 				// type of step k: the last step processed is step nbits - 1 with real_imag = nbits & 1 = 0 (148 and 88 are
 				// even) and the flag alternates, so real_imag(k) = (nbits - 1 - k) & 1 = (k + 1) & 1
