@@ -177,8 +177,8 @@ va_demod_kernel(const c32 *__restrict__ iq, const trxhip_burst_params *__restric
 			case 7: r = va_corr<VA_TSC_CODES7, 16>(p); break;
 			default: r = va_corr<VA_ACC_CODES, 31>(p); break;
 			}
-			const float fl = nb ? 16.0f : 31.0f;                   // tseqlen = 26 - 10 / 41 - 10
-			const c32 c = make_float2(r.x / fl, -r.y / fl);        // conj(result) / (length + 0j)
+			// conj(result) / (length + 0j), length = tseqlen = 26 - 10 / 41 - 10: a division by 16 is an exact scaling
+			const c32 c = nb ? make_float2(r.x * 0.0625f, -r.y * 0.0625f) : make_float2(r.x / 31.0f, -r.y / 31.0f);
 			if (lane < nw) {
 				corr[lane] = c;
 				const float h = (float)sqrt((double)c.x * (double)c.x + (double)c.y * (double)c.y);   // abs(): hypotf
@@ -338,6 +338,7 @@ va_demod_kernel(const c32 *__restrict__ iq, const trxhip_burst_params *__restric
 		const float4 fc = f4;
 		f4 = *reinterpret_cast<const float4 *>(mysym + k0 + 4);    // next group in flight while this one runs (pad: 152 entries)
 		const bool act = k0 < nbits_row;                           // this row's burst is still running (rows may differ in length)
+		unsigned long long posw[4], nzw[4];
 #pragma unroll
 		for (int r = 0; r < 4; r++) {
 			const float sym = (r == 0) ? fc.x : (r == 1) ? fc.y : (r == 2) ? fc.z : fc.w;
@@ -358,9 +359,13 @@ va_demod_kernel(const c32 *__restrict__ iq, const trxhip_burst_params *__restric
 			const float d = c2 - c1;
 			const float npm = (d < 0) ? c1 : c2;
 			pm = act ? npm : pm;
-			const unsigned long long pos = __ballot(d > 0), nz = __ballot(d != 0);
-			if (lane == 0)
-				words[k0 + r] = make_uint4((unsigned)pos, (unsigned)(pos >> 32), (unsigned)nz, (unsigned)(nz >> 32));
+			posw[r] = __ballot(d > 0);
+			nzw[r] = __ballot(d != 0);
+		}
+		if (lane == 0) {                                           // one masked block per four steps
+#pragma unroll
+			for (int r = 0; r < 4; r++)
+				words[k0 + r] = make_uint4((unsigned)posw[r], (unsigned)(posw[r] >> 32), (unsigned)nzw[r], (unsigned)(nzw[r] >> 32));
 		}
 	}
 	wave_sync();
