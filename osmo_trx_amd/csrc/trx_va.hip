@@ -150,9 +150,13 @@ va_demod_kernel(const c32 *__restrict__ iq, const trxhip_burst_params *__restric
 		// the products with 0 are +-0 and only ever decide the sign of a zero result, which nothing downstream can see
 		// (sums, comparisons, |.|^2): two multiplies per sample instead of four and two additions.
 		const c32 *src = iq + (size_t)b * L;
-		for (int i = lane; i < L; i += WAVE) {
-			const c32 v = src[i];
-			xs[(i & 3) * XA + (i >> 2)] = make_float2(v.x * scale, v.y * scale);
+		{
+			// sample lane + 64 r: phase lane & 3, entry (lane >> 2) + 16 r -- one address per lane, immediate offsets
+			c32 *xp = xs + (lane & 3) * XA + (lane >> 2);
+			for (int i = lane, r = 0; i < L; i += WAVE, r++) {
+				const c32 v = src[i];
+				xp[16 * r] = make_float2(v.x * scale, v.y * scale);
+			}
 		}
 		for (int i = L + lane; i < 4 * XA; i += WAVE)              // zero behind the burst (the reference's "j < L ? x[j] : 0")
 			xs[(i & 3) * XA + (i >> 2)] = make_float2(0.0f, 0.0f);
@@ -258,10 +262,15 @@ va_demod_kernel(const c32 *__restrict__ iq, const trxhip_burst_params *__restric
 					if (rnd * WAVE < nbits) {                      // wave-uniform
 						const int m = lane + rnd * WAVE;
 						const int mc = m < VA_NB ? m : VA_NB - 1;      // lanes past the last symbol recompute it (not stored)
+						// sample start + 4 mc + ii: phase (start + ii) & 3; four per-lane bases, then immediate offsets
+						const c32 *pb[4];
+#pragma unroll
+						for (int k = 0; k < 4; k++)
+							pb[k] = xs + ((start + k) & 3) * XA + ((start + k) >> 2) + mc;
 #pragma unroll
 						for (int u = 0; u < VA_FL / 2; u++) {
-							const int sj = start + half * (VA_FL / 2) + u;
-							const c32 xv = lds_c32(xs + (sj & 3) * XA + (sj >> 2) + mc);
+							const int ii = half * (VA_FL / 2) + u;
+							const c32 xv = lds_c32(pb[ii & 3] + (ii >> 2));
 							const c32 t = cmul(xv, hc[u]);
 							acc[rnd] = acc[rnd] + (trx_v2f){ t.x, t.y };
 						}
@@ -375,35 +384,37 @@ va_demod_kernel(const c32 *__restrict__ iq, const trxhip_burst_params *__restric
 	// out[k] > 0 <=> out_bit && d != 0.  After a multiple of 4 steps lane l of a row holds state l again.
 	const float m4 = __int_as_float(__builtin_amdgcn_ds_bpermute(((lane & ~15) | 4) << 2, __float_as_int(pm)));
 	const float m12 = __int_as_float(__builtin_amdgcn_ds_bpermute(((lane & ~15) | 12) << 2, __float_as_int(pm)));
-	unsigned state = (m12 > m4) ? 12u : 4u;
-	unsigned out_bit = 0u;
+	// The walk tracks, instead of the state s_k, the LANE of the row that produced s_k's decision at step k,
+	// l_k = rotr4^(k+1)(s_k) (new state n of step k sits at lane rotr4^(k+1)(n)): s_(k-1) = (s_k >> 1) + (decision << 3) is
+	// rotr4(s_k) with bit 3 replaced by the decision, hence l_(k-1) = l_k with bit q = (3 - k) & 3 replaced by it -- no
+	// rotation per step; bits 0 and 1 of s_k (its parity) sit at bits q and (q + 1) & 3 of l_k.  nbits = 0 mod 4: l = s at
+	// the start.  The row's 16 decision / non-zero bits of step k are the u16 at bytes 2 row / 8 + 2 row of words[k].
+	unsigned ln = (m12 > m4) ? 12u : 4u;
+	unsigned out_bit = 0u;                                         // only bit 0 is meaningful (masked by `nonzero` where used)
 	unsigned ones[5] = { 0u, 0u, 0u, 0u, 0u };                     // bit k & 31 of word k >> 5: output k is > 0
-	const bool hi_row = row >= 2;
-	const unsigned fsh = (row & 1) ? 16u : 0u;
+	const unsigned short *w16 = reinterpret_cast<const unsigned short *>(words) + row;
 #pragma unroll
 	for (int wq = 4; wq >= 0; wq--) {
 		if (32 * wq >= nmax)
 			continue;
 		const int khi = (nmax - 1 < 32 * wq + 31) ? nmax - 1 - 32 * wq : 31;
 		unsigned acc = 0u;
-		uint4 wnext = words[32 * wq + khi];                        // wave-uniform address: a broadcast read, one step ahead
+		unsigned pnext = w16[8 * (32 * wq + khi)], nnext = w16[8 * (32 * wq + khi) + 4];   // one step ahead
 		for (int kk = khi; kk >= 0; kk--) {
 			const int k = 32 * wq + kk;
-			const uint4 wd = wnext;
-			wnext = words[k > 0 ? k - 1 : 0];
+			const unsigned pw = pnext, nw2 = nnext;
+			const int kp = k > 0 ? k - 1 : 0;
+			pnext = w16[8 * kp];
+			nnext = w16[8 * kp + 4];
 			if (k < nbits_row) {
 				// type of step k: the last step processed is step nbits - 1 with real_imag = nbits & 1 = 0 (148 and 88 are
 				// even) and the flag alternates, so real_imag(k) = (nbits - 1 - k) & 1 = (k + 1) & 1
 				const unsigned real_imag = (unsigned)(k + 1) & 1u;
-				// the bit of new state n at step k sits at lane rotr4^(k+1)(n) of the row
-				const unsigned rr = (unsigned)(k + 1) & 3u;
-				const unsigned bit = (((state >> rr) | (state << (4u - rr))) & 15u) + fsh;
-				const unsigned pw = hi_row ? wd.y : wd.x, nw2 = hi_row ? wd.w : wd.z;
-				const unsigned decision = (pw >> bit) & 1u, nonzero = (nw2 >> bit) & 1u;
+				const unsigned q = (unsigned)(3 - k) & 3u, q1 = (q + 1u) & 3u;
+				const unsigned decision = (pw >> ln) & 1u, nonzero = (nw2 >> ln) & 1u;
 				acc |= (out_bit & nonzero) << kk;
-				const unsigned parity = ((state >> 1) ^ state) & 1u;
-				out_bit = out_bit ^ real_imag ^ parity;
-				state = (state >> 1) + (decision << 3);
+				out_bit = out_bit ^ real_imag ^ (ln >> q) ^ (ln >> q1);
+				ln = (ln & ~(1u << q)) | (decision << q);
 			}
 		}
 		ones[wq] = acc;
