@@ -104,6 +104,14 @@ __device__ __forceinline__ float lane_val(float v, int l)
 	return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), __builtin_amdgcn_readfirstlane(l)));
 }
 
+// v_writelane_b32: the wave-uniform value `sval` into lane LANE of `word`, the other lanes untouched
+template <int LANE>
+__device__ __forceinline__ int write_lane(int word, int sval)
+{
+	asm("v_writelane_b32 %0, %1, %2" : "+v"(word) : "s"(__builtin_amdgcn_readfirstlane(sval)), "n"(LANE));
+	return word;
+}
+
 // DPP move: lanes without a valid source keep their own value
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp(float v)
@@ -209,6 +217,19 @@ __device__ __forceinline__ trx_v2f pk_fma_tap(trx_v2f x, trx_v2f hpair, trx_v2f 
 	else
 		asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(x), "v"(hpair));
 	return acc;
+}
+
+// x * h for a complex x and a real tap h that is element HI of a 64-bit register pair: one v_pk_mul_f32 with the tap
+// selected by op_sel (the compiler spends a v_mov on every odd tap); the product is rounded as the reference's is
+template <int HI>
+__device__ __forceinline__ trx_v2f pk_mul_tap(trx_v2f x, trx_v2f hpair)
+{
+	trx_v2f r;
+	if (HI)
+		asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(x), "v"(hpair));
+	else
+		asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(r) : "v"(x), "v"(hpair));
+	return r;
 }
 
 // Complex.h:113 norm2(): i*i + r*r

@@ -209,11 +209,11 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 				else v = make_float2((float)(int16_t)(pre_i[r] & 0xffffu), (float)(int16_t)(pre_i[r] >> 16));
 				pload[16 * r] = v;
 				amax = fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y)));
-				if (r < 5)                                          // samples 4i, i < 80 (:1576-1584)
-					if ((lane & 3) == 0)
-						epart += norm2(v);
+				if (r < 5)                                          // samples 4i, i < 80 (:1576-1584); masked to lane % 4 == 0 below
+					epart = fmaf(v.x, v.x, fmaf(v.y, v.y, epart));      // (tree-summed anyway: tolerance 3e-6, not an ordered sum)
 			}
 		}
+		epart = (lane & 3) ? 0.0f : epart;
 		DIAG_MARK(14);
 		if (b + total_waves < n_bursts)
 			prefetch(b + total_waves);
@@ -270,15 +270,17 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 					__builtin_assume(len >= 16 && len <= 49);
 					{
 						const c32 *pd = P + PH_M0 + (56 + lane) - 4;
-						float yr = 0.0f, yi = 0.0f;
+						const float4 *g4 = reinterpret_cast<const float4 *>(gdec);
+						v2f ya = { 0.0f, 0.0f };
 #pragma unroll
 						for (int k = 0; k < 16; k++) {
 							const c32 x = lds_c32(pd + ((k + 1) & 3) * PH_A + ((k + 1) >> 2));
-							const float g = gdec[k];
-							yr += x.x * g;
-							yi += x.y * g;
+							const float4 gq = g4[k >> 2];
+							const v2f gp = (k & 2) ? (v2f){ gq.z, gq.w } : (v2f){ gq.x, gq.y };
+							const v2f xv = { x.x, x.y };
+							ya = ya + ((k & 1) ? pk_mul_tap<1>(xv, gp) : pk_mul_tap<0>(xv, gp));   // y += x * g[k]: product, then sum
 						}
-						const c32 y = make_float2(yr, yi);
+						const c32 y = make_float2(ya.x, ya.y);
 						dec[56 + lane] = y;
 						unit_bad |= (__ballot(unit_unsafe(y) && lane < 15 + len) != 0ull) ? 1 : 0;
 						wave_sync();
@@ -664,19 +666,21 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 		}
 
 		DIAG_MARK(11);
-		// ---- result record: 32 bytes, one dword per lane 0..7
-		if (lane < 8) {
+		// ---- result record: 32 bytes, one dword per lane 0..7.  Every field is wave-uniform: v_writelane drops it into
+		// its lane (one instruction per field instead of a compare and a select)
+		{
 			const bool det = rc > 0;
-			uint32_t word = (uint32_t)rc;
-			word = (lane == 1) ? __float_as_uint(det ? toa : 0.0f) : word;
-			word = (lane == 2) ? __float_as_uint(det ? amp.x : 0.0f) : word;
-			word = (lane == 3) ? __float_as_uint(det ? amp.y : 0.0f) : word;
-			word = (lane == 4) ? __float_as_uint(det ? ci : 0.0f) : word;
-			word = (lane == 5) ? __float_as_uint(energy) : word;
-			word = (lane == 6) ? __float_as_uint(rssi) : word;
-			word = (lane == 7) ? ((uint32_t)(det ? out_tsc : 0) | ((uint32_t)clip << 8) | ((uint32_t)idle << 16) |
-					      ((uint32_t)(nbits / 4) << 24)) : word;
-			reinterpret_cast<uint32_t *>(results + b)[lane] = word;
+			const uint32_t flags = (uint32_t)(det ? out_tsc : 0) | ((uint32_t)clip << 8) | ((uint32_t)idle << 16) | ((uint32_t)(nbits / 4) << 24);
+			int word = rc;
+			word = write_lane<1>(word, __float_as_int(det ? toa : 0.0f));
+			word = write_lane<2>(word, __float_as_int(det ? amp.x : 0.0f));
+			word = write_lane<3>(word, __float_as_int(det ? amp.y : 0.0f));
+			word = write_lane<4>(word, __float_as_int(det ? ci : 0.0f));
+			word = write_lane<5>(word, __float_as_int(energy));
+			word = write_lane<6>(word, __float_as_int(rssi));
+			word = write_lane<7>(word, (int)flags);
+			if (lane < 8)
+				reinterpret_cast<int *>(results + b)[lane] = word;
 		}
 		DIAG_MARK(12);
 	}
