@@ -131,3 +131,17 @@ int caller(complex *buf, float *out)            /* the calls of pullRadioVector(
         defined = set(nm(SHIM, "-D", "--defined-only"))
         for s in wanted:
             assert s in defined, s
+
+
+def test_reference_vector_test_against_standalone_header(tmp_path):
+    """The reference's own tests/CommonLibs/VectorTest.cpp, compiled unmodified from where it lies against the stand-alone
+    look-alike Vector.h (host/compat), prints the reference's VectorTest.ok (kept as tests/golden/VectorTest.ok): the
+    aliasing / ownership behaviour of the stand-alone container type is the reference's (row a2)."""
+    src = os.path.join(REF, "tests", "CommonLibs", "VectorTest.cpp")
+    if not os.path.exists(src):
+        pytest.skip("needs /root/reference (container only)")
+    exe = str(tmp_path / "VectorTest")
+    subprocess.check_call(["g++", "-std=gnu++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "osmo_trx_amd", "host", "compat"),
+                           "-o", exe, src])
+    out = subprocess.run([exe], stdout=subprocess.PIPE, text=True, check=True).stdout
+    assert out == open(os.path.join(ROOT, "tests", "golden", "VectorTest.ok")).read()
