@@ -183,64 +183,157 @@ extern "C" int trx_launch_convolve(const float *d_x, int x_len, const float *d_h
 //   y_p[T] = sum_k xp[T-15+k] * sub_p[k]   with the previous block as history   (:86-94)
 //   X_c[T] = 4-point forward DFT over p of y_p[T]                          (cxvec_fft, :96)
 // Block boundaries of the reference are invisible in the maths (history carry == continuous stream,
-// zero history before the first sample), so one thread computes one output time T for all 4
-// channels: 4 x 16 real-tap FIRs + one radix-2 butterfly pair, inputs staged through LDS.
+// zero history before the first sample).  A workgroup takes CH_TILE consecutive output times; a thread computes
+// CH_J = 4 consecutive ones for all 4 channels, so that the 16-tap windows of its outputs share their samples: 19 LDS
+// reads per path for 4 outputs instead of 64 (the one-output-per-thread version of round 1 was bound by LDS
+// bandwidth, not by HBM).  The staged samples are kept per path in a 4-phase layout -- xs[p][t & 3][t >> 2] -- so
+// that lane l's sample t = 4 l + v sits at entry l + (v >> 2) of phase v & 3: consecutive lanes read consecutive
+// 8-byte entries (bank-conflict-free) although each lane advances by 4 samples.  Sums run k = 0..15 per output,
+// product then add, as convolve_base.c:41-54 does.
 // ------------------------------------------------------------------------------------------------
 #define CH_M 4
 #define CH_H 16
 #define CH_TPB 256
+#define CH_J 4
+#define CH_TILE (CH_TPB * CH_J)
+#define CH_PHA 264                     // entries per phase array: >= (CH_TILE + 15 + 3) / 4 = 260; 2 * 264 = 16 (mod 64) dwords, so
+                                       // the four phases of one loader pass fall on disjoint bank groups
 
-__global__ void __launch_bounds__(CH_TPB)
+typedef float ch_v2f __attribute__((ext_vector_type(2)));
+template <int HI>
+__device__ __forceinline__ ch_v2f ch_mul_tap(ch_v2f x, ch_v2f hpair)
+{
+	ch_v2f r;                          // x * (tap HI of the pair): one v_pk_mul_f32, the tap picked by op_sel
+	if (HI)
+		asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(x), "v"(hpair));
+	else
+		asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(r) : "v"(x), "v"(hpair));
+	return r;
+}
+
+// one complex sample from LDS as its own ds_read_b64 (a merged ds_read2_b64 occupies the LDS twice as long as two single
+// reads, MI355X_MICROARCH.md); volatile only stops the merge
+__device__ __forceinline__ ch_v2f ch_lds(const c32 *p)
+{
+	typedef const volatile ch_v2f __attribute__((address_space(3))) *lds_ptr;
+	return *(lds_ptr)(p);
+}
+
+__global__ void __launch_bounds__(CH_TPB) __attribute__((amdgpu_waves_per_eu(4, 4)))     // 4 workgroups of 34 KB LDS per CU
 channelize_kernel(const uint32_t *__restrict__ in, c32 *__restrict__ out, size_t n_total, size_t out_stride,
 		  const trx_tables *__restrict__ tab, const uint4 *__restrict__ hist)
 {
-	// wideband samples (T0-15)*4 .. (T0+TPB)*4 as fp32, stored per path: xs[p][t], t = T - (T0-15)
-	__shared__ c32 xs[CH_M][CH_TPB + CH_H];
-	__shared__ float taps[CH_M][CH_H];
+	// wideband time steps (T0-15) .. (T0+CH_TILE-1) as fp32, per path and phase: xs[p][t & 3][t >> 2], t = T - (T0-15)
+	__shared__ __attribute__((aligned(16))) c32 xs[CH_M][4][CH_PHA];
+	__shared__ __attribute__((aligned(16))) float taps[CH_M][CH_H];
 	if (threadIdx.x < CH_M * CH_H)
 		taps[threadIdx.x / CH_H][threadIdx.x % CH_H] = tab->chan_taps[threadIdx.x / CH_H][threadIdx.x % CH_H];
-
-	for (size_t T0 = (size_t)blockIdx.x * CH_TPB; T0 < n_total; T0 += (size_t)gridDim.x * CH_TPB) {
-		__syncthreads();
-		// one 16-byte load per time step: its 4 wideband samples are the 4 paths' inputs (path M-1-n <- sample n)
-		const uint4 *in4 = reinterpret_cast<const uint4 *>(in);
-		for (int t = threadIdx.x; t < CH_TPB + CH_H - 1; t += CH_TPB) {
-			const long long ts = (long long)T0 - (CH_H - 1) + t;               // absolute time step
-			uint4 u = make_uint4(0u, 0u, 0u, 0u);
-			if (ts >= 0 && (size_t)ts < n_total)
-				u = in4[ts];
-			else if (ts < 0 && hist)
-				u = hist[(CH_H - 1) + ts];                                     // carried history: time steps -15..-1
-			const uint32_t w[4] = { u.x, u.y, u.z, u.w };
+	const uint4 *in4 = reinterpret_cast<const uint4 *>(in);
+	auto stage = [&](int t, uint4 u) {         // time step t of the tile (0..14 = history) -> the four paths' fp32 samples
+		const uint32_t w[4] = { u.x, u.y, u.z, u.w };
 #pragma unroll
-			for (int n = 0; n < CH_M; n++)
-				xs[CH_M - 1 - n][t] = make_float2((float)(int16_t)(w[n] & 0xffffu), (float)(int16_t)(w[n] >> 16));
+		for (int n = 0; n < CH_M; n++)         // path M-1-n <- wideband sample n of the time step (Channelizer.cpp:37-48)
+			xs[CH_M - 1 - n][t & 3][t >> 2] = make_float2((float)(int16_t)(w[n] & 0xffffu), (float)(int16_t)(w[n] >> 16));
+	};
+
+	// A workgroup owns a contiguous run of tiles: the last 15 time steps of one tile are the history of the next, so every
+	// tile costs exactly CH_J aligned 16-byte loads per thread, and those of tile k+1 are issued before tile k is
+	// computed (register prefetch: the loads stay in flight during the arithmetic instead of in front of a barrier).
+	const size_t n_tiles = (n_total + CH_TILE - 1) / CH_TILE;
+	const size_t per_wg = (n_tiles + gridDim.x - 1) / gridDim.x;
+	const size_t tile_lo = (size_t)blockIdx.x * per_wg;
+	const size_t tile_hi = (tile_lo + per_wg < n_tiles) ? tile_lo + per_wg : n_tiles;
+	uint4 pre[CH_J], carry = make_uint4(0u, 0u, 0u, 0u);
+	auto prefetch = [&](size_t tile) {
+#pragma unroll
+		for (int i = 0; i < CH_J; i++) {
+			const size_t ts = tile * CH_TILE + (size_t)i * CH_TPB + threadIdx.x;
+			pre[i] = (ts < n_total) ? in4[ts] : make_uint4(0u, 0u, 0u, 0u);
 		}
+	};
+	if (tile_lo < tile_hi) {
+		prefetch(tile_lo);
+		if (threadIdx.x >= CH_TPB - (CH_H - 1)) {                              // history of the run's first tile, from memory
+			const long long ts = (long long)(tile_lo * CH_TILE) - CH_TPB + threadIdx.x;   // time steps T0-15 .. T0-1
+			if (ts >= 0)
+				carry = in4[ts];
+			else if (hist)
+				carry = hist[(CH_H - 1) + ts];                                 // carried history of a stream: time steps -15..-1
+		}
+	}
+	for (size_t tile = tile_lo; tile < tile_hi; tile++) {
+		const size_t T0 = tile * CH_TILE;
 		__syncthreads();
-		const size_t T = T0 + threadIdx.x;
+		if (threadIdx.x >= CH_TPB - (CH_H - 1))
+			stage(threadIdx.x - (CH_TPB - (CH_H - 1)), carry);                 // t = 0..14
+#pragma unroll
+		for (int i = 0; i < CH_J; i++)
+			stage((CH_H - 1) + i * CH_TPB + threadIdx.x, pre[i]);
+		carry = pre[CH_J - 1];                                                 // threads 241..255: the tile's last 15 time steps
+		__syncthreads();
+		if (tile + 1 < tile_hi)
+			prefetch(tile + 1);
+		const size_t T = T0 + (size_t)CH_J * threadIdx.x;                     // first of this thread's CH_J output times
 		if (T < n_total) {
-			c32 yp[CH_M];
+			c32 yp[CH_J][CH_M];
 #pragma unroll
 			for (int p = 0; p < CH_M; p++) {
-				float yr = 0.0f, yi = 0.0f;
+				// samples v = 0 .. 18 of the thread's window: tap k of output j is sample j + k
+				ch_v2f x[CH_J + CH_H - 1];
+#pragma unroll
+				for (int v = 0; v < CH_J + CH_H - 1; v++) {
+					x[v] = ch_lds(&xs[p][v & 3][threadIdx.x + (v >> 2)]);
+				}
+				const float2 *g2 = reinterpret_cast<const float2 *>(&taps[p][0]);   // broadcast reads, a pair of taps each
+				ch_v2f acc[CH_J];
+#pragma unroll
+				for (int j = 0; j < CH_J; j++)
+					acc[j] = (ch_v2f){ 0.0f, 0.0f };
 #pragma unroll
 				for (int k = 0; k < CH_H; k++) {
-					const c32 x = xs[p][threadIdx.x + k];
-					const float g = taps[p][k];
-					yr += x.x * g;
-					yi += x.y * g;
+					const float2 gq = g2[k >> 1];
+					const ch_v2f gp = (ch_v2f){ gq.x, gq.y };
+#pragma unroll
+					for (int j = 0; j < CH_J; j++)
+						acc[j] = acc[j] + ((k & 1) ? ch_mul_tap<1>(x[j + k], gp) : ch_mul_tap<0>(x[j + k], gp));
+					if (k & 1)
+						__builtin_amdgcn_sched_barrier(0);                     // keeps the products from piling up in registers
 				}
-				yp[p] = make_float2(yr, yi);
+#pragma unroll
+				for (int j = 0; j < CH_J; j++) {
+					asm volatile("" : "+v"(acc[j]));                           // the sums are finished here (not sunk into the store branches)
+					yp[j][p] = make_float2(acc[j].x, acc[j].y);
+				}
+				__builtin_amdgcn_sched_barrier(0);                             // one path's window in registers at a time
 			}
-			// forward 4-point DFT, radix-2 butterflies (exact +-1 / +-j twiddles)
-			const c32 t1 = make_float2(yp[0].x + yp[2].x, yp[0].y + yp[2].y);
-			const c32 t2 = make_float2(yp[0].x - yp[2].x, yp[0].y - yp[2].y);
-			const c32 t3 = make_float2(yp[1].x + yp[3].x, yp[1].y + yp[3].y);
-			const c32 t4 = make_float2(yp[1].x - yp[3].x, yp[1].y - yp[3].y);
-			out[0 * out_stride + T] = make_float2(t1.x + t3.x, t1.y + t3.y);
-			out[1 * out_stride + T] = make_float2(t2.x + t4.y, t2.y - t4.x);   // t2 - j*t4
-			out[2 * out_stride + T] = make_float2(t1.x - t3.x, t1.y - t3.y);
-			out[3 * out_stride + T] = make_float2(t2.x - t4.y, t2.y + t4.x);   // t2 + j*t4
+			// forward 4-point DFT per output time, radix-2 butterflies (exact +-1 / +-j twiddles)
+			c32 o[CH_M][CH_J];
+#pragma unroll
+			for (int j = 0; j < CH_J; j++) {
+				const c32 t1 = make_float2(yp[j][0].x + yp[j][2].x, yp[j][0].y + yp[j][2].y);
+				const c32 t2 = make_float2(yp[j][0].x - yp[j][2].x, yp[j][0].y - yp[j][2].y);
+				const c32 t3 = make_float2(yp[j][1].x + yp[j][3].x, yp[j][1].y + yp[j][3].y);
+				const c32 t4 = make_float2(yp[j][1].x - yp[j][3].x, yp[j][1].y - yp[j][3].y);
+				o[0][j] = make_float2(t1.x + t3.x, t1.y + t3.y);
+				o[1][j] = make_float2(t2.x + t4.y, t2.y - t4.x);               // t2 - j*t4
+				o[2][j] = make_float2(t1.x - t3.x, t1.y - t3.y);
+				o[3][j] = make_float2(t2.x - t4.y, t2.y + t4.x);               // t2 + j*t4
+			}
+			// 32 contiguous bytes per channel and thread: two 16-byte stores when the row allows it
+			const bool vec = (T + CH_J <= n_total) && ((out_stride & 1) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+#pragma unroll
+			for (int c = 0; c < CH_M; c++) {
+				c32 *dst = out + c * out_stride + T;
+				if (vec) {
+					reinterpret_cast<float4 *>(dst)[0] = make_float4(o[c][0].x, o[c][0].y, o[c][1].x, o[c][1].y);
+					reinterpret_cast<float4 *>(dst)[1] = make_float4(o[c][2].x, o[c][2].y, o[c][3].x, o[c][3].y);
+				} else {
+#pragma unroll
+					for (int j = 0; j < CH_J; j++)
+						if (T + j < n_total)
+							dst[j] = o[c][j];
+				}
+			}
 		}
 	}
 }
@@ -273,8 +366,8 @@ extern "C" int trx_launch_channelize(const int16_t *d_in, float *d_out, size_t n
 {
 	if (n_total == 0)
 		return 0;
-	size_t blocks = (n_total + CH_TPB - 1) / CH_TPB;
-	if (blocks > 256 * 8) blocks = 256 * 8;
+	size_t blocks = (n_total + CH_TILE - 1) / CH_TILE;
+	if (blocks > 256 * 4) blocks = 256 * 4;                              // 4 workgroups of 34 KB LDS per CU, each a run of tiles
 	hipLaunchKernelGGL(channelize_kernel, dim3((unsigned)blocks), dim3(CH_TPB), 0, stream,
 			   reinterpret_cast<const uint32_t *>(d_in), reinterpret_cast<c32 *>(d_out), n_total, out_stride, d_tab,
 			   reinterpret_cast<const uint4 *>(d_hist_io));
@@ -294,10 +387,14 @@ extern "C" int trx_launch_channelize(const int16_t *d_in, float *d_out, size_t n
 // paths) spread over the banks.  Index math is 32-bit inside a tile (the tile base is a multiple of the period).
 // ------------------------------------------------------------------------------------------------
 #define RS_TPB 256
-#define RS_TILE_IN 3072                                                  // q*TM input samples per tile
+#define RS_TILE_IN 3072                                                  // about q*TM input samples per tile
 
+// Outputs o and o + p*m share their filter path ((q*o) % p), so a thread that walks o = t, t + S, t + 2S, ... with
+// S = p*m (m = ceil(256 / p): S = 260 for 65/48, 65/96 and 52/75) keeps its 16 taps in registers for the whole kernel and
+// reads only its 16 input samples from LDS per output; its input index advances by q*m per step.  The S - 256 output
+// residues no thread owns (4 of 260) are swept afterwards with the taps read from LDS per output.
 __global__ void __launch_bounds__(RS_TPB)
-resample_kernel(const c32 *__restrict__ in, c32 *__restrict__ out, size_t n_in, size_t n_out, int p, int q, int tm,
+resample_kernel(const c32 *__restrict__ in, c32 *__restrict__ out, size_t n_in, size_t n_out, int p, int q, int tm, int m,
 		size_t n_tiles, size_t in_stride, size_t out_stride, const float *__restrict__ parts,
 		const c32 *__restrict__ hist)
 {
@@ -311,24 +408,76 @@ resample_kernel(const c32 *__restrict__ in, c32 *__restrict__ out, size_t n_in, 
 	const c32 *x = in + chan * in_stride;
 	c32 *y = out + chan * out_stride;
 	const int tile_in = q * tm, tile_out = p * tm;
-	for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+	const int S = p * m, iters = tm / m;                                 // tm is a multiple of m (launcher)
+	const int t = threadIdx.x;
+	const bool owner = t < S;                                            // (S >= 256 unless p > 256: then S = p and some threads idle)
+	const unsigned qt = (unsigned)q * (unsigned)t;
+	const int n_t = (int)(qt / (unsigned)p), path_t = (int)(qt % (unsigned)p);
+	ch_v2f h2[8];                                                        // this thread's 16 taps, in pairs
+#pragma unroll
+	for (int k = 0; k < 8; k++)
+		h2[k] = owner ? (ch_v2f){ parts[path_t * 16 + 2 * k], parts[path_t * 16 + 2 * k + 1] } : (ch_v2f){ 0.0f, 0.0f };
+	const int nstep = q * m;
+	// a workgroup owns a contiguous run of tiles and fetches tile k+1 into registers before it computes tile k
+	constexpr int NPRE = (RS_TILE_IN + RS_TPB - 1) / RS_TPB;             // tile_in <= RS_TILE_IN
+	const size_t per_wg = (n_tiles + gridDim.x - 1) / gridDim.x;
+	const size_t tile_lo = (size_t)blockIdx.x * per_wg;
+	const size_t tile_hi = (tile_lo + per_wg < n_tiles) ? tile_lo + per_wg : n_tiles;
+	c32 pre[NPRE], pre_h = make_float2(0.0f, 0.0f);
+	auto prefetch = [&](size_t tile) {
 		const long long n0 = (long long)tile * tile_in;                    // first input sample of the tile
+#pragma unroll
+		for (int i = 0; i < NPRE; i++) {
+			const int j = i * RS_TPB + t;
+			const size_t sidx = (size_t)n0 + j;
+			pre[i] = (j < tile_in && sidx < n_in) ? x[sidx] : make_float2(0.0f, 0.0f);
+		}
+		if (t < 15) {                                                      // the 15 samples in front of the tile
+			const long long sidx = n0 - 15 + t;
+			pre_h = make_float2(0.0f, 0.0f);
+			if (sidx >= 0) { if ((size_t)sidx < n_in) pre_h = x[sidx]; }
+			else if (hist) pre_h = hist[chan * 16 + 15 + sidx];                // carried history: samples -15..-1
+		}
+	};
+	if (tile_lo < tile_hi)
+		prefetch(tile_lo);
+	for (size_t tile = tile_lo; tile < tile_hi; tile++) {
 		__syncthreads();
-		for (int j = threadIdx.x; j < tile_in + 15; j += RS_TPB) {
-			const long long s = n0 - 15 + j;
-			c32 v = make_float2(0.0f, 0.0f);
-			if (s >= 0 && (size_t)s < n_in) v = x[s];
-			else if (s < 0 && hist) v = hist[chan * 16 + 15 + s];               // carried history: samples -15..-1
-			xs[j] = v;
+		if (t < 15)
+			xs[t] = pre_h;
+#pragma unroll
+		for (int i = 0; i < NPRE; i++) {
+			const int j = i * RS_TPB + t;
+			if (j < tile_in)
+				xs[15 + j] = pre[i];
 		}
 		__syncthreads();
+		if (tile + 1 < tile_hi)
+			prefetch(tile + 1);
 		const size_t o0 = tile * (size_t)tile_out;
-		for (int o = threadIdx.x; o < tile_out; o += RS_TPB) {
+		if (owner) {
+			const c32 *xp = xs + n_t;                                      // xs[j] = in[n0 - 15 + j]
+			c32 *yo = y + o0 + t;
+			size_t o = o0 + t;
+			for (int it = 0; it < iters && o < n_out; it++, o += S, xp += nstep, yo += S) {
+				ch_v2f acc = { 0.0f, 0.0f };
+#pragma unroll
+				for (int k = 0; k < 16; k++) {
+					const ch_v2f xv = ch_lds(xp + k);
+					acc = acc + ((k & 1) ? ch_mul_tap<1>(xv, h2[k >> 1]) : ch_mul_tap<0>(xv, h2[k >> 1]));   // product, then sum
+				}
+				*yo = make_float2(acc.x, acc.y);
+			}
+		}
+		// residues RS_TPB .. S-1 of every step: (S - RS_TPB) * iters outputs, taps from LDS
+		const int nres = S - RS_TPB;
+		for (int idx = t; idx < nres * iters; idx += RS_TPB) {
+			const int o = RS_TPB + idx % nres + S * (idx / nres);
 			if (o0 + o >= n_out)
-				break;
+				continue;
 			const unsigned qi = (unsigned)q * (unsigned)o;
 			const int n = (int)(qi / (unsigned)p), path = (int)(qi % (unsigned)p);
-			const c32 *xp = xs + n;                                        // xs[j] = in[n0 - 15 + j]
+			const c32 *xp = xs + n;
 			float yr = 0.0f, yi = 0.0f;
 #pragma unroll
 			for (int k = 0; k < 16; k++) {
@@ -348,13 +497,16 @@ extern "C" int trx_launch_resample(const float *d_in, float *d_out, size_t n_in,
 	const size_t n_out = n_in / q * p;
 	if (n_chan * n_out == 0)
 		return 0;
-	const int tm = RS_TILE_IN / q;
+	const int m = (RS_TPB + p - 1) / p;                                  // outputs o and o + p*m share a filter path
+	int tm = RS_TILE_IN / q / m * m;                                     // periods per tile: a multiple of m
+	if (tm < m) tm = m;
 	const size_t n_tiles = (n_out + (size_t)p * tm - 1) / ((size_t)p * tm);
 	size_t gx = n_tiles;
-	if (gx > 2048) gx = 2048;
+	const size_t gmax = 1024 / n_chan > 0 ? 1024 / n_chan : 1;           // 4 workgroups (29 KB of LDS, 112 VGPRs) per CU over all channels,
+	if (gx > gmax) gx = gmax;                                            // each walking a contiguous run of tiles
 	const size_t lds = (size_t)(16 + q * tm) * sizeof(c32) + (size_t)16 * (p + 1) * sizeof(float);
 	hipLaunchKernelGGL(resample_kernel, dim3((unsigned)gx, (unsigned)n_chan), dim3(RS_TPB), lds, stream,
-			   reinterpret_cast<const c32 *>(d_in), reinterpret_cast<c32 *>(d_out), n_in, n_out, p, q, tm, n_tiles,
+			   reinterpret_cast<const c32 *>(d_in), reinterpret_cast<c32 *>(d_out), n_in, n_out, p, q, tm, m, n_tiles,
 			   in_stride, out_stride, parts, reinterpret_cast<const c32 *>(d_hist_io));
 	if (d_hist_io)
 		hipLaunchKernelGGL(save_chan_hist_kernel, dim3((unsigned)n_chan), dim3(64), 0, stream,
