@@ -80,12 +80,17 @@ struct Entry {
 	int32_t code;
 	uint32_t pkt_len;
 };
+/* One channel's delivery ring: single producer (the completion thread), single consumer (that channel's RxUpper thread,
+ * Transceiver.cpp:1229-1253).  The consumer takes entries without a lock -- `tail` is published with release semantics
+ * after the entries are written -- and only goes to the mutex / condition variable when the ring is empty. */
 struct Chan {
 	std::mutex mu;
 	std::condition_variable cv;
 	std::vector<uint8_t> ring;                  /* fifo_depth x (sizeof(Entry) + payload) */
-	size_t head = 0, count = 0;
-	std::atomic<size_t> outstanding{0};         /* pushed and not yet pulled: the reference's FIFO occupancy */
+	alignas(64) std::atomic<size_t> tail{0};    /* entries delivered so far (completion thread) */
+	std::atomic<int> waiting{0};                /* the consumer sleeps on cv (checked by the completion thread after publishing) */
+	alignas(64) size_t head = 0;                /* entries pulled so far (consumer's own) */
+	alignas(64) std::atomic<size_t> outstanding{0};     /* pushed and not yet pulled: the reference's FIFO occupancy */
 };
 const uint32_t CLOSED = 1u << 30;
 struct Batch {
@@ -199,13 +204,13 @@ struct BurstGatherer::Impl {
 				if (first[c] == first[c + 1])
 					continue;
 				Chan &ch = chan[c];
+				size_t tail = ch.tail.load(std::memory_order_relaxed);
 				{
-					std::lock_guard<std::mutex> g(ch.mu);
 					for (uint32_t k = first[c]; k < first[c + 1]; k++) {
 						const uint32_t i = order[k];
 						const Route &r = b.slot[i].r;
-						/* cannot overflow: outstanding <= fifo_depth = ring size */
-						uint8_t *e = entry(ch, ch.head + ch.count);
+						/* cannot overflow: tail - head <= outstanding <= fifo_depth = ring size */
+						uint8_t *e = entry(ch, tail++);
 						Entry hd;
 						if (ok) hd.res = b.h.results[i]; else memset(&hd.res, 0, sizeof(hd.res));
 						hd.route = r;
@@ -216,10 +221,13 @@ struct BurstGatherer::Impl {
 							memcpy(e + sizeof(Entry), b.h.pkt + (size_t)i * stride, hd.pkt_len);
 						else if (ok && b.h.soft && !hd.res.idle)
 							memcpy(e + sizeof(Entry), b.h.soft + (size_t)i * stride, 4u * hd.res.nbits_div4 * sizeof(float));
-						ch.count++;
 					}
 				}
-				ch.cv.notify_one();
+				ch.tail.store(tail, std::memory_order_seq_cst);          /* publish; then look for a sleeping consumer */
+				if (ch.waiting.load(std::memory_order_seq_cst)) {
+					std::lock_guard<std::mutex> g(ch.mu);
+					ch.cv.notify_one();
+				}
 			}
 			lk.lock();
 			b.count = 0;
@@ -429,10 +437,14 @@ int BurstGatherer::pull(size_t c, BurstIndication *bi, uint8_t *pkt, size_t *pkt
 	if (c >= m.chan.size() || !bi)
 		return -EIO;
 	Chan &ch = m.chan[c];
-	std::unique_lock<std::mutex> lk(ch.mu);
-	ch.cv.wait(lk, [&] { return ch.count > 0 || m.stopping || !m.running; });
-	if (ch.count == 0)
-		return -EIO;
+	if (ch.tail.load(std::memory_order_acquire) == ch.head) {         /* empty: block, as the reference's FIFO read does (:683) */
+		std::unique_lock<std::mutex> lk(ch.mu);
+		ch.waiting.store(1, std::memory_order_seq_cst);
+		ch.cv.wait(lk, [&] { return ch.tail.load(std::memory_order_seq_cst) != ch.head || m.stopping || !m.running; });
+		ch.waiting.store(0, std::memory_order_relaxed);
+		if (ch.tail.load(std::memory_order_acquire) == ch.head)
+			return -EIO;
+	}
 	const uint8_t *e = m.entry(ch, ch.head);
 	Entry hd;
 	memcpy(&hd, e, sizeof(hd));
@@ -448,8 +460,7 @@ int BurstGatherer::pull(size_t c, BurstIndication *bi, uint8_t *pkt, size_t *pkt
 		memcpy(pkt, e + sizeof(Entry), hd.pkt_len);
 	if (pkt_len)
 		*pkt_len = hd.pkt_len;
-	ch.head = (ch.head + 1) % m.cfg.fifo_depth;
-	ch.count--;
+	ch.head++;
 	ch.outstanding.fetch_sub(1, std::memory_order_release);
 	return hd.code;
 }
