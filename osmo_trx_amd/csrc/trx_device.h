@@ -60,7 +60,9 @@ typedef float2 c32;
 // per-phase cycle accounting (s_memtime deltas summed over all bursts by lane 0 of every wave)
 #define TRX_DIAG_WAVES 8192
 static __device__ unsigned long long g_trx_diag[TRX_DIAG_WAVES * 24];   // per wave (no atomics); one copy per translation unit
-#define DIAG_DECL unsigned long long diag_acc[24] = {0}; unsigned long long diag_prev = __builtin_readcyclecounter()
+// slots 20..23 are not sums: wall-clock start / end of the wave (s_memrealtime, 100 MHz), HW_ID and XCC_ID
+#define DIAG_DECL unsigned long long diag_acc[24] = {0}; unsigned long long diag_prev = __builtin_readcyclecounter(); \
+	const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime()
 #define DIAG_ARG , unsigned long long *diag_acc, unsigned long long &diag_prev
 #define DIAG_PASS , diag_acc, diag_prev
 #define DIAG_MARK(k)                                                                            \
@@ -72,8 +74,16 @@ static __device__ unsigned long long g_trx_diag[TRX_DIAG_WAVES * 24];   // per w
 #define DIAG_FLUSH()                                                                            \
 	do {                                                                                    \
 		const unsigned _w = (blockIdx.x * 16 + (threadIdx.x >> 6)) % TRX_DIAG_WAVES;    \
-		if ((threadIdx.x & 63) == 0)                                                    \
-			for (int _k = 0; _k < 24; _k++) g_trx_diag[_w * 24 + _k] += diag_acc[_k]; \
+		if ((threadIdx.x & 63) == 0) {                                                  \
+			for (int _k = 0; _k < 20; _k++) g_trx_diag[_w * 24 + _k] += diag_acc[_k]; \
+			unsigned _hw, _xcc;                                                     \
+			asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(_hw));        \
+			asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(_xcc));      \
+			g_trx_diag[_w * 24 + 20] = diag_t0;                                     \
+			g_trx_diag[_w * 24 + 21] = __builtin_amdgcn_s_memrealtime();            \
+			g_trx_diag[_w * 24 + 22] = _hw;                                         \
+			g_trx_diag[_w * 24 + 23] = _xcc;                                        \
+		}                                                                               \
 	} while (0)
 #else
 #define ABL(bit) 0

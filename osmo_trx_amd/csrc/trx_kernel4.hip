@@ -50,6 +50,12 @@ extern "C" int trxhip_diag_read(unsigned long long *out, int reset)
 	}
 	return 0;
 }
+// raw per-wave records (24 words each; 20..23 = start / end wall clock, HW_ID, XCC_ID of the last launch)
+extern "C" int trxhip_diag_read_waves(unsigned long long *out, int n_waves)
+{
+	if (n_waves > TRX_DIAG_WAVES) n_waves = TRX_DIAG_WAVES;
+	return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trx_diag), (size_t)n_waves * 24 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
 #endif
 
 __device__ __forceinline__ int fdiv(int a, int b) { const int q = a / b; return (a % b != 0 && a < 0) ? q - 1 : q; }   // b > 0
@@ -104,6 +110,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 	float *comp = lhdr + 8 * LSEQ_NHDR;                            // [65][36] composite delay-o-decimate filters
 	int *pkcl = reinterpret_cast<int *>(comp + K4_DROWS * 36);     // [5][64] PeakConst fields by lane
 	c32 *wbase = reinterpret_cast<c32 *>(smem + K4_TABLES_BYTES) + (size_t)wave * K4_SLICE;
+	int *const wg_next = reinterpret_cast<int *>(reinterpret_cast<c32 *>(smem + K4_TABLES_BYTES) + (size_t)waves_per_block * K4_SLICE);   // work counter
 	c32 *const P = wbase;                                          // polyphase burst: P[r*PH_A + PH_M0 + m] = x[4m + r]
 	c32 *const dec = wbase + K4_XS;                                // 1-SPS (decimated) burst, zero tail
 	c32 *const cz = dec + TRX_DEC_NARROW + TRX_CZ_PAD;             // zero-padded correlation
@@ -145,11 +152,25 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 	}
 	for (int i = lane; i < K4_SLICE; i += WAVE)
 		wbase[i] = make_float2(0.0f, 0.0f);
+	if (threadIdx.x == 0)
+		*wg_next = waves_per_block;                                 // items 0 .. waves-1 are the waves' first ones
 	__syncthreads();
 
 	const float fs_db = 6.02059991f * __log2f(full_scale);          // 20*log10(full_scale)
-	const unsigned total_waves = gridDim.x * waves_per_block;
-	const unsigned first = blockIdx.x * waves_per_block + wave;
+	// Work distribution.  The workgroup owns the bursts blockIdx.x, blockIdx.x + gridDim.x, ... ("items" j = 0, 1, ...) and its
+	// waves CLAIM them one at a time from an LDS counter, one burst ahead (at prefetch time).  A static split -- the same number
+	// of bursts for every wave -- leaves the CU under-occupied for the last third of the kernel: the SIMD's issue arbitration
+	// favours its oldest wave, which then finishes its share at 65 % of the kernel's duration, the next one at 75 % ...
+	// (tools/wave_timeline.py: wave end times 1200 .. 1860 us inside every workgroup), and four waves per SIMD is exactly what
+	// hides this kernel's latencies.
+	const unsigned n_wg = gridDim.x;
+	const unsigned items = (blockIdx.x < n_bursts) ? (n_bursts - blockIdx.x + n_wg - 1) / n_wg : 0u;
+	auto claim = [&]() -> unsigned {
+		int j = 0;
+		if (lane == 0)
+			j = __hip_atomic_fetch_add(wg_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		return (unsigned)uni(j);
+	};
 
 	// Software prefetch of the next burst (see burst_pull_kernel)
 	uint32_t pre_i[NLD];
@@ -173,14 +194,16 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 			}
 		}
 	};
-	if (first < n_bursts)
-		prefetch(first);
+	if ((unsigned)wave < items)
+		prefetch((unsigned)wave * n_wg + blockIdx.x);
 
 	// loader address: sample r*64 + lane -> phase lane&3, m = 16r + lane>>2
 	c32 *const pload = P + (lane & 3) * PH_A + PH_M0 + (lane >> 2);
 
 	DIAG_DECL;
-	for (unsigned b = first; b < n_bursts; b += total_waves) {
+	unsigned j_next = 0;
+	for (unsigned j = (unsigned)wave; j < items; j = j_next) {
+		const unsigned b = j * n_wg + blockIdx.x;
 		// Re-materialise the lane id per burst (2 VALU ops): otherwise every lane-derived address, tree-node
 		// offset and LUT base of every phase is hoisted out of this loop and kept live across it, which
 		// costs ~50 VGPRs and spills.
@@ -215,8 +238,9 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 		}
 		epart = (lane & 3) ? 0.0f : epart;
 		DIAG_MARK(14);
-		if (b + total_waves < n_bursts)
-			prefetch(b + total_waves);
+		j_next = claim();
+		if (j_next < items)
+			prefetch(j_next * n_wg + blockIdx.x);
 		DIAG_MARK(15);
 
 		if (type != TRXHIP_OFF) {                                   // Transceiver.cpp:704-707
@@ -711,7 +735,7 @@ extern "C" int trx_launch_pull4(const void *d_iq, int cf32, const trxhip_burst_p
 #ifdef TRX_DIAG
 	if (const char *e = getenv("TRXHIP_WPB")) { const int v = atoi(e); if (v >= 1 && v <= wpb) wpb = v; }   // occupancy scan
 #endif
-	const size_t lds = K4_TABLES_BYTES + (size_t)wpb * K4_SLICE * sizeof(c32);
+	const size_t lds = K4_TABLES_BYTES + (size_t)wpb * K4_SLICE * sizeof(c32) + 16;     // + the workgroup's work counter
 	size_t need = (n_bursts + wpb - 1) / wpb;
 	size_t grid = (size_t)n_cu;
 #ifdef TRX_DIAG
@@ -728,7 +752,7 @@ extern "C" int trx_launch_pull4(const void *d_iq, int cf32, const trxhip_burst_p
 		const unsigned long long bit = 1ull << (dev & 63);                                              \
 		if (!(armed.load(std::memory_order_acquire) & bit)) {                                           \
 			if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize,        \
-						(int)(K4_TABLES_BYTES + (size_t)K4_WPB(CF_, EX_) * K4_SLICE * sizeof(c32))) != hipSuccess) \
+						(int)(K4_TABLES_BYTES + (size_t)K4_WPB(CF_, EX_) * K4_SLICE * sizeof(c32) + 16)) != hipSuccess) \
 				return TRXHIP_EIO;                                                                  \
 			armed.fetch_or(bit, std::memory_order_release);                                             \
 		}                                                                                               \
