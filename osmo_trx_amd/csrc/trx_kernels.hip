@@ -57,6 +57,7 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 	const int xs_alloc = (xs_len + 1) & ~1;
 	const int slice_c32 = xs_alloc + TRX_DEC_LEN + TRX_CZ_LEN;
 	c32 *wbase = reinterpret_cast<c32 *>(smem + TRX_TABLES_LDS_BYTES) + (size_t)wave * slice_c32;
+	int *const wg_next = reinterpret_cast<int *>(reinterpret_cast<c32 *>(smem + TRX_TABLES_LDS_BYTES) + (size_t)waves_per_block * slice_c32);   // work counter
 	c32 *const xs = wbase + TRX_PAD;                               // burst sample 0
 	c32 *const dec = wbase + xs_alloc;                             // 1-SPS (decimated) burst, zero tail
 	c32 *const cz = dec + TRX_DEC_LEN + TRX_CZ_PAD;                // zero-padded correlation
@@ -86,12 +87,22 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 	}
 	for (int i = lane; i < slice_c32; i += WAVE)
 		wbase[i] = make_float2(0.0f, 0.0f);
+	if (threadIdx.x == 0)
+		*wg_next = waves_per_block;
 	__syncthreads();
 
 	const float fs_db = 6.02059991f * __log2f(full_scale);          // 20*log10(full_scale)
 	const PeakConst pkc = peak_const(threadIdx.x & (WAVE - 1));      // lane constants of the TOA bisection
-	const unsigned total_waves = gridDim.x * waves_per_block;
-	const unsigned first = blockIdx.x * waves_per_block + wave;
+	// the workgroup's bursts are blockIdx.x, blockIdx.x + gridDim.x, ...; its waves claim them one ahead from an LDS counter
+	// (a static split leaves the CU under-occupied for the last third of the kernel, see burst_pull4_kernel)
+	const unsigned n_wg = gridDim.x;
+	const unsigned items = (blockIdx.x < n_bursts) ? (n_bursts - blockIdx.x + n_wg - 1) / n_wg : 0u;
+	auto claim = [&]() -> unsigned {
+		int j = 0;
+		if (lane == 0)
+			j = __hip_atomic_fetch_add(wg_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		return (unsigned)uni(j);
+	};
 
 	// Software prefetch: the raw samples and the parameter word of this wave's NEXT burst sit in
 	// registers (NLD dwords per lane, coalesced 256 B per wave-load) while the current burst is
@@ -117,11 +128,13 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 			}
 		}
 	};
-	if (first < n_bursts)
-		prefetch(first);
+	if ((unsigned)wave < items)
+		prefetch((unsigned)wave * n_wg + blockIdx.x);
 
 	DIAG_DECL;
-	for (unsigned b = first; b < n_bursts; b += total_waves) {
+	unsigned j_next = 0;
+	for (unsigned j = (unsigned)wave; j < items; j = j_next) {
+		const unsigned b = j * n_wg + blockIdx.x;
 		const unsigned prm0 = (unsigned)uni((int)pre_prm);
 		const int type = prm0 & 0xff;
 		const int tsc = (prm0 >> 8) & 0xff;
@@ -153,11 +166,13 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 							epart += norm2(v);
 				}
 			}
-			if (b + total_waves < n_bursts)
-				prefetch(b + total_waves);
+			j_next = claim();
+			if (j_next < items)
+				prefetch(j_next * n_wg + blockIdx.x);
 		} else {
-			if (b + total_waves < n_bursts)
-				pre_prm = reinterpret_cast<const uint32_t *>(params)[2 * (size_t)(b + total_waves)];
+			j_next = claim();
+			if (j_next < items)
+				pre_prm = reinterpret_cast<const uint32_t *>(params)[2 * (size_t)(j_next * n_wg + blockIdx.x)];
 			for (int i = lane; i < L; i += WAVE) {
 				c32 v;
 				if (CF32) {
@@ -386,7 +401,7 @@ extern "C" size_t trx_pull_lds_bytes(int L, int waves_per_block)
 {
 	const int xs_len = TRX_PAD + L + TRX_PAD;
 	const size_t slice_c32 = ((xs_len + 1) & ~1) + TRX_DEC_LEN + TRX_CZ_LEN;
-	return TRX_TABLES_LDS_BYTES + (size_t)waves_per_block * slice_c32 * sizeof(c32);
+	return TRX_TABLES_LDS_BYTES + (size_t)waves_per_block * slice_c32 * sizeof(c32) + 16;   // + the workgroup's work counter
 }
 
 extern "C" int trx_launch_pull4(const void *d_iq, int cf32, const trxhip_burst_params *d_params,
