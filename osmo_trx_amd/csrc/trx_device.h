@@ -123,6 +123,27 @@ __device__ __forceinline__ int write_lane(int word, int sval)
 }
 
 // DPP move: lanes without a valid source keep their own value
+// Work claiming from a workgroup-wide LDS counter, split in two so that the atomic's latency is covered by whatever runs
+// between issue and use: lane 0 alone executes one ds_add_rtn_u32 (exec is narrowed around it -- both calls sit in
+// wave-uniform code where every lane is active), the other half waits for it and moves the ticket to a scalar register.
+// The compiler's own form of "if (lane == 0) atomic" is the generic wave-aggregated sequence (mbcnt, bcnt, saveexec
+// twice, ~9 VALU + ~12 SALU) with a full wait right behind the atomic.
+__device__ __forceinline__ int claim_issue(const int *lds_counter)
+{
+	const unsigned addr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) int *)lds_counter;
+	int ticket;
+	asm volatile("s_mov_b64 exec, 1\n\t"
+		     "ds_add_rtn_u32 %0, %1, %2\n\t"
+		     "s_mov_b64 exec, -1"
+		     : "=&v"(ticket) : "v"(addr), "v"(1) : "memory");
+	return ticket;                                   // lane 0, once the LDS has answered
+}
+__device__ __forceinline__ int claim_take(int ticket)
+{
+	asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ticket) : : "memory");
+	return __builtin_amdgcn_readfirstlane(ticket);
+}
+
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp(float v)
 {

@@ -165,12 +165,6 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 	// hides this kernel's latencies.
 	const unsigned n_wg = gridDim.x;
 	const unsigned items = (blockIdx.x < n_bursts) ? (n_bursts - blockIdx.x + n_wg - 1) / n_wg : 0u;
-	auto claim = [&]() -> unsigned {
-		int j = 0;
-		if (lane == 0)
-			j = __hip_atomic_fetch_add(wg_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-		return (unsigned)uni(j);
-	};
 
 	// Software prefetch of the next burst (see burst_pull_kernel)
 	uint32_t pre_i[NLD];
@@ -209,6 +203,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 		// costs ~50 VGPRs and spills.
 		int lane;
 		asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+		const int ticket = claim_issue(wg_next);                   // this wave's next item; taken at prefetch time below
 		const unsigned prm0 = (unsigned)uni((int)pre_prm);
 		DIAG_MARK(13);
 		const int type = prm0 & 0xff;
@@ -238,7 +233,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 		}
 		epart = (lane & 3) ? 0.0f : epart;
 		DIAG_MARK(14);
-		j_next = claim();
+		j_next = (unsigned)claim_take(ticket);
 		if (j_next < items)
 			prefetch(j_next * n_wg + blockIdx.x);
 		DIAG_MARK(15);

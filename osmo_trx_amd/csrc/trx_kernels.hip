@@ -97,12 +97,6 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 	// (a static split leaves the CU under-occupied for the last third of the kernel, see burst_pull4_kernel)
 	const unsigned n_wg = gridDim.x;
 	const unsigned items = (blockIdx.x < n_bursts) ? (n_bursts - blockIdx.x + n_wg - 1) / n_wg : 0u;
-	auto claim = [&]() -> unsigned {
-		int j = 0;
-		if (lane == 0)
-			j = __hip_atomic_fetch_add(wg_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-		return (unsigned)uni(j);
-	};
 
 	// Software prefetch: the raw samples and the parameter word of this wave's NEXT burst sit in
 	// registers (NLD dwords per lane, coalesced 256 B per wave-load) while the current burst is
@@ -135,6 +129,7 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 	unsigned j_next = 0;
 	for (unsigned j = (unsigned)wave; j < items; j = j_next) {
 		const unsigned b = j * n_wg + blockIdx.x;
+		const int ticket = claim_issue(wg_next);                   // this wave's next item; taken at prefetch time below
 		const unsigned prm0 = (unsigned)uni((int)pre_prm);
 		const int type = prm0 & 0xff;
 		const int tsc = (prm0 >> 8) & 0xff;
@@ -166,11 +161,11 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 							epart += norm2(v);
 				}
 			}
-			j_next = claim();
+			j_next = (unsigned)claim_take(ticket);
 			if (j_next < items)
 				prefetch(j_next * n_wg + blockIdx.x);
 		} else {
-			j_next = claim();
+			j_next = (unsigned)claim_take(ticket);
 			if (j_next < items)
 				pre_prm = reinterpret_cast<const uint32_t *>(params)[2 * (size_t)(j_next * n_wg + blockIdx.x)];
 			for (int i = lane; i < L; i += WAVE) {
