@@ -194,6 +194,65 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 	// loader address: sample r*64 + lane -> phase lane&3, m = 16r + lane>>2
 	c32 *const pload = P + (lane & 3) * PH_A + PH_M0 + (lane >> 2);
 
+	// Deferred output.  vmcnt counts loads and stores alike and retires in order, so a wave that issues its stores at the end
+	// of burst k -- after the prefetch loads of burst k+1 -- cannot consume the last prefetched dword before those stores
+	// have been acknowledged as well: ~500 cycles per burst spent waiting for a write nothing depends on.  The common
+	// outputs (soft bits of the fused demodulator, which sit in dec[] until the next detection; the result record, whose
+	// fields are wave-uniform) are therefore written at the top of the NEXT burst, after its samples have been converted
+	// and before its own prefetch is issued: at every wait the prefetch loads are then the youngest memory operations.
+	int pend_mode = 0;                                              // 0: record only, 1: soft bits from dec[], 2: zero row
+	bool pend_any = false;
+	float *pend_so = nullptr;
+	int pend_nwrite = 0, pend_rc = 0;
+	unsigned pend_b = 0;
+	uint32_t pend_flags = 0u;
+	float pend_toa = 0.0f, pend_ax = 0.0f, pend_ay = 0.0f, pend_ci = 0.0f, pend_energy = 0.0f, pend_rssi = 0.0f;
+	auto flush = [&](int lane) {
+		if (!pend_any)
+			return;
+		if (pend_mode == 1) {
+			// symbols lane, lane + 64, lane + 128: the first two always exist and are always stored (rows of 128
+			// floats or more: 148 / 156 / 444 in practice), only the third needs its range checks; one pointer per lane
+			float *const sp = pend_so + lane;
+			const c32 *const dp = dec + lane, *const rp = rrot + lane;
+#pragma unroll
+			for (int r = 0; r < 3; r++) {
+				const int i = lane + r * WAVE;
+				const int off = (r < 2 || lane < 32) ? r * WAVE : 159 - lane;    // symbol 128 + lane, capped at entry 159
+				const c32 d = dp[off];
+				const c32 rr = rp[off];
+				float sv = rr.x * d.x - rr.y * d.y;                     // real(rot * x)  (:2066-2068)
+				if (slice & 1)
+					sv = __builtin_amdgcn_fmed3f(0.5f * (sv + 1.0f), 0.0f, 1.0f);
+				if (r < 2) {
+					sp[r * WAVE] = sv;
+				} else {
+					sv = (i < pend_nwrite) ? sv : 0.0f;
+					if (i < soft_stride)
+						sp[2 * WAVE] = sv;
+				}
+			}
+			for (int i = lane + 3 * WAVE; i < soft_stride; i += WAVE) // soft_stride > 192: zero tail
+				pend_so[i] = 0.0f;
+		} else if (pend_mode == 2) {
+			for (int i = lane; i < soft_stride; i += WAVE)
+				pend_so[i] = 0.0f;
+		}
+		// result record: 32 bytes, one dword per lane 0..7.  Every field is wave-uniform: v_writelane drops it into
+		// its lane (one instruction per field instead of a compare and a select)
+		int word = pend_rc;
+		word = write_lane<1>(word, __float_as_int(pend_toa));
+		word = write_lane<2>(word, __float_as_int(pend_ax));
+		word = write_lane<3>(word, __float_as_int(pend_ay));
+		word = write_lane<4>(word, __float_as_int(pend_ci));
+		word = write_lane<5>(word, __float_as_int(pend_energy));
+		word = write_lane<6>(word, __float_as_int(pend_rssi));
+		word = write_lane<7>(word, (int)pend_flags);
+		if (lane < 8)
+			reinterpret_cast<int *>(results + pend_b)[lane] = word;
+		pend_any = false;
+	};
+
 	DIAG_DECL;
 	unsigned j_next = 0;
 	for (unsigned j = (unsigned)wave; j < items; j = j_next) {
@@ -233,6 +292,8 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 		}
 		epart = (lane & 3) ? 0.0f : epart;
 		DIAG_MARK(14);
+		flush(lane);                                               // the previous burst's output (its dec[] is still intact)
+		pend_mode = 0;
 		j_next = (unsigned)claim_take(ticket);
 		if (j_next < items)
 			prefetch(j_next * n_wg + blockIdx.x);
@@ -633,29 +694,9 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 					wave_sync();
 
 					if (!is_edge && soft_stride >= 2 * WAVE) {
-						// symbols lane, lane + 64, lane + 128: the first two always exist and are always stored (rows of 128
-						// floats or more: 148 / 156 / 444 in practice), only the third needs its range checks; one pointer per lane
-						float *const sp = so + lane;
-						const c32 *const dp = dec + lane, *const rp = rrot + lane;
-#pragma unroll
-						for (int r = 0; r < 3; r++) {
-							const int i = lane + r * WAVE;
-							const int off = (r < 2 || lane < 32) ? r * WAVE : 159 - lane;    // symbol 128 + lane, capped at entry 159
-							const c32 d = dp[off];
-							const c32 rr = rp[off];
-							float sv = rr.x * d.x - rr.y * d.y;                     // real(rot * x)  (:2066-2068)
-							if (slice & 1)
-								sv = __builtin_amdgcn_fmed3f(0.5f * (sv + 1.0f), 0.0f, 1.0f);
-							if (r < 2) {
-								sp[r * WAVE] = sv;
-							} else {
-								sv = (i < nwrite) ? sv : 0.0f;
-								if (i < soft_stride)
-									sp[2 * WAVE] = sv;
-							}
-						}
-						for (int i = lane + 3 * WAVE; i < soft_stride; i += WAVE) // soft_stride > 192: zero tail
-							so[i] = 0.0f;
+						pend_mode = 1;                                              // written by flush() at the top of the next burst
+						pend_so = so;
+						pend_nwrite = nwrite;
 					} else if (!is_edge) {                                          // short rows: truncated to soft_stride
 #pragma unroll
 						for (int r = 0; r < 3; r++) {
@@ -678,31 +719,28 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 				}
 				wave_sync();
 			}
-		} else {
-			if (so)
-				for (int i = lane; i < soft_stride; i += WAVE)
-					so[i] = 0.0f;
+		} else if (so) {
+			pend_mode = 2;
+			pend_so = so;
 		}
 
 		DIAG_MARK(11);
-		// ---- result record: 32 bytes, one dword per lane 0..7.  Every field is wave-uniform: v_writelane drops it into
-		// its lane (one instruction per field instead of a compare and a select)
 		{
 			const bool det = rc > 0;
-			const uint32_t flags = (uint32_t)(det ? out_tsc : 0) | ((uint32_t)clip << 8) | ((uint32_t)idle << 16) | ((uint32_t)(nbits / 4) << 24);
-			int word = rc;
-			word = write_lane<1>(word, __float_as_int(det ? toa : 0.0f));
-			word = write_lane<2>(word, __float_as_int(det ? amp.x : 0.0f));
-			word = write_lane<3>(word, __float_as_int(det ? amp.y : 0.0f));
-			word = write_lane<4>(word, __float_as_int(det ? ci : 0.0f));
-			word = write_lane<5>(word, __float_as_int(energy));
-			word = write_lane<6>(word, __float_as_int(rssi));
-			word = write_lane<7>(word, (int)flags);
-			if (lane < 8)
-				reinterpret_cast<int *>(results + b)[lane] = word;
+			pend_flags = (uint32_t)(det ? out_tsc : 0) | ((uint32_t)clip << 8) | ((uint32_t)idle << 16) | ((uint32_t)(nbits / 4) << 24);
+			pend_rc = rc;
+			pend_toa = det ? toa : 0.0f;
+			pend_ax = det ? amp.x : 0.0f;
+			pend_ay = det ? amp.y : 0.0f;
+			pend_ci = det ? ci : 0.0f;
+			pend_energy = energy;
+			pend_rssi = rssi;
+			pend_b = b;
+			pend_any = true;
 		}
 		DIAG_MARK(12);
 	}
+	flush(lane);
 	DIAG_FLUSH();
 }
 
