@@ -157,14 +157,21 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 	__syncthreads();
 
 	const float fs_db = 6.02059991f * __log2f(full_scale);          // 20*log10(full_scale)
-	// Work distribution.  The workgroup owns the bursts blockIdx.x, blockIdx.x + gridDim.x, ... ("items" j = 0, 1, ...) and its
+	// Work distribution.  The workgroup owns every gridDim.x-th group of 16 bursts ("items" j = 0, 1, ... in that order) and its
 	// waves CLAIM them one at a time from an LDS counter, one burst ahead (at prefetch time).  A static split -- the same number
 	// of bursts for every wave -- leaves the CU under-occupied for the last third of the kernel: the SIMD's issue arbitration
 	// favours its oldest wave, which then finishes its share at 65 % of the kernel's duration, the next one at 75 % ...
 	// (tools/wave_timeline.py: wave end times 1200 .. 1860 us inside every workgroup), and four waves per SIMD is exactly what
 	// hides this kernel's latencies.
 	const unsigned n_wg = gridDim.x;
-	const unsigned items = (blockIdx.x < n_bursts) ? (n_bursts - blockIdx.x + n_wg - 1) / n_wg : 0u;
+	// items are handed out in groups of 16 CONSECUTIVE bursts (group g belongs to workgroup g % gridDim.x): neighbouring
+	// bursts share the 128-byte line their boundary falls in, and with them on one CU that line is fetched from HBM once
+	const unsigned n_groups = (n_bursts + 15u) >> 4;
+	const unsigned my_groups = (blockIdx.x < n_groups) ? (n_groups - blockIdx.x + n_wg - 1) / n_wg : 0u;
+	unsigned items = my_groups << 4;
+	if (my_groups && (my_groups - 1) * n_wg + blockIdx.x == n_groups - 1)
+		items -= (n_groups << 4) - n_bursts;                        // the batch's last group may be short
+	auto burst_of = [&](unsigned jj) { return (((jj >> 4) * n_wg + blockIdx.x) << 4) + (jj & 15u); };
 
 	// Software prefetch of the next burst (see burst_pull_kernel)
 	uint32_t pre_i[NLD];
@@ -189,7 +196,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 		}
 	};
 	if ((unsigned)wave < items)
-		prefetch((unsigned)wave * n_wg + blockIdx.x);
+		prefetch(burst_of((unsigned)wave));
 
 	// loader address: sample r*64 + lane -> phase lane&3, m = 16r + lane>>2
 	c32 *const pload = P + (lane & 3) * PH_A + PH_M0 + (lane >> 2);
@@ -256,7 +263,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 	DIAG_DECL;
 	unsigned j_next = 0;
 	for (unsigned j = (unsigned)wave; j < items; j = j_next) {
-		const unsigned b = j * n_wg + blockIdx.x;
+		const unsigned b = burst_of(j);
 		// Re-materialise the lane id per burst (2 VALU ops): otherwise every lane-derived address, tree-node
 		// offset and LUT base of every phase is hoisted out of this loop and kept live across it, which
 		// costs ~50 VGPRs and spills.
@@ -296,7 +303,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 		pend_mode = 0;
 		j_next = (unsigned)claim_take(ticket);
 		if (j_next < items)
-			prefetch(j_next * n_wg + blockIdx.x);
+			prefetch(burst_of(j_next));
 		DIAG_MARK(15);
 
 		if (type != TRXHIP_OFF) {                                   // Transceiver.cpp:704-707
@@ -769,7 +776,7 @@ extern "C" int trx_launch_pull4(const void *d_iq, int cf32, const trxhip_burst_p
 	if (const char *e = getenv("TRXHIP_WPB")) { const int v = atoi(e); if (v >= 1 && v <= wpb) wpb = v; }   // occupancy scan
 #endif
 	const size_t lds = K4_TABLES_BYTES + (size_t)wpb * K4_SLICE * sizeof(c32) + 16;     // + the workgroup's work counter
-	size_t need = (n_bursts + wpb - 1) / wpb;
+	size_t need = (n_bursts + 15) / 16;                             // work is handed out in groups of 16 bursts
 	size_t grid = (size_t)n_cu;
 #ifdef TRX_DIAG
 	if (const char *e = getenv("TRXHIP_GRID")) { const int v = atoi(e); if (v >= 1) grid = (size_t)v; }

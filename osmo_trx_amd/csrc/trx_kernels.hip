@@ -96,7 +96,14 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 	// the workgroup's bursts are blockIdx.x, blockIdx.x + gridDim.x, ...; its waves claim them one ahead from an LDS counter
 	// (a static split leaves the CU under-occupied for the last third of the kernel, see burst_pull4_kernel)
 	const unsigned n_wg = gridDim.x;
-	const unsigned items = (blockIdx.x < n_bursts) ? (n_bursts - blockIdx.x + n_wg - 1) / n_wg : 0u;
+	// items are handed out in groups of 16 CONSECUTIVE bursts (group g belongs to workgroup g % gridDim.x): neighbouring
+	// bursts share the 128-byte line their boundary falls in, and with them on one CU that line is fetched from HBM once
+	const unsigned n_groups = (n_bursts + 15u) >> 4;
+	const unsigned my_groups = (blockIdx.x < n_groups) ? (n_groups - blockIdx.x + n_wg - 1) / n_wg : 0u;
+	unsigned items = my_groups << 4;
+	if (my_groups && (my_groups - 1) * n_wg + blockIdx.x == n_groups - 1)
+		items -= (n_groups << 4) - n_bursts;                        // the batch's last group may be short
+	auto burst_of = [&](unsigned jj) { return (((jj >> 4) * n_wg + blockIdx.x) << 4) + (jj & 15u); };
 
 	// Software prefetch: the raw samples and the parameter word of this wave's NEXT burst sit in
 	// registers (NLD dwords per lane, coalesced 256 B per wave-load) while the current burst is
@@ -123,12 +130,12 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 		}
 	};
 	if ((unsigned)wave < items)
-		prefetch((unsigned)wave * n_wg + blockIdx.x);
+		prefetch(burst_of((unsigned)wave));
 
 	DIAG_DECL;
 	unsigned j_next = 0;
 	for (unsigned j = (unsigned)wave; j < items; j = j_next) {
-		const unsigned b = j * n_wg + blockIdx.x;
+		const unsigned b = burst_of(j);
 		const int ticket = claim_issue(wg_next);                   // this wave's next item; taken at prefetch time below
 		const unsigned prm0 = (unsigned)uni((int)pre_prm);
 		const int type = prm0 & 0xff;
@@ -163,11 +170,11 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 			}
 			j_next = (unsigned)claim_take(ticket);
 			if (j_next < items)
-				prefetch(j_next * n_wg + blockIdx.x);
+				prefetch(burst_of(j_next));
 		} else {
 			j_next = (unsigned)claim_take(ticket);
 			if (j_next < items)
-				pre_prm = reinterpret_cast<const uint32_t *>(params)[2 * (size_t)(j_next * n_wg + blockIdx.x)];
+				pre_prm = reinterpret_cast<const uint32_t *>(params)[2 * (size_t)burst_of(j_next)];
 			for (int i = lane; i < L; i += WAVE) {
 				c32 v;
 				if (CF32) {
@@ -422,7 +429,7 @@ extern "C" int trx_launch_pull(const void *d_iq, int cf32, const trxhip_burst_pa
 	const size_t lds = trx_pull_lds_bytes(L, wpb);
 	if (lds > 160 * 1024)
 		return TRXHIP_EINVAL;
-	size_t need = (n_bursts + wpb - 1) / wpb;
+	size_t need = (n_bursts + 15) / 16;                             // work is handed out in groups of 16 bursts
 	size_t grid = (size_t)n_cu * (size_t)((160 * 1024) / lds);
 	if (grid > need) grid = need;
 
