@@ -228,9 +228,9 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 				const int off = (r < 2 || lane < 32) ? r * WAVE : 159 - lane;    // symbol 128 + lane, capped at entry 159
 				const c32 d = dp[off];
 				const c32 rr = rp[off];
-				float sv = rr.x * d.x - rr.y * d.y;                     // real(rot * x)  (:2066-2068)
-				if (slice & 1)
-					sv = __builtin_amdgcn_fmed3f(0.5f * (sv + 1.0f), 0.0f, 1.0f);
+				float sv = fmaf(-rr.y, d.y, rr.x * d.x);                // real(rot * x)  (:2066-2068); fused demodulator: one rounding less
+				if (slice & 1)                                          // vectorSlicer: 0.5 * (x + 1) = fma(0.5, x, 0.5) bit for bit (scaling by 2 is exact)
+					sv = __builtin_amdgcn_fmed3f(fmaf(0.5f, sv, 0.5f), 0.0f, 1.0f);
 				if (r < 2) {
 					sp[r * WAVE] = sv;
 				} else {
@@ -301,7 +301,9 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 		DIAG_MARK(14);
 		flush(lane);                                               // the previous burst's output (its dec[] is still intact)
 		pend_mode = 0;
+		DIAG_MARK(16);
 		j_next = (unsigned)claim_take(ticket);
+		DIAG_MARK(17);
 		if (j_next < items)
 			prefetch(burst_of(j_next));
 		DIAG_MARK(15);
@@ -554,7 +556,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 							const c32 r = rrot[i];
 							sv = r.x * yr - r.y * yi;                       // real(rot * x)  (:2066-2068)
 							if (slice & 1)
-								sv = __builtin_amdgcn_fmed3f(0.5f * (sv + 1.0f), 0.0f, 1.0f);
+								sv = __builtin_amdgcn_fmed3f(fmaf(0.5f, sv, 0.5f), 0.0f, 1.0f);
 						}
 						so[i] = sv;
 					}
@@ -638,13 +640,23 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 					// the 1-SPS symbols go through dec[] (free once detection is done; the 8-PSK tail wants them there
 					// anyway): FIR lanes write theirs, the edge rounds overwrite the few partial ones, then every lane
 					// reads back lane + 64 r for a coalesced store.  dec[156..159] stay zero for the next detection.
+					if (n_lo == 0 && lo_tab && i_full_hi >= nwrite - 1) {
+						// the usual geometry (0 <= toa < 9 symbols): outputs 0..3 are the partial ones and lo_tab overwrites them,
+						// everything else up to the last symbol stored is a full output -- no per-output selection
+						if (lane < 52) {
 #pragma unroll
-					for (int j = 0; j < 3; j++) {
-						const int i = 3 * lane + j;
-						const bool full = (i >= i_full_lo) && (i <= i_full_hi);
-						const c32 d = full ? cmul(make_float2(acc[j].x, acc[j].y), scale) : make_float2(0.0f, 0.0f);
-						if (i < 156)
-							dec[i] = d;
+							for (int j = 0; j < 3; j++)
+								dec[3 * lane + j] = cmul(make_float2(acc[j].x, acc[j].y), scale);
+						}
+					} else {
+#pragma unroll
+						for (int j = 0; j < 3; j++) {
+							const int i = 3 * lane + j;
+							const bool full = (i >= i_full_lo) && (i <= i_full_hi);
+							const c32 d = full ? cmul(make_float2(acc[j].x, acc[j].y), scale) : make_float2(0.0f, 0.0f);
+							if (i < 156)
+								dec[i] = d;
+						}
 					}
 
 					// exact masked two-stage sum for 4 consecutive outputs i0..i0+3: lane = 16*e + t computes
@@ -713,7 +725,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 							const c32 rr = rrot[ii];
 							float sv = rr.x * d.x - rr.y * d.y;
 							if (slice & 1)
-								sv = __builtin_amdgcn_fmed3f(0.5f * (sv + 1.0f), 0.0f, 1.0f);
+								sv = __builtin_amdgcn_fmed3f(fmaf(0.5f, sv, 0.5f), 0.0f, 1.0f);
 							sv = (i < nwrite) ? sv : 0.0f;
 							if (i < soft_stride)
 								so[i] = sv;

@@ -364,7 +364,7 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 						const c32 r = rrot[i];
 						sv = r.x * d.x - r.y * d.y;                         // real(rot * x)  (:2066-2068)
 						if (slice & 1)                                      // vectorSlicer (:546-556): clamp(0.5*(s+1), 0, 1)
-							sv = __builtin_amdgcn_fmed3f(0.5f * (sv + 1.0f), 0.0f, 1.0f);
+							sv = __builtin_amdgcn_fmed3f(fmaf(0.5f, sv, 0.5f), 0.0f, 1.0f);   // 0.5 * (x + 1), bit for bit
 					}
 					so[i] = sv;
 				}

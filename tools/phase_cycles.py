@@ -18,8 +18,8 @@ trx.detect_demod(iq, dp, _diag_mask=int(os.environ.get('DIAG_MASK', '0'), 0)); t
 L.trxhip_diag_read(buf, 1)
 names = ["0 load/convert", "1 clip/energy/rssi", "2 decimate", "3 correlate", "4 argmax+gate", "5 peak ratio", "6 bisection",
          "7 C/I + amp", "8 demod setup", "9 edge round(s)", "10 composite FIR", "11 epilogue+stores", "12 result record"]
-names += ["13 wait first prefetched dword", "14 convert + LDS writes", "15 issue next prefetch"]
-tot = sum(buf[:16])
+names += ["13 wait first prefetched dword", "14 convert + LDS writes", "15 issue next prefetch", "16 flush previous burst's output", "17 take the work ticket"]
+tot = sum(buf[:18])
 for i, nm in enumerate(names):
     print(f"{nm:22s} {buf[i] / n:8.0f} cycles/burst  {100.0 * buf[i] / tot:5.1f} %")
 print(f"{'total':22s} {tot / n:8.0f}")
