@@ -77,19 +77,30 @@ def sq_counters(tag, bursts=1 << 20, waves_per_simd=4, waves_per_cu=16):
     if not per:
         return
     d = {}
+    n_simd, n_cu, n_xcd = 1024, 256, 8
     if "SQ_WAVE_CYCLES" in per:
         d["wave_cycles_per_burst"] = round(4 * per["SQ_WAVE_CYCLES"], 1)              # quad-cycles -> cycles
-    if "SQ_ACTIVE_INST_VALU" in per and "SQ_WAVE_CYCLES" in per:
-        d["valu_cycles_per_burst"] = round(4 * per["SQ_ACTIVE_INST_VALU"], 1)
-        d[f"valu_busy_at_{waves_per_simd}_waves_per_simd"] = round(waves_per_simd * per["SQ_ACTIVE_INST_VALU"] / per["SQ_WAVE_CYCLES"], 3)
-        d[f"salu_busy_at_{waves_per_simd}_waves_per_simd"] = round(waves_per_simd * per.get("SQ_ACTIVE_INST_SCA", 0) / per["SQ_WAVE_CYCLES"], 3)
-        d[f"lds_busy_at_{waves_per_cu}_waves_per_cu"] = round(waves_per_cu * per.get("SQ_LDS_IDX_ACTIVE", 0) / (4 * per["SQ_WAVE_CYCLES"]), 3)
-        for k in ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"):
+    if "GRBM_GUI_ACTIVE" in per and "SQ_WAVE_CYCLES" in per:
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs: kernel duration in shader cycles = value / 8 (and / wall time = the
+        # effective clock, MI355X_MICROARCH.md "DVFS give-back")
+        kcyc = per["GRBM_GUI_ACTIVE"] * bursts / n_xcd
+        d["kernel_cycles"] = round(kcyc)
+        d["mean_resident_waves_per_simd"] = round(4 * per["SQ_WAVE_CYCLES"] * bursts / (kcyc * n_simd), 2)
+        if "SQ_ACTIVE_INST_VALU" in per:
+            d["valu_busy"] = round(4 * per["SQ_ACTIVE_INST_VALU"] * bursts / (kcyc * n_simd), 3)      # of every SIMD, whole kernel
+        if "SQ_ACTIVE_INST_SCA" in per:
+            d["salu_busy"] = round(4 * per["SQ_ACTIVE_INST_SCA"] * bursts / (kcyc * n_simd), 3)
+        if "SQ_LDS_IDX_ACTIVE" in per:
+            d["lds_busy"] = round(per["SQ_LDS_IDX_ACTIVE"] * bursts / (kcyc * n_cu), 3)                 # cycles, per CU
+    if "SQ_WAVE_CYCLES" in per:
+        for k in ("SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"):
             if k in per:
                 d["wave_time_share_" + k[3:].lower()] = round(per[k] / per["SQ_WAVE_CYCLES"], 3)
     out = {"tag": tag, "kernel": KERNEL, "bursts_per_launch": bursts, "per_burst": per, "derived": d,
            "note": "rocprofv3 --pmc, three separate passes (tools/run_profiles.sh), bench.py --main-only --steps 2; "
-                   "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are quad-cycles (MI355X_MICROARCH.md)"}
+                   "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are quad-cycles (MI355X_MICROARCH.md); busy fractions are over the "
+                   "kernel's duration on all 1024 SIMDs / 256 CUs (GRBM_GUI_ACTIVE / 8 XCDs), so they include the time a SIMD holds "
+                   "fewer than its 4 waves (mean_resident_waves_per_simd)"}
     json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_sq_counters.json"), "w"), indent=1)
     print(json.dumps(d, indent=1))
 
