@@ -474,3 +474,33 @@ def test_soft_rows_shorter_and_longer_than_a_burst(trx, stride):
         g_res, g_soft = run_gpu(trx, iq, params, 4, soft_stride=stride, exact=exact)
         check_parity(g_res, g_soft, o_res, o_soft, soft_atol=0.0 if exact else FUSED_SOFT_ATOL)
     assert not o_soft[:, 148:].any()
+
+
+@pytest.mark.parametrize("sps", [4, 1])
+def test_results_do_not_depend_on_the_batch_size(trx, sps):
+    """The kernels hand bursts out dynamically (waves claim them from a per-workgroup counter, in groups of 16 consecutive
+    bursts per workgroup; soft bits and result record of a burst are stored while the next one is being processed).  None of
+    that may show: every burst's record and soft row are the same whether it is processed alone, in a ragged batch (sizes
+    around the group and workgroup granularities: 1, 15, 16, 17, 255, 257, 4095, 4097) or in the whole batch, at any offset.
+    Mixed slot types so that the different code paths follow each other inside one wave."""
+    from osmo_trx_amd import synth
+    n = 12288
+    if sps == 4:
+        iq, params = synth.make_mixed_bursts(n, "cuda:0")
+        params["type"][5::64] = O.OFF
+        params["type"][9::64] = O.IDLE
+    else:
+        iq, params, _ = synth.make_normal_bursts(n, "cuda:0", 1)
+    d_p = trx.params_tensor(params)
+    for exact in (False, True):
+        if sps == 1 and not exact:
+            continue                                           # one demodulator at 1 SPS
+        res, soft = trx.detect_demod(iq, d_p, sps=sps, exact=exact)
+        torch.cuda.synchronize()
+        off = 0
+        for m in (1, 15, 16, 17, 255, 257, 4095, 4097, 1, 2, 33):
+            sl = slice(off, off + m)
+            r2, s2 = trx.detect_demod(iq[sl].contiguous(), d_p[sl].contiguous(), sps=sps, exact=exact)
+            assert torch.equal(res[sl], r2) and torch.equal(soft[sl], s2), (sps, exact, m, off)
+            off += m
+        assert off <= n
