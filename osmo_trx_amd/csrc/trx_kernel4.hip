@@ -18,9 +18,10 @@
 //         outputs whose decimator window straddles those edges are recomputed with the exact masked two-stage
 //         sum, so the result differs from the reference only by rounding (<= 2e-6 of full scale; bar 1e-4).
 //     Detection (rc, TOA, amp, C/I) is shared and bit-exact in both modes.
-//   * occupancy: 16 waves per CU (4 per SIMD) for the fused kernel -- per-wave LDS is cut to 7.7 KB (NARROW
-//     buffers, trx_device.h) and the kernel kept under 128 VGPRs; measured, the kernel is bound by VALU + LDS
-//     issue (profiles/), so every reduction below is an instruction-count reduction.
+//   * occupancy: 16 waves per CU (4 per SIMD) -- per-wave LDS is cut to 7.7 KB (NARROW buffers, trx_device.h) and the
+//     kernel kept at 128 VGPRs.  A wave is one serial program per burst and a SIMD runs four: what counts is that all
+//     four stay resident to the end of the launch (waves CLAIM bursts, they are not dealt them) and the length of a
+//     wave's timeline per burst, to which every issue slot -- vector, scalar, wait -- adds the same.
 #include <atomic>
 #include "trx_device.h"
 
@@ -80,12 +81,12 @@ __device__ __forceinline__ PhBase ph_bases(const c32 *P, int ph0, int m0)
 	return b;
 }
 
-// waves per workgroup (one workgroup per CU).  Fused: 16 = 4 per SIMD (<= 128 VGPRs; 36 KB of tables + 16 x 7.7 KB
-// slices = 158.2 KB of the 160 KB LDS, which is why the per-wave buffers are the NARROW ones).  Measured 12 -> 16
-// waves: 378 -> 420 Mbursts/s; the kernel is latency bound per wave (profiles/).  Exact: 168 VGPRs.
-#define K4_WPB_FUSED 16
-#define K4_WPB_EXACT 16            // int16 input; the complex64-input exact kernel (20 prefetch registers) stays at 12
-#define K4_WPB(CF_, EX_) ((CF_) ? 12 : 16)            // complex64 input (sigProcLib-signature calls): 20 prefetch registers
+// waves per workgroup (one persistent workgroup per CU): 16 = 4 per SIMD for int16 input, both demodulators (<= 128
+// VGPRs; 36.6 KB of tables + 16 x 7.7 KB slices + the work counter = 159.7 KB of the 160 KB LDS, which is why the per-wave
+// buffers are the NARROW ones); 12 for complex64 input (sigProcLib-signature calls: 20 prefetch registers).  Throughput
+// is (resident waves) / (a wave's time per burst): 12 -> 16 waves was worth 11 % in round 1, and keeping all 16 busy until
+// the end of the launch (work claiming, below) another 13 % in round 2.
+#define K4_WPB(CF_, EX_) ((CF_) ? 12 : 16)
 
 template <bool CF32, bool EXACT>
 __global__ void __launch_bounds__(K4_WPB(CF32, EXACT) * WAVE)
