@@ -15,62 +15,80 @@
 
 TRX_SHIM_NS_BEGIN
 
-#define NORMAL_BURST_NBITS 148
-#define EDGE_BURST_NBITS 444
+/* soft bits per burst: GMSK, 8-PSK (sigProcLib.h:27-28) */
+enum { NORMAL_BURST_NBITS = 148, EDGE_BURST_NBITS = 444 };
 
-/** Codes for burst types of received bursts (sigProcLib.h:30-38) */
-enum CorrType { OFF, TSC, EXT_RACH, RACH, SCH, EDGE, IDLE };
+/* what a timeslot is expected to carry (sigProcLib.h:30-38); the values are part of the interface (0 .. 6) */
+enum CorrType {
+	OFF = 0,        /* timeslot is off */
+	TSC = 1,        /* normal burst, GMSK */
+	EXT_RACH = 2,   /* access burst, training sequences TS0 .. TS2 */
+	RACH = 3,       /* access burst, TS0 */
+	SCH = 4,        /* synchronisation burst (MS side) */
+	EDGE = 5,       /* normal burst, 8-PSK, falls back to TSC */
+	IDLE = 6        /* nothing expected: noise measurement */
+};
 
-/** sigProcLib.h:40-46 */
-enum SignalError { SIGERR_NONE, SIGERR_BOUNDS, SIGERR_CLIP, SIGERR_UNSUPPORTED, SIGERR_INTERNAL };
+/* negated, these are detectAnyBurst()'s error returns (sigProcLib.h:40-46) */
+enum SignalError {
+	SIGERR_NONE = 0,
+	SIGERR_BOUNDS = 1,
+	SIGERR_CLIP = 2,
+	SIGERR_UNSUPPORTED = 3,
+	SIGERR_INTERNAL = 4
+};
 
+/* peak-to-average ratio a correlation has to exceed (sigProcLib.h:48) */
 #define BURST_THRESH 4.0
 
-/** estimated burst parameters (sigProcLib.h:113-118) */
+/* the detector's findings, consumed by the demodulator (sigProcLib.h:113-118): 20 bytes, toa at 8, tsc at 12, ci at 16 */
 struct estim_burst_params {
-	complex amp;
-	float toa;
-	uint8_t tsc;
-	float ci;
+	complex amp;    /* channel amplitude */
+	float toa;      /* symbols, relative to the expected position */
+	uint8_t tsc;    /* training sequence found */
+	float ci;       /* dB */
 };
 
-/** Setup: generates the tables on the host, uploads them to the GPU, creates the context.
- *  Returns false when no MI355X is usable (there is no CPU fallback).  sigProcLib.h:57 */
+/* which part of the buffer detectSCHBurst() searches (sigProcLib.h:139-143) */
+enum class sch_detect_type { SCH_DETECT_FULL, SCH_DETECT_NARROW, SCH_DETECT_BUFFER };
+
+/* ---- life cycle (sigProcLib.h:57, :60).  Setup generates the tables on the host, uploads them and creates the GPU
+ * context; false when no MI355X is usable -- there is no CPU fallback. */
 bool sigProcLibSetup();
-/** sigProcLib.h:60 */
 void sigProcLibDestroy(void);
 
-/** Operate soft slicer on a soft-bit vector (sigProcLib.h:63) */
-void vectorSlicer(float *dest, const float *src, size_t len);
+/* ---- the receive path in the order pullRadioVector() walks it (Transceiver.cpp:724-803) */
 
-/** Rough energy estimator (sigProcLib.h:105): mean |x|^2 of windowLength samples taken at stride 4 */
-float energyDetect(const signalVector &rxBurst, unsigned windowLength);
+/* mean |x|^2 over `window` samples taken at stride 4 (sigProcLib.h:105) */
+float energyDetect(const signalVector &burst, unsigned window);
 
-/** 8-PSK/GMSK/RACH burst detector (sigProcLib.h:131-137)
- *  @return CorrType (>0) if detected, 0 if not, -SignalError on error */
-int detectAnyBurst(const signalVector &burst, unsigned tsc, float threshold, int sps, CorrType type,
-		   unsigned max_toa, struct estim_burst_params *ebp);
+/* > 0: the CorrType found, 0: nothing, < 0: -SignalError (sigProcLib.h:131-137) */
+int detectAnyBurst(const signalVector &burst,
+		   unsigned tsc,
+		   float threshold,
+		   int sps,
+		   CorrType expected,
+		   unsigned max_toa,
+		   struct estim_burst_params *found);
 
-/** Fractional + integer delay (sigProcLib.h:97, sigProcLib.cpp:1046-1098).  out == NULL: returns a new vector the
- *  caller deletes; otherwise `out` is resized to the result and returned.  NULL on a GPU error. */
-signalVector *delayVector(const signalVector *in, signalVector *out, float delay);
+/* soft bits of a detected burst as a new SoftVector the caller deletes (Transceiver.cpp:805), NULL on error
+ * (sigProcLib.h:151-152) */
+SoftVector *demodAnyBurst(const signalVector &burst, CorrType detected, int sps, struct estim_burst_params *found);
 
-/** In-place complex scaling (sigProcLib.h:94, sigProcLib.cpp:1188-1213) */
-void scaleVector(signalVector &x, complex scale);
+/* -1 .. +1 soft values to 0 .. 1 (sigProcLib.h:63) */
+void vectorSlicer(float *out, const float *in, size_t n);
 
-/** SCH synchronisation-burst search of the MS side (sigProcLib.h:139-148, sigProcLib.cpp:1805-1861)
- *  @return 1 if detected (ebp: toa, amp, ci), 0 if not (toa = amp = 0), -1 on error */
-enum class sch_detect_type {
-	SCH_DETECT_FULL,
-	SCH_DETECT_NARROW,
-	SCH_DETECT_BUFFER,
-};
-int detectSCHBurst(signalVector &rxBurst, float detectThreshold, int sps, sch_detect_type state,
-		   struct estim_burst_params *ebp);
+/* ---- helpers that are entry points of their own */
 
-/** Demodulate burst based on type and output soft bits (sigProcLib.h:151-152).
- *  Returns a new SoftVector the caller deletes (Transceiver.cpp:805), or NULL. */
-SoftVector *demodAnyBurst(const signalVector &burst, CorrType type, int sps, struct estim_burst_params *ebp);
+/* fractional + integer delay (sigProcLib.h:97, sigProcLib.cpp:1046-1098).  dst == NULL: a new vector the caller deletes;
+ * otherwise dst is resized to the result and returned.  NULL on a GPU error. */
+signalVector *delayVector(const signalVector *src, signalVector *dst, float delay);
+
+/* x *= factor, in place (sigProcLib.h:94, sigProcLib.cpp:1188-1213) */
+void scaleVector(signalVector &x, complex factor);
+
+/* 1: found (toa, amp, ci filled), 0: not found (toa = amp = 0), -1: error (sigProcLib.h:144-148, sigProcLib.cpp:1805-1861) */
+int detectSCHBurst(signalVector &buffer, float threshold, int sps, sch_detect_type where, struct estim_burst_params *found);
 
 TRX_SHIM_NS_END
 #endif
