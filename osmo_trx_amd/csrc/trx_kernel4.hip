@@ -382,7 +382,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 					rc = hit ? TRXHIP_TSC : (clip ? -TRXHIP_SIGERR_CLIP : 0);                 // :1764, :1953-1954
 					toa -= 10.0f;                                                              // :1768
 					out_tsc = tsc;
-				} else if (type == TRXHIP_RACH && max_toa <= 64) {
+				} else if ((type == TRXHIP_RACH || type == TRXHIP_EXT_RACH) && max_toa <= 64) {
 					// Access bursts, straight-line as well: detectRACHBurst (:1782-1803) with TS0 only is one window -- target 48,
 					// head 8, tail 8 + max_toa -> start 39, len 16 + max_toa <= 80, 40 taps -- over dec[0 .. 39 + len): two
 					// decimation rounds (lane, lane + 64), two correlation rounds inside detect_burst().
@@ -408,12 +408,21 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 					unit_bad |= (__ballot(bad) != 0ull) ? 1 : 0;
 					wave_sync();
 					DIAG_MARK(2);
-					const int hit = detect_burst<true, true>(dec, 156, cz, lseq + LSEQ_RACH(0), lhdr + 8 * 8, 40, thresh, 39, len, sincv,
-										 pkc, lane, &toa, &amp, &ci, slice, unit_bad ? -1 : 8 DIAG_PASS);
+					int hit = detect_burst<true, true>(dec, 156, cz, lseq + LSEQ_RACH(0), lhdr + 8 * 8, 40, thresh, 39, len, sincv,
+									   pkc, lane, &toa, &amp, &ci, slice, unit_bad ? -1 : 8 DIAG_PASS);
 					wave_sync();
-					rc = hit ? TRXHIP_RACH : (clip ? -TRXHIP_SIGERR_CLIP : 0);                // :1764, :1797-1800
-					toa -= 8.0f;                                                               // :1768
 					out_tsc = 0;                                                               // ebp->tsc = i (:1797)
+					if (!hit && type == TRXHIP_EXT_RACH) {
+						// extended access bursts: TS1, then TS2 over the same window, first hit wins (:1791-1800)
+						for (int c = 1; c < 3 && !hit; c++) {
+							hit = detect_burst<true, true>(dec, 156, cz, lseq + LSEQ_RACH(c), lhdr + 8 * (8 + c), 40, thresh, 39, len,
+										       sincv, pkc, lane, &toa, &amp, &ci, slice, unit_bad ? -1 : 8 + c DIAG_PASS);
+							wave_sync();
+							out_tsc = c;
+						}
+					}
+					rc = hit ? type : (clip ? -TRXHIP_SIGERR_CLIP : 0);                       // :1764, :1797-1800
+					toa -= 8.0f;                                                               // :1768
 				} else {
 					DetectOut d;
 					rc = detect_any_burst<true, true>(type, tsc, max_toa, clip, decimate, dec, 156, cz, lseq, lhdr, thresh, sincv, pkc,
