@@ -2,7 +2,7 @@
 """Throughput vs waves per CU (diagnostic build): TRXHIP_LIB=.../libtrxhip_diag.so python tools/occupancy_scan.py"""
 import os, sys, subprocess
 if len(sys.argv) == 1:
-    for w in (1, 2, 3, 4, 6, 8, 10, 12):
+    for w in (1, 2, 4, 6, 8, 10, 12, 14, 16):
         env = dict(os.environ, TRXHIP_WPB=str(w))
         out = subprocess.run([sys.executable, __file__, "run"], env=env, capture_output=True, text=True).stdout.strip()
         print(f"waves/CU {w:2d}: {out}")
@@ -10,7 +10,7 @@ if len(sys.argv) == 1:
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from osmo_trx_amd import TrxHip, synth
-n = 1 << 18
+n = 1 << 20
 trx = TrxHip(0)
 iq, params, _ = synth.make_normal_bursts(n, "cuda:0", 4)
 dp = trx.params_tensor(params)
