@@ -274,6 +274,9 @@ typedef struct trxhip_hostpipe_slot {      /* pinned host memory, valid until tr
 int  trxhip_hostpipe_create(trxhip_ctx *ctx, const trxhip_hostpipe_cfg *cfg, trxhip_hostpipe **out);
 void trxhip_hostpipe_destroy(trxhip_hostpipe *p);
 int  trxhip_hostpipe_slot_buffers(trxhip_hostpipe *p, int slot, trxhip_hostpipe_slot *out);
+/* change the scalar parameters of later submits (detection threshold, rxFullScale, rssi_offset) without touching the
+ * staging buffers: callers whose channels differ in full scale share one pipe */
+int  trxhip_hostpipe_set_levels(trxhip_hostpipe *p, float threshold, float full_scale, float rssi_offset);
 /* enqueue slot's first n_bursts bursts; returns at once.  The slot's buffers must not be touched until wait(). */
 int  trxhip_hostpipe_submit(trxhip_hostpipe *p, int slot, size_t n_bursts);
 /* block until the slot's job has finished (TRXHIP_OK), or return TRXHIP_EIO if it failed */

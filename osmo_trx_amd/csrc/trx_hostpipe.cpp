@@ -116,6 +116,16 @@ int trxhip_hostpipe_slot_buffers(trxhip_hostpipe *p, int slot, trxhip_hostpipe_s
 	return TRXHIP_OK;
 }
 
+int trxhip_hostpipe_set_levels(trxhip_hostpipe *p, float threshold, float full_scale, float rssi_offset)
+{
+	if (!p || !(full_scale > 0.0f) || !(threshold >= 0.0f))
+		return TRXHIP_EINVAL;
+	p->cfg.threshold = threshold;
+	p->cfg.full_scale = full_scale;
+	p->cfg.rssi_offset = rssi_offset;
+	return TRXHIP_OK;
+}
+
 int trxhip_hostpipe_submit(trxhip_hostpipe *p, int slot, size_t n)
 {
 	if (!p || slot < 0 || slot >= p->cfg.depth || n > p->cfg.max_bursts)

@@ -11,6 +11,17 @@
 // into pinned memory -- no second copy) that is launched when it holds max_batch bursts or its first burst has
 // waited timeout_us; `depth` batches are in flight on their own streams (trxhip_hostpipe_*), so upload, kernels and
 // download of consecutive batches overlap.
+//
+// Reservation protocol (the only shared write of a push is one fetch_add on the filling batch's `reserved` word):
+//   * exactly one batch at a time is OPEN (reserved < max_batch): the one `filling` names.  Every other batch -- closed and
+//     waiting for the submitter, in flight, or parked in free_q -- holds reserved >= CLOSED, so a producer that read
+//     `filling`, was descheduled for a whole batch round trip and only then executes its fetch_add lands on a closed word
+//     and retries with the current `filling`.  A batch is re-opened (epoch bumped, first_ns cleared, reserved = 0) only at
+//     the moment it is published as `filling`, under `mu`.  Hence a reservation always lands in the open batch, batches are
+//     closed, submitted and completed in the order they were opened, and a channel's bursts come back in push order.
+//   * stop() joins the submitter, lets the completion thread drain what was submitted, and discards bursts that were
+//     gathered but not submitted (their pull() returns -EIO, as after any stop); start() after stop() begins from empty
+//     FIFOs.  stop() may race with push()/pull(); the destructor may not.
 #include <atomic>
 #include <cerrno>
 #include <chrono>
@@ -61,6 +72,18 @@ int trxdPackBurstInd(uint8_t *buf, const BurstIndication *bi, unsigned version)
 namespace {
 typedef std::chrono::steady_clock Clock;
 inline int64_t now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(Clock::now().time_since_epoch()).count(); }
+/* condition_variable::wait_for() on the steady clock is pthread_cond_clockwait(), which gcc 11's ThreadSanitizer does not
+ * intercept (it then believes the mutex stays held across the wait and reports double locks and races between holders of
+ * the same mutex).  Under TSan only, wait on the system clock: pthread_cond_timedwait(), which it does model. */
+template <typename Rep, typename Period>
+inline void timed_wait(std::condition_variable &cv, std::unique_lock<std::mutex> &lk, std::chrono::duration<Rep, Period> d)
+{
+#ifdef __SANITIZE_THREAD__
+	cv.wait_until(lk, std::chrono::system_clock::now() + d);
+#else
+	cv.wait_for(lk, d);
+#endif
+}
 
 struct Route {
 	uint16_t chan;
@@ -91,11 +114,12 @@ struct Chan {
 	std::atomic<int> waiting{0};                /* the consumer sleeps on cv (checked by the completion thread after publishing) */
 	alignas(64) size_t head = 0;                /* entries pulled so far (consumer's own) */
 	alignas(64) std::atomic<size_t> outstanding{0};     /* pushed and not yet pulled: the reference's FIFO occupancy */
+	std::atomic<int> trxd_version{0};           /* TRXD header version of this channel (mVersionTRXD[chan], Transceiver.cpp:1238) */
 };
-const uint32_t CLOSED = 1u << 30;
+const uint64_t CLOSED = 1ull << 62;             /* far above any sum of stale fetch_adds */
 struct Batch {
 	/* the one word every push touches sits alone in its cache line */
-	alignas(64) std::atomic<uint32_t> reserved{0};      /* slots handed out; >= CLOSED once the batch is closed */
+	alignas(64) std::atomic<uint64_t> reserved{CLOSED}; /* slots handed out; >= CLOSED unless this is the open (filling) batch */
 	alignas(64) std::atomic<int64_t> first_ns{0};       /* arrival of the first burst (0 = none yet) */
 	trxhip_hostpipe_slot h;
 	uint32_t count = 0;                         /* final size once closed */
@@ -116,8 +140,21 @@ struct BurstGatherer::Impl {
 	alignas(64) int pad_ = 0;
 	std::deque<int> free_q, closed_q, flight_q;
 	std::atomic<bool> stopping{false}, running{false};
+	bool submitter_done = false;                /* under mu: nothing more will enter flight_q */
 	std::thread submitter, completer;
-	std::atomic<uint64_t> n_batches{0}, n_dropped{0};
+	std::atomic<uint64_t> n_batches{0}, n_dropped{0}, n_rejected{0};
+
+	/* make parked batch s the open one (caller holds mu, filling < 0 or being replaced): the ONLY place a batch is re-armed */
+	void publish_locked(int s)
+	{
+		Batch &b = batch[s];
+		b.count = 0;
+		b.epoch++;
+		b.first_ns.store(0, std::memory_order_relaxed);
+		b.reserved.store(0, std::memory_order_release);
+		filling.store(s, std::memory_order_release);
+		cv_space.notify_all();
+	}
 
 	/* close batch f (full, or its first burst timed out) and make the next free one the filling batch; idempotent */
 	void close_locked(int f)
@@ -125,15 +162,16 @@ struct BurstGatherer::Impl {
 		if (filling.load(std::memory_order_relaxed) != f)
 			return;
 		Batch &b = batch[f];
-		const uint32_t old = b.reserved.exchange(CLOSED, std::memory_order_acq_rel);
-		b.count = old < cfg.max_batch ? old : (uint32_t)cfg.max_batch;
+		const uint64_t old = b.reserved.exchange(CLOSED, std::memory_order_acq_rel);   /* < CLOSED: f was the open batch */
+		b.count = old < cfg.max_batch ? (uint32_t)old : (uint32_t)cfg.max_batch;
 		closed_q.push_back(f);
-		int next = -1;
 		if (!free_q.empty()) {
-			next = free_q.front();
+			const int next = free_q.front();
 			free_q.pop_front();
+			publish_locked(next);
+		} else {
+			filling.store(-1, std::memory_order_release);
 		}
-		filling.store(next, std::memory_order_release);
 		cv_work.notify_all();
 	}
 
@@ -165,10 +203,10 @@ struct BurstGatherer::Impl {
 					close_locked(f);
 					continue;
 				}
-				cv_work.wait_for(lk, std::chrono::nanoseconds(deadline - now));
+				timed_wait(cv_work, lk, std::chrono::nanoseconds(deadline - now));
 			} else {
 				/* nothing gathered: a push of a first burst does not take `mu`, so poll at the timeout's granularity */
-				cv_work.wait_for(lk, std::chrono::microseconds(cfg.timeout_us ? cfg.timeout_us : 1));
+				timed_wait(cv_work, lk, std::chrono::microseconds(cfg.timeout_us ? cfg.timeout_us : 1));
 			}
 		}
 	}
@@ -180,9 +218,9 @@ struct BurstGatherer::Impl {
 		std::vector<uint32_t> order, first, fill;
 		std::unique_lock<std::mutex> lk(mu);
 		for (;;) {
-			cv_done.wait(lk, [&] { return stopping || !flight_q.empty(); });
+			cv_done.wait(lk, [&] { return (stopping && submitter_done) || !flight_q.empty(); });
 			if (flight_q.empty())
-				return;                                        /* stopping and drained */
+				return;                                        /* stopping, submitter gone, everything submitted delivered */
 			const int s = flight_q.front();
 			flight_q.pop_front();
 			Batch &b = batch[s];
@@ -219,8 +257,12 @@ struct BurstGatherer::Impl {
 						memcpy(e, &hd, sizeof(hd));
 						if (ok && b.h.pkt)
 							memcpy(e + sizeof(Entry), b.h.pkt + (size_t)i * stride, hd.pkt_len);
-						else if (ok && b.h.soft && !hd.res.idle)
-							memcpy(e + sizeof(Entry), b.h.soft + (size_t)i * stride, 4u * hd.res.nbits_div4 * sizeof(float));
+						else if (ok && b.h.soft && !hd.res.idle) {
+							/* the kernels report nbits = 444 for an 8-PSK detection whatever the row width: never copy
+							 * more than the row (and the ring entry) holds */
+							const size_t nb = 4u * hd.res.nbits_div4;
+							memcpy(e + sizeof(Entry), b.h.soft + (size_t)i * stride, (nb < stride ? nb : stride) * sizeof(float));
+						}
 					}
 				}
 				ch.tail.store(tail, std::memory_order_seq_cst);          /* publish; then look for a sleeping consumer */
@@ -230,15 +272,11 @@ struct BurstGatherer::Impl {
 				}
 			}
 			lk.lock();
-			b.count = 0;
-			b.epoch++;
-			b.first_ns.store(0, std::memory_order_relaxed);
-			b.reserved.store(0, std::memory_order_release);
-			if (filling.load(std::memory_order_relaxed) < 0)
-				filling.store(s, std::memory_order_release);
+			/* parked batches stay CLOSED (a stale reservation must fail); re-armed only when published */
+			if (filling.load(std::memory_order_relaxed) < 0 && !stopping)
+				publish_locked(s);
 			else
 				free_q.push_back(s);
-			cv_space.notify_all();
 		}
 	}
 };
@@ -287,8 +325,13 @@ bool BurstGatherer::start()
 	c.threshold = BURST_THRESH;
 	c.full_scale = (float)m.cfg.rxFullScale;
 	c.rssi_offset = (float)m.cfg.rssi_offset;
+	if (m.pipe) {                                                  /* restart: the previous run's staging slots, streams, events */
+		trxhip_hostpipe_destroy(m.pipe);
+		m.pipe = nullptr;
+	}
 	if (trxhip_hostpipe_create(trxsigproc_context(), &c, &m.pipe) != TRXHIP_OK)
 		return false;
+	std::lock_guard<std::mutex> g(m.mu);
 	m.batch = std::vector<Batch>(m.cfg.depth);
 	m.free_q.clear(); m.closed_q.clear(); m.flight_q.clear();
 	for (int s = 0; s < m.cfg.depth; s++) {
@@ -299,11 +342,21 @@ bool BurstGatherer::start()
 		if (s)
 			m.free_q.push_back(s);
 	}
-	m.chan = std::vector<Chan>(m.cfg.chans);
-	for (size_t c2 = 0; c2 < m.cfg.chans; c2++)
-		m.chan[c2].ring.resize(m.cfg.fifo_depth * m.entry_bytes);
+	if (m.chan.size() != m.cfg.chans) {
+		m.chan = std::vector<Chan>(m.cfg.chans);
+		for (size_t c2 = 0; c2 < m.cfg.chans; c2++)
+			m.chan[c2].trxd_version.store(m.cfg.trxd_version < 0 ? 0 : m.cfg.trxd_version, std::memory_order_relaxed);
+	}
+	for (size_t c2 = 0; c2 < m.cfg.chans; c2++) {                  /* empty FIFOs (a stopped run may have left bursts behind) */
+		Chan &ch = m.chan[c2];
+		ch.ring.assign(m.cfg.fifo_depth * m.entry_bytes, 0);
+		ch.head = 0;
+		ch.tail.store(0, std::memory_order_relaxed);
+		ch.outstanding.store(0, std::memory_order_relaxed);
+	}
 	m.stopping = false;
-	m.filling.store(0);
+	m.submitter_done = false;
+	m.publish_locked(0);
 	m.running = true;
 	m.submitter = std::thread([&m] { m.submit_loop(); });
 	m.completer = std::thread([&m] { m.complete_loop(); });
@@ -322,8 +375,22 @@ void BurstGatherer::stop()
 		m.cv_done.notify_all();
 		m.cv_space.notify_all();
 	}
-	m.submitter.join();
-	m.completer.join();
+	m.submitter.join();                                            /* it may have been inside trxhip_hostpipe_submit() */
+	{
+		std::lock_guard<std::mutex> g(m.mu);
+		m.submitter_done = true;
+		m.cv_done.notify_all();
+	}
+	m.completer.join();                                            /* delivers every batch that was submitted */
+	{
+		/* gathered but never submitted: discarded (pull() on an empty FIFO of a stopped gatherer returns -EIO) */
+		std::lock_guard<std::mutex> g(m.mu);
+		const int f = m.filling.load(std::memory_order_relaxed);
+		if (f >= 0)
+			m.batch[f].reserved.store(CLOSED, std::memory_order_release);
+		m.filling.store(-1, std::memory_order_release);
+		m.closed_q.clear();
+	}
 	for (size_t c = 0; c < m.chan.size(); c++) {
 		std::lock_guard<std::mutex> g(m.chan[c].mu);
 		m.chan[c].cv.notify_all();
@@ -353,6 +420,10 @@ size_t BurstGatherer::pushSlot(const size_t *chans, const BurstRequest *rqs, siz
 	size_t n_ok = 0;
 	for (size_t k = 0; k < n; k++) {
 		bool ok = chans[k] < m.chan.size() && rqs[k].iq;
+		if (ok && rqs[k].type == EDGE && !m.cfg.egprs) {              /* 444-bit rows were not configured (cfg->egprs) */
+			m.n_rejected++;
+			ok = false;
+		}
 		if (ok) {
 			Chan &ch = m.chan[chans[k]];
 			if (ch.outstanding.fetch_add(1, std::memory_order_acq_rel) >= m.cfg.fifo_depth) {
@@ -384,13 +455,19 @@ size_t BurstGatherer::pushSlot(const size_t *chans, const BurstRequest *rqs, siz
 			continue;
 		}
 		Batch &b = m.batch[f];
+#ifdef TRX_GATHERER_TEST_STALL
+		TRX_GATHERER_TEST_STALL();      /* tests/gatherer_stub: deschedule here for longer than a batch round trip */
+#endif
 		const uint32_t want = (uint32_t)(n_ok - done);
-		const uint32_t idx0 = b.reserved.fetch_add(want, std::memory_order_acq_rel);   /* the only shared write of a push */
-		if (idx0 >= m.cfg.max_batch) {                             /* full or closed: wait for the roll-over */
+		const uint64_t idx0_ = b.reserved.fetch_add(want, std::memory_order_acq_rel);  /* the only shared write of a push */
+		if (idx0_ >= m.cfg.max_batch) {
+			/* full (its last taker is rolling it over), or closed / in flight / parked (this thread read `filling` a
+			 * while ago): nothing was reserved -- the word is >= max_batch and stays so until the batch is re-opened */
 			if (m.filling.load(std::memory_order_acquire) == f)
 				std::this_thread::yield();
 			continue;
 		}
+		const uint32_t idx0 = (uint32_t)idx0_;
 		const uint32_t got = (idx0 + want <= m.cfg.max_batch) ? want : (uint32_t)m.cfg.max_batch - idx0;
 		if (idx0 == 0) {
 			b.first_ns.store(now_ns(), std::memory_order_release);     /* arms the timeout */
@@ -416,7 +493,7 @@ size_t BurstGatherer::pushSlot(const size_t *chans, const BurstRequest *rqs, siz
 				trxhip_trxd_meta &mt = b.h.meta[idx];
 				mt.fn = rq.fn;
 				mt.tn = rq.tn;
-				mt.version = (uint8_t)m.cfg.trxd_version;
+				mt.version = (uint8_t)m.chan[chans[k]].trxd_version.load(std::memory_order_relaxed);
 				mt.tss = 0;
 				mt.reserved = 0;
 			}
@@ -465,6 +542,23 @@ int BurstGatherer::pull(size_t c, BurstIndication *bi, uint8_t *pkt, size_t *pkt
 	return hd.code;
 }
 
+bool BurstGatherer::setTrxdVersion(size_t c, int version)
+{
+	Impl &m = *impl_;
+	if (m.cfg.trxd_version < 0 || version < 0 || version > 1)
+		return false;                                                  /* float mode is gatherer-wide */
+	if (m.chan.size() != m.cfg.chans) {                                /* before the first start(): create the channels now */
+		m.chan = std::vector<Chan>(m.cfg.chans);
+		for (size_t k = 0; k < m.cfg.chans; k++)
+			m.chan[k].trxd_version.store(m.cfg.trxd_version, std::memory_order_relaxed);
+	}
+	if (c >= m.chan.size())
+		return false;
+	m.chan[c].trxd_version.store(version, std::memory_order_relaxed);
+	return true;
+}
+
+uint64_t BurstGatherer::rejected() const { return impl_->n_rejected.load(); }
 uint64_t BurstGatherer::batches() const { return impl_->n_batches.load(); }
 uint64_t BurstGatherer::dropped() const { return impl_->n_dropped.load(); }
 

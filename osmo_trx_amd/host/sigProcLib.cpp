@@ -389,24 +389,36 @@ int pullRadioVectorBatch(const BurstRequest *req, size_t n, int sps, size_t burs
 		return 0;
 	if (!g_ctx || !req || !out)
 		return -EIO;
-	/* pinned staging slots, one stream each: while chunk k's kernels run, chunk k+1 uploads and chunk k-1 downloads */
-	trxhip_hostpipe_cfg c;
-	memset(&c, 0, sizeof(c));
-	c.max_bursts = 2048;
-	c.depth = 3;
-	c.burst_len = (int32_t)burst_len;
-	c.sps = sps;
-	c.soft_stride = (int32_t)stride;
-	c.flags = TRXHIP_FLAG_SLICE;                               /* vectorSlicer applied; fused demodulator */
-	c.threshold = BURST_THRESH;
-	c.full_scale = (float)rxFullScale;
-	if (!t.pipe || memcmp(&c, &t.pipe_cfg, sizeof(c)) != 0) {
+	/* pinned staging slots, one stream each: while chunk k's kernels run, chunk k+1 uploads and chunk k-1 downloads.
+	 * The pipe is per calling thread and keyed by geometry only (sps, burst length): its slot capacity follows the
+	 * largest batch seen (powers of two, 64 .. 2048 bursts: a thread that pulls 8 bursts at a time pins 0.6 MB, not
+	 * 26 MB) and its rows the widest ever asked for (444 once an egprs batch came by), both grow-only, so that
+	 * alternating batch sizes / egprs settings / full scales never re-allocates; levels are set per call. */
+	trxhip_hostpipe_cfg c = t.pipe ? t.pipe_cfg : trxhip_hostpipe_cfg();
+	uint32_t cap = 64;
+	while (cap < n && cap < 2048)
+		cap <<= 1;
+	if (!t.pipe || c.sps != sps || c.burst_len != (int32_t)burst_len || c.max_bursts < cap || c.soft_stride < (int32_t)stride) {
+		const uint32_t keep_cap = (t.pipe && c.sps == sps && c.burst_len == (int32_t)burst_len) ? c.max_bursts : 0;
+		const int32_t keep_stride = t.pipe ? c.soft_stride : 0;
+		memset(&c, 0, sizeof(c));
+		c.max_bursts = cap > keep_cap ? cap : keep_cap;
+		c.depth = 3;
+		c.burst_len = (int32_t)burst_len;
+		c.sps = sps;
+		c.soft_stride = (int32_t)stride > keep_stride ? (int32_t)stride : keep_stride;
+		c.flags = TRXHIP_FLAG_SLICE;                           /* vectorSlicer applied; fused demodulator */
+		c.threshold = BURST_THRESH;
+		c.full_scale = (float)rxFullScale;
 		if (t.pipe) trxhip_hostpipe_destroy(t.pipe);
 		t.pipe = nullptr;
 		if (trxhip_hostpipe_create(g_ctx, &c, &t.pipe) != TRXHIP_OK)
 			return -EIO;
 		t.pipe_cfg = c;
 	}
+	if (trxhip_hostpipe_set_levels(t.pipe, BURST_THRESH, (float)rxFullScale, 0.0f) != TRXHIP_OK)
+		return -EIO;
+	const size_t row = (size_t)c.soft_stride;                  /* the pipe's row width (>= stride) */
 	const size_t burst_bytes = burst_len * 2 * sizeof(int16_t);
 	const size_t n_chunks = (n + c.max_bursts - 1) / c.max_bursts;
 	int err = 0;
@@ -419,7 +431,7 @@ int pullRadioVectorBatch(const BurstRequest *req, size_t n, int sps, size_t burs
 			return;
 		}
 		for (size_t i = 0; i < m; i++)
-			trxsigproc_fill_indication(out[off + i], req[off + i], h.results[i], h.soft + i * stride, stride, rssi_offset);
+			trxsigproc_fill_indication(out[off + i], req[off + i], h.results[i], h.soft + i * row, stride, rssi_offset);
 	};
 	for (size_t k = 0; k < n_chunks; k++) {
 		if (k >= (size_t)c.depth)

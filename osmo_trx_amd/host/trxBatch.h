@@ -84,16 +84,23 @@ struct BurstGathererConfig {
 	double rxFullScale;       /* mRadioInterface->fullScaleOutputValue() */
 	double rssi_offset;
 	bool egprs;               /* 8-PSK slots possible: 444-bit rows */
-	int trxd_version;         /* -1: float soft bits in BurstIndication::rx_burst; 0 / 1: TRXD datagrams packed on the GPU */
+	int trxd_version;         /* -1: float soft bits in BurstIndication::rx_burst; 0 / 1: TRXD datagrams packed on the GPU
+	                           * (the initial header version of every channel, see setTrxdVersion()) */
 	int depth;                /* staging batches in flight (>= 2) */
 };
 class BurstGatherer {
 public:
 	explicit BurstGatherer(const BurstGathererConfig &cfg);
 	~BurstGatherer();
-	bool start();                                   /* needs sigProcLibSetup(); false without a GPU */
-	void stop();                                    /* wakes every blocked pull() with -EIO */
-	/* producer: false = dropped (channel FIFO full, radioInterface.cpp:277-280) */
+	bool start();                                   /* needs sigProcLibSetup(); false without a GPU.  After stop(): restarts with empty FIFOs */
+	/* Joins the worker threads: batches already submitted are delivered, bursts gathered but not yet submitted are
+	 * discarded; every blocked (and every later) pull() on an empty FIFO returns -EIO.  May race with push()/pull(). */
+	void stop();
+	/* TRXD header version of one channel (the reference negotiates it per channel: mVersionTRXD[chan],
+	 * Transceiver.cpp:1238-1250); applies to bursts pushed afterwards.  false in float mode (trxd_version < 0). */
+	bool setTrxdVersion(size_t chan, int version);
+	/* producer: false = dropped (channel FIFO full, radioInterface.cpp:277-280) or rejected (an EDGE slot on a gatherer
+	 * configured without egprs: the 444-bit rows do not exist) */
 	bool push(size_t chan, const BurstRequest &req);
 	/* producer, one timeslot of driveReceiveRadio() (radioInterface.cpp:272-281: one burst per channel): n bursts for
 	 * the channels chans[0..n), gathered with a single reservation.  accepted[k] (optional) = false where the channel's
@@ -106,6 +113,7 @@ public:
 	/* counters */
 	uint64_t batches() const;
 	uint64_t dropped() const;
+	uint64_t rejected() const;
 private:
 	struct Impl;
 	Impl *impl_;

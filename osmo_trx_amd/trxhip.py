@@ -67,6 +67,7 @@ SYMBOLS = {
     "trxhip_hostpipe_create": (_I, [_VP, _VP, C.POINTER(_VP)]),
     "trxhip_hostpipe_destroy": (None, [_VP]),
     "trxhip_hostpipe_slot_buffers": (_I, [_VP, _I, _VP]),
+    "trxhip_hostpipe_set_levels": (_I, [_VP, C.c_float, C.c_float, C.c_float]),
     "trxhip_hostpipe_submit": (_I, [_VP, _I, _SZ]),
     "trxhip_hostpipe_wait": (_I, [_VP, _I]),
     "trxhip_hostpipe_query": (_I, [_VP, _I]),

@@ -1,0 +1,149 @@
+// gatherer_stress.cpp -- BurstGatherer under ThreadSanitizer / AddressSanitizer, on the CPU stand-in of the hostpipe.
+// One producer thread and one consumer thread per channel on an oversubscribed machine; checks the class's contract
+// (radioInterface.cpp:272-291, Transceiver.cpp:1229-1253): every accepted burst is delivered exactly once, to its own
+// channel, in push order; dropped bursts (FIFO full) are never delivered.
+//   gatherer_stress <channels> <pushes_per_channel> <max_batch> <timeout_us> <trxd_version> [restart]
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "trxBatch.h"
+#ifdef TRXHIP_SA_NS
+using namespace trxhip_sa;
+#endif
+
+extern "C" int stub_live_pipes(void);
+static const uint32_t END_FN = 0xfffff0;       /* below 2^24: exact in the stub's float echo */
+
+static int run_once(BurstGatherer &g, size_t nch, uint32_t per_chan, int version, std::atomic<long> &errors)
+{
+	std::vector<std::atomic<uint32_t>> accepted(nch);
+	std::vector<std::thread> th;
+	std::atomic<size_t> producers_left{nch};
+	std::atomic<uint64_t> refused{0};                              /* pushes that returned false (regular bursts and end-marker retries) */
+	const uint64_t dropped0 = g.dropped();
+	for (size_t c = 0; c < nch; c++)
+		accepted[c].store(0);
+	for (size_t c = 0; c < nch; c++) {
+		th.emplace_back([&, c] {                                   /* producer of channel c */
+			std::vector<int16_t> iq(625 * 2, 0);
+			uint32_t acc = 0;
+			for (uint32_t fn = 1; fn <= per_chan; fn++) {
+				iq[0] = (int16_t)(fn & 0x7fff); iq[1] = (int16_t)(fn >> 15); iq[2] = (int16_t)c;
+				BurstRequest rq;
+				memset(&rq, 0, sizeof(rq));
+				rq.iq = iq.data(); rq.type = (fn % 97 == 0) ? OFF : TSC; rq.tsc = fn & 7; rq.max_toa = 3; rq.fn = fn; rq.tn = fn & 7;
+				/* seven bursts in eight wait for room (so that most are accepted and the ordering check has something to
+				 * look at); the eighth is dropped when the FIFO is full, as the reference's producer does */
+				bool ok = g.push(c, rq);
+				while (!ok && (fn & 7) != 0) { refused++; std::this_thread::yield(); ok = g.push(c, rq); }
+				if (ok) acc++; else refused++;
+				if ((fn & 1023) == 0) std::this_thread::yield();
+			}
+			/* end marker (retried until the FIFO takes it): tells the consumer that nothing follows */
+			iq[0] = (int16_t)(END_FN & 0x7fff); iq[1] = (int16_t)(END_FN >> 15);
+			BurstRequest rq;
+			memset(&rq, 0, sizeof(rq));
+			rq.iq = iq.data(); rq.type = TSC; rq.fn = END_FN;
+			while (!g.push(c, rq)) { refused++; std::this_thread::yield(); }
+			accepted[c].store(acc, std::memory_order_release);
+			producers_left--;
+		});
+		th.emplace_back([&, c] {                                   /* consumer of channel c */
+			BurstIndication bi;
+			uint8_t pkt[TRXD_MAX_PKT_LEN];
+			uint32_t last_fn = 0, got = 0;
+			for (;;) {
+				size_t plen = 0;
+				memset(&bi, 0, sizeof(bi));
+				const int rc = g.pull(c, &bi, version >= 0 ? pkt : NULL, &plen);
+				if (rc == -5) { errors++; fprintf(stderr, "chan %zu: pull -EIO\n", c); break; }
+				if (bi.fn == END_FN) break;
+				got++;
+				if (bi.fn <= last_fn) { errors++; fprintf(stderr, "chan %zu: fn %u after %u\n", c, bi.fn, last_fn); }
+				last_fn = bi.fn;
+				const bool off = (bi.fn % 97 == 0);
+				if ((rc == -2) != off) { errors++; fprintf(stderr, "chan %zu fn %u: rc %d\n", c, bi.fn, rc); }
+				if (!off) {
+					if ((uint32_t)bi.toa != bi.fn || (size_t)bi.energy != c) { errors++; fprintf(stderr, "chan %zu fn %u: echoed fn %u chan %g\n", c, bi.fn, (uint32_t)bi.toa, bi.energy); }
+					if (version >= 0) {
+						const uint32_t pfn = ((uint32_t)pkt[1] << 24) | ((uint32_t)pkt[2] << 16) | ((uint32_t)pkt[3] << 8) | pkt[4];
+						if (pfn != bi.fn || (pkt[0] >> 4) != (int)(c & 1)) { errors++; fprintf(stderr, "chan %zu fn %u: packet fn %u version %d\n", c, bi.fn, pfn, pkt[0] >> 4); }
+					} else if (bi.nbits != 148 || bi.rx_burst[0] != (float)(bi.fn & 1)) { errors++; fprintf(stderr, "chan %zu fn %u: soft row\n", c, bi.fn); }
+				}
+			}
+			while (producers_left.load() != 0) std::this_thread::yield();      /* accepted[] is final */
+			if (got != accepted[c].load()) { errors++; fprintf(stderr, "chan %zu: got %u of %u accepted\n", c, got, accepted[c].load()); }
+		});
+	}
+	for (auto &t : th) t.join();
+	uint64_t acc = 0;
+	for (size_t c = 0; c < nch; c++) acc += accepted[c].load();
+	printf("accepted %llu of %llu, dropped %llu, batches %llu\n", (unsigned long long)acc, (unsigned long long)nch * per_chan,
+	       (unsigned long long)g.dropped(), (unsigned long long)g.batches());
+	if (g.dropped() - dropped0 != refused.load() || acc + refused.load() < (uint64_t)nch * per_chan) { errors++; fprintf(stderr, "drop accounting: gatherer %llu, producers %llu\n", (unsigned long long)(g.dropped() - dropped0), (unsigned long long)refused.load()); }
+	return 0;
+}
+
+int main(int argc, char **argv)
+{
+	const size_t nch = argc > 1 ? atoi(argv[1]) : 16;
+	const uint32_t per_chan = argc > 2 ? atoi(argv[2]) : 65536;
+	BurstGathererConfig cfg;
+	memset(&cfg, 0, sizeof(cfg));
+	cfg.chans = nch; cfg.max_batch = argc > 3 ? atoi(argv[3]) : 64; cfg.timeout_us = argc > 4 ? atoi(argv[4]) : 50;
+	cfg.fifo_depth = 32; cfg.sps = 4; cfg.burst_len = 625; cfg.rxFullScale = 32767.0; cfg.rssi_offset = 0.0;
+	cfg.egprs = false; cfg.trxd_version = argc > 5 ? atoi(argv[5]) : -1; cfg.depth = 4;
+	const bool restart = argc > 6 && atoi(argv[6]);
+	std::atomic<long> errors{0};
+	{
+		BurstGatherer g(cfg);
+		if (cfg.trxd_version >= 0)
+			for (size_t c = 0; c < nch; c++)
+				if (!g.setTrxdVersion(c, (int)(c & 1))) errors++;      /* per-channel header version (mVersionTRXD[chan]) */
+		if (!g.start()) { fprintf(stderr, "start failed\n"); return 2; }
+		run_once(g, nch, per_chan, cfg.trxd_version, errors);
+		/* an EDGE slot on a gatherer without egprs rows is refused, not written past the 148-float payload */
+		{
+			std::vector<int16_t> iq(625 * 2, 0);
+			BurstRequest rq; memset(&rq, 0, sizeof(rq));
+			rq.iq = iq.data(); rq.type = EDGE; rq.fn = 1;
+			if (g.push(0, rq) || g.rejected() != 1) { errors++; fprintf(stderr, "EDGE push on !egprs accepted\n"); }
+		}
+		if (restart) {
+			/* stop with bursts gathered but not submitted, restart: one pipe alive, FIFOs empty, full run again */
+			std::vector<int16_t> iq(625 * 2, 0);
+			BurstRequest rq; memset(&rq, 0, sizeof(rq));
+			rq.iq = iq.data(); rq.type = TSC; rq.fn = 7;
+			for (int k = 0; k < 5; k++) g.push(0, rq);
+			g.stop();
+			BurstIndication bi;
+			int n_eio = 0, n_ok = 0;
+			for (int k = 0; k < 6; k++) { const int rc = g.pull(0, &bi); if (rc == -5) { n_eio++; break; } n_ok++; }
+			if (n_eio != 1) { errors++; fprintf(stderr, "pull after stop: %d delivered, no -EIO\n", n_ok); }
+			if (!g.start()) { errors++; fprintf(stderr, "restart failed\n"); }
+			if (stub_live_pipes() != 1) { errors++; fprintf(stderr, "%d hostpipes alive after restart\n", stub_live_pipes()); }
+			run_once(g, nch, per_chan / 4 + 1, cfg.trxd_version, errors);
+		}
+		g.stop();
+	}
+	if (stub_live_pipes() != 0) { errors++; fprintf(stderr, "%d hostpipes leaked\n", stub_live_pipes()); }
+	/* EDGE rows with egprs = false used to overflow the ring entry: egprs gatherer, float mode, 444-bit rows delivered */
+	{
+		cfg.egprs = true; cfg.trxd_version = -1; cfg.chans = 1;
+		BurstGatherer g(cfg);
+		if (!g.start()) return 2;
+		std::vector<int16_t> iq(625 * 2, 0);
+		iq[0] = 5;
+		BurstRequest rq; memset(&rq, 0, sizeof(rq));
+		rq.iq = iq.data(); rq.type = EDGE; rq.fn = 5;
+		BurstIndication bi;
+		if (!g.push(0, rq) || g.pull(0, &bi) != 0 || bi.nbits != 444 || bi.rx_burst[443] != (float)((5 + 443) & 1)) { errors++; fprintf(stderr, "EDGE row\n"); }
+		g.stop();
+	}
+	printf("errors %ld\n", errors.load());
+	return errors.load() ? 1 : 0;
+}
