@@ -50,6 +50,7 @@ extern "C" int trx_launch_vector_slicer(float *d_dst, const float *d_src, size_t
 
 #define TRXHIP_FLAG_DIAG_MASK 0x7fffff00   /* phase-ablation bits of the -DTRX_DIAG profiling build (tools/) */
 #define TRXHIP_IFLAG_NO_UNIT  0x40         /* internal: see trx_device.h */
+#define TRXHIP_IFLAG_NO_SYM   0x80
 
 extern "C" {
 
@@ -119,6 +120,10 @@ int trxhip_create_from_tables(trxhip_ctx **out, int device, const void *h_blob, 
 	ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 	ctx->d_tables = nullptr;
 	ctx->no_unit = trx_unit_masks_match(t) ? 0 : 1;
+	ctx->no_sym = 0;                                           /* the straight-line decimator reads taps 0..7 and mirrors them */
+	for (int k = 0; k < 8; k++)
+		if (memcmp(&t->dec_taps[k], &t->dec_taps[15 - k], sizeof(float)) != 0)
+			ctx->no_sym = 1;
 	if (hipMalloc(reinterpret_cast<void **>(&ctx->d_tables), sizeof(trx_tables)) != hipSuccess) {
 		delete ctx;
 		return TRXHIP_ENOMEM;
@@ -188,6 +193,8 @@ static int pull_common(trxhip_ctx *ctx, const void *d_iq, int cf32, const trxhip
 		return TRXHIP_EINVAL;
 	if (ctx->no_unit)
 		flags |= TRXHIP_IFLAG_NO_UNIT;
+	if (ctx->no_sym)
+		flags |= TRXHIP_IFLAG_NO_SYM;
 	return trx_launch_pull(d_iq, cf32, d_params, d_results, d_soft, ctx->d_tables, d_ebp_in, n_bursts, burst_len, sps,
 			       threshold, full_scale, soft_stride, flags, ctx->n_cu, static_cast<hipStream_t>(stream));
 }

@@ -10,6 +10,7 @@ struct trxhip_ctx {
 	int n_cu;
 	trx_tables *d_tables;
 	int no_unit;        /* tables do not have the compiled-in unit structure: keep the multiplying correlation */
+	int no_sym;         /* decimator taps not bitwise symmetric: the kernels' straight-line paths (mirrored taps) are off */
 };
 
 static inline int with_device(const trxhip_ctx *ctx)

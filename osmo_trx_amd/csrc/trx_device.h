@@ -285,6 +285,7 @@ __device__ __forceinline__ float norm2(c32 v) { return v.y * v.y + v.x * v.x; }
 // ------------------------------------------------------------------------------------------------
 #define TRX_UNIT_RATIO_LOG2 17
 #define TRX_IFLAG_NO_UNIT 0x40      // bit of the kernels' `slice` argument set by the C ABI when the tables lack the unit structure
+#define TRX_IFLAG_NO_SYM  0x80      // ... when the /4 decimator's taps are not bitwise symmetric (g[k] == g[15-k]): no straight-line paths
 // bit k set: the +-1 component of tap k is -1 (from the generated tables; tests/test_capi_cpu.py pins them)
 #define TRX_UNIT_NEG_TSC0   0x447bull
 #define TRX_UNIT_NEG_TSC1   0xc5bbull
@@ -569,12 +570,16 @@ __device__ __forceinline__ int detect_tail(const c32 *sig, int sig_len, c32 *cz,
 		// does -- but two IEEE divisions, two correctly rounded square roots and an fp64 add cost ~45 VALU ops.
 		// A 1-ulp-per-op estimate (total error < 1e-6) decides every burst whose ratio is not within 4e-6 of
 		// the threshold; only those (about one in 1e5) take the exactly rounded path.
+		// Compared as squares: |amp|^2 against (thresh * rms)^2 -- one transcendental (the sqrt of the mean) instead of four;
+		// 1 / num is a scalar select (num is 7 or 8 after the edge gate), the margins are the squares of the linear ones.
 		const float amp2 = norm2(amp0);
-		const float rms_e = __builtin_amdgcn_sqrtf(avg * __builtin_amdgcn_rcpf((float)num)) + 0.00001f;
-		const float ratio_e = __builtin_amdgcn_sqrtf(amp2) * __builtin_amdgcn_rcpf(rms_e);
-		if (ratio_e < thresh * (1.0f - 4e-6f))
+		const float rnum = (num == 8) ? 0.125f : (num == 7) ? (1.0f / 7.0f) : (num == 6) ? (1.0f / 6.0f) : 0.2f;
+		const float rms_e = __builtin_amdgcn_sqrtf(avg * rnum) + 0.00001f;
+		const float t_e = thresh * rms_e;
+		const float t2 = t_e * t_e;
+		if (amp2 < t2 * (1.0f - 8e-6f))
 			return 0;
-		if (!(ratio_e > thresh * (1.0f + 4e-6f))) {
+		if (!(amp2 > t2 * (1.0f + 8e-6f))) {
 			const float rms = (float)((double)sqrtf(avg / (float)num) + 0.00001);
 			const float ratio = sqrtf(amp2) / rms;
 			if (ratio < thresh)

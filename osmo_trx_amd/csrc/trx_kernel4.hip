@@ -88,13 +88,49 @@ __device__ __forceinline__ PhBase ph_bases(const c32 *P, int ph0, int m0)
 // the end of the launch (work claiming, below) another 13 % in round 2.
 #define K4_WPB(CF_, EX_) ((CF_) ? 12 : 16)
 
-template <bool CF32, bool EXACT>
+// One output of the /4 decimator (downsampleBurst, :1587-1601) on the polyphase layout: y = sum_k x[4i-15+k] * g[k], product
+// then sum, k ascending (the reference's order).  All 16 samples are fetched before the first multiply -- the compiler's own
+// schedule interleaves reads and waits with 2-5 reads in flight and exposes the LDS latency six times -- and the taps come as
+// g[0..7] only (two 16-byte broadcast reads): the filter is bitwise symmetric, g[k] == g[15-k] (checked when the context
+// is created; TRX_IFLAG_NO_SYM otherwise keeps callers on the generic path).
+__device__ __forceinline__ c32 decimate16_sym(const c32 *pd, const float *gdec)
+{
+	const float4 *g4 = reinterpret_cast<const float4 *>(gdec);
+	c32 xs[16];
+#pragma unroll
+	for (int k = 0; k < 16; k++)
+		xs[k] = lds_c32(pd + ((k + 1) & 3) * PH_A + ((k + 1) >> 2));
+	const float4 gA = g4[0], gB = g4[1];
+	__builtin_amdgcn_sched_barrier(0);
+	v2f ya = { 0.0f, 0.0f };
+#pragma unroll
+	for (int k = 0; k < 16; k++) {
+		const int kk = k < 8 ? k : 15 - k;
+		const float4 gq = (kk >> 2) ? gB : gA;
+		const v2f gp = (kk & 2) ? (v2f){ gq.z, gq.w } : (v2f){ gq.x, gq.y };
+		const v2f xv = { xs[k].x, xs[k].y };
+		ya = ya + ((kk & 1) ? pk_mul_tap<1>(xv, gp) : pk_mul_tap<0>(xv, gp));
+	}
+	return make_float2(ya.x, ya.y);
+}
+
+// COMMON = the call pullRadioVector() makes (Transceiver.cpp:665-815) and bench.py times: 625-sample int16 bursts, detection
+// + demodulation, vectorSlicer applied, rows of 148 soft bits, no diagnostic flags.  Those launch parameters are then
+// compile-time constants (the launcher checks them) and the scalar tests, selects and generic store loops they feed
+// disappear from the burst loop; every other call takes the general instantiation of the same source.
+template <bool CF32, bool EXACT, bool COMMON>
 __global__ void __launch_bounds__(K4_WPB(CF32, EXACT) * WAVE)
 burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__restrict__ params,
-		   trxhip_burst_result *__restrict__ results, float *__restrict__ soft,
-		   const trx_tables *__restrict__ tab, const float4 *__restrict__ ebp_in,
-		   unsigned n_bursts, int L, float thresh, float full_scale, int soft_stride, int slice)
+		   trxhip_burst_result *__restrict__ results, float *__restrict__ soft_arg,
+		   const trx_tables *__restrict__ tab, const float4 *__restrict__ ebp_arg,
+		   unsigned n_bursts, int L_arg, float thresh, float full_scale, int soft_stride_arg, int slice_arg)
 {
+	static_assert(!(COMMON && CF32), "the common instantiation reads int16 bursts");
+	const int L = COMMON ? 625 : L_arg;
+	const int soft_stride = COMMON ? 148 : soft_stride_arg;
+	const int slice = COMMON ? TRXHIP_FLAG_SLICE : slice_arg;
+	const float4 *const ebp_in = COMMON ? nullptr : ebp_arg;
+	float *const soft = soft_arg;
 	constexpr int NLD = 10;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const int lane = threadIdx.x & (WAVE - 1);
@@ -220,18 +256,23 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 			return;
 		if (pend_mode == 1) {
 			// symbols lane, lane + 64, lane + 128: the first two always exist and are always stored (rows of 128
-			// floats or more: 148 / 156 / 444 in practice), only the third needs its range checks; one pointer per lane
+			// floats or more: 148 / 156 / 444 in practice), only the third needs its range checks; one pointer per lane.
+			// real(rot[i] * x[i]) (:2066-2068) with rot[i] = (-j)^i up to the table's 1e-16 phase residue: +re, +im, -re, -im
+			// for i & 3 = 0..3, and i & 3 = lane & 3 in all three rounds -- so the lane reads the one component it needs
+			// (a 4-byte LDS read) and the sign rides on the slicer's multiplier (fused demodulator only: tolerance 1e-5)
 			float *const sp = pend_so + lane;
-			const c32 *const dp = dec + lane, *const rp = rrot + lane;
+			const float *const dp = reinterpret_cast<const float *>(dec + lane) + (lane & 1);
+			const float hs = (lane & 2) ? -0.5f : 0.5f;
 #pragma unroll
 			for (int r = 0; r < 3; r++) {
 				const int i = lane + r * WAVE;
-				const int off = (r < 2 || lane < 32) ? r * WAVE : 159 - lane;    // symbol 128 + lane, capped at entry 159
-				const c32 d = dp[off];
-				const c32 rr = rp[off];
-				float sv = fmaf(-rr.y, d.y, rr.x * d.x);                // real(rot * x)  (:2066-2068); fused demodulator: one rounding less
-				if (slice & 1)                                          // vectorSlicer: 0.5 * (x + 1) = fma(0.5, x, 0.5) bit for bit (scaling by 2 is exact)
-					sv = __builtin_amdgcn_fmed3f(fmaf(0.5f, sv, 0.5f), 0.0f, 1.0f);
+				const int off = (r < 2 || lane < 32) ? r * WAVE : 0;             // symbol 128 + lane (lanes >= 32: discarded below)
+				const float d = dp[2 * off];
+				float sv;
+				if (slice & 1)                                          // vectorSlicer: 0.5 * (x + 1) = fma(0.5, x, 0.5) (scaling by 2 is exact)
+					sv = __builtin_amdgcn_fmed3f(fmaf(hs, d, 0.5f), 0.0f, 1.0f);
+				else
+					sv = (hs + hs) * d;
 				if (r < 2) {
 					sp[r * WAVE] = sv;
 				} else {
@@ -281,7 +322,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 		float toa = 0.0f, ci = 0.0f, energy = 0.0f, rssi = 0.0f;
 		c32 amp = make_float2(0.0f, 0.0f);
 		int out_tsc = 0, clip = 0, idle = 1, nbits = 0;
-		float *so = soft ? soft + (size_t)b * soft_stride : nullptr;
+		float *so = (COMMON || soft) ? soft + (size_t)b * soft_stride : nullptr;
 
 		// ---- phase 0: registers -> fp32 polyphase LDS; clip scan and energyDetect partial sums on the fly
 		float amax = 0.0f, epart = 0.0f;
@@ -293,7 +334,9 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 				if (CF32) v = pre_c[r];
 				else v = make_float2((float)(int16_t)(pre_i[r] & 0xffffu), (float)(int16_t)(pre_i[r] >> 16));
 				pload[16 * r] = v;
-				amax = fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y)));
+				// maxAmplitude(): one v_max3_f32 with |.| source modifiers per sample (the compiler's tree of v_max / v_max3
+				// is 1.5 instructions per sample)
+				asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(v.x), "v"(v.y));
 				if (r < 5)                                          // samples 4i, i < 80 (:1576-1584); masked to lane % 4 == 0 below
 					epart = fmaf(v.x, v.x, fmaf(v.y, v.y, epart));      // (tree-summed anyway: tolerance 3e-6, not an ordered sum)
 			}
@@ -350,7 +393,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 					unit_bad |= (__ballot(bad) != 0ull) ? 1 : 0;
 					wave_sync();
 				};
-				if (type == TRXHIP_TSC && tsc < 8 && max_toa <= 33) {
+				if (type == TRXHIP_TSC && tsc < 8 && max_toa <= 33 && !(slice & TRX_IFLAG_NO_SYM)) {
 					// The common slot, straight-line: a normal burst is ONE detectGeneralBurst() window (analyzeTrafficBurst,
 					// :1887-1904: target 82, head 10, tail 6 + max_toa -> start 71, len 16 + max_toa <= 49), whose 31 + max_toa
 					// <= 64 decimated samples dec[56 ..] are one round with lane = sample.  Same functions as the general
@@ -359,18 +402,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 					const int len = 16 + max_toa;
 					__builtin_assume(len >= 16 && len <= 49);
 					{
-						const c32 *pd = P + PH_M0 + (56 + lane) - 4;
-						const float4 *g4 = reinterpret_cast<const float4 *>(gdec);
-						v2f ya = { 0.0f, 0.0f };
-#pragma unroll
-						for (int k = 0; k < 16; k++) {
-							const c32 x = lds_c32(pd + ((k + 1) & 3) * PH_A + ((k + 1) >> 2));
-							const float4 gq = g4[k >> 2];
-							const v2f gp = (k & 2) ? (v2f){ gq.z, gq.w } : (v2f){ gq.x, gq.y };
-							const v2f xv = { x.x, x.y };
-							ya = ya + ((k & 1) ? pk_mul_tap<1>(xv, gp) : pk_mul_tap<0>(xv, gp));   // y += x * g[k]: product, then sum
-						}
-						const c32 y = make_float2(ya.x, ya.y);
+						const c32 y = decimate16_sym(P + PH_M0 + (56 + lane) - 4, gdec);
 						dec[56 + lane] = y;
 						unit_bad |= (__ballot(unit_unsafe(y) && lane < 15 + len) != 0ull) ? 1 : 0;
 						wave_sync();
@@ -382,7 +414,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 					rc = hit ? TRXHIP_TSC : (clip ? -TRXHIP_SIGERR_CLIP : 0);                 // :1764, :1953-1954
 					toa -= 10.0f;                                                              // :1768
 					out_tsc = tsc;
-				} else if ((type == TRXHIP_RACH || type == TRXHIP_EXT_RACH) && max_toa <= 64) {
+				} else if ((type == TRXHIP_RACH || type == TRXHIP_EXT_RACH) && max_toa <= 64 && !(slice & TRX_IFLAG_NO_SYM)) {
 					// Access bursts, straight-line as well: detectRACHBurst (:1782-1803) with TS0 only is one window -- target 48,
 					// head 8, tail 8 + max_toa -> start 39, len 16 + max_toa <= 80, 40 taps -- over dec[0 .. 39 + len): two
 					// decimation rounds (lane, lane + 64), two correlation rounds inside detect_burst().
@@ -392,16 +424,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 #pragma unroll
 					for (int r = 0; r < 2; r++) {
 						const int i = lane + r * WAVE;                          // < 128 <= TRX_DEC_NARROW
-						const c32 *pd = P + PH_M0 + i - 4;
-						float yr = 0.0f, yi = 0.0f;
-#pragma unroll
-						for (int k = 0; k < 16; k++) {
-							const c32 x = lds_c32(pd + ((k + 1) & 3) * PH_A + ((k + 1) >> 2));
-							const float g = gdec[k];
-							yr += x.x * g;
-							yi += x.y * g;
-						}
-						const c32 y = make_float2(yr, yi);
+						const c32 y = decimate16_sym(P + PH_M0 + i - 4, gdec);
 						dec[i] = y;
 						bad |= unit_unsafe(y) && i < 39 + len;
 					}
@@ -432,6 +455,31 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 			}
 		}
 
+#if defined(TRX_SENS_VALU) || defined(TRX_SENS_PLAIN) || defined(TRX_SENS_LDS) || defined(TRX_SENS_SALU)
+		// measurement builds only (tools/build_variants.py): N extra instructions of one kind per burst, results unused --
+		// the slope of throughput against N is what one instruction of that kind costs (or its removal buys)
+		{
+			v2f sx = { toa, ci }, sy = sx;
+			float sp = toa, sq = ci;
+			int ss = (int)b;
+#ifdef TRX_SENS_VALU
+			asm volatile(".rept %c4\n v_pk_add_f32 %0, %0, %2\n v_pk_add_f32 %1, %1, %2\n .endr" : "+v"(sx), "+v"(sy) : "v"(sx), "v"(sy), "n"(TRX_SENS_VALU / 2));
+#endif
+#ifdef TRX_SENS_PLAIN
+			asm volatile(".rept %c2\n v_add_f32 %0, %0, %0\n v_add_f32 %1, %1, %1\n .endr" : "+v"(sp), "+v"(sq) : "n"(TRX_SENS_PLAIN / 2));
+#endif
+#ifdef TRX_SENS_LDS
+			{
+				const unsigned la = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)sincv + lane * 8;
+				asm volatile(".rept %c3\n ds_read_b64 %0, %2\n ds_read_b64 %1, %2 offset:512\n .endr\n s_waitcnt lgkmcnt(0)" : "=&v"(sx), "=&v"(sy) : "v"(la), "n"(TRX_SENS_LDS / 2) : "memory");
+			}
+#endif
+#ifdef TRX_SENS_SALU
+			asm volatile(".rept %c1\n s_add_u32 %0, %0, 3\n .endr" : "+s"(ss) : "n"(TRX_SENS_SALU) : "scc");
+#endif
+			if (sx.x + sy.y + sp + sq == 1.2345e-30f || ss == 0x7fffffff) energy += 1.0f;      // keep the results alive
+		}
+#endif
 		// ---- demodAnyBurst -> demodGmskBurst (:2055-2072) ----
 		if (rc > 0 && !ABL(0)) {
 			// demodCommon (:2030-2048): delayVector(burst, -toa*sps) -> scaleVector(1/amp) -> downsampleBurst
@@ -804,9 +852,12 @@ extern "C" int trx_launch_pull4(const void *d_iq, int cf32, const trxhip_burst_p
 	if (const char *e = getenv("TRXHIP_GRID")) { const int v = atoi(e); if (v >= 1) grid = (size_t)v; }
 #endif
 	if (grid > need) grid = need;
-#define LAUNCH4(CF_, EX_)                                                                                       \
+	/* the instantiation with the common launch parameters folded (see the kernel) */
+	const bool common = !cf32 && L == 625 && d_soft && !d_ebp_in && soft_stride == 148 &&
+			    (flags & ~TRXHIP_FLAG_EXACT_DEMOD) == TRXHIP_FLAG_SLICE;
+#define LAUNCH4(CF_, EX_, CM_)                                                                                  \
 	do {                                                                                                    \
-		auto k = burst_pull4_kernel<CF_, EX_>;                                                          \
+		auto k = burst_pull4_kernel<CF_, EX_, CM_>;                                                     \
 		/* the > 64 KB dynamic-LDS opt-in is per kernel and device: once, not per launch (small batches) */ \
 		static std::atomic<unsigned long long> armed{0ull};                                             \
 		int dev = 0;                                                                                    \
@@ -822,8 +873,9 @@ extern "C" int trx_launch_pull4(const void *d_iq, int cf32, const trxhip_burst_p
 				   d_soft, d_tab, reinterpret_cast<const float4 *>(d_ebp_in), (unsigned)n_bursts, L, thresh, \
 				   full_scale, soft_stride, flags);                                             \
 	} while (0)
-	if (cf32) { if (exact) LAUNCH4(true, true); else LAUNCH4(true, false); }
-	else      { if (exact) LAUNCH4(false, true); else LAUNCH4(false, false); }
+	if (cf32)        { if (exact) LAUNCH4(true, true, false); else LAUNCH4(true, false, false); }
+	else if (common) { if (exact) LAUNCH4(false, true, true); else LAUNCH4(false, false, true); }
+	else             { if (exact) LAUNCH4(false, true, false); else LAUNCH4(false, false, false); }
 #undef LAUNCH4
 	return hipGetLastError() == hipSuccess ? 0 : TRXHIP_EIO;
 }
