@@ -541,9 +541,13 @@ __device__ __forceinline__ void peak_detect_spec(const c32 *cz, int max_idx, con
 //   sig    : what was correlated (computeCI reads N samples of it), sig_len its length
 //   hdr    : {gain.re, gain.im, ginv.re, ginv.im, ci_den, toa, n, 1/ci_den}
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int detect_tail(const c32 *sig, int sig_len, c32 *cz, const float *hdr, int N, float thresh,
-					    int start, int len, int bidx, const float *sincv, const PeakConst &pc, int lane,
-					    float *toa_out, c32 *amp_out, float *ci_out, int slice DIAG_ARG)
+//   on_toa : called with the refined position (1/512 symbol units, before "- sync->toa" and "- head") as soon as peakDetect
+//            has it -- the 4-SPS kernel starts fetching what its demodulator needs for that TOA behind computeCI
+struct NoToaHook { __device__ __forceinline__ void operator()(int) const {} };
+template <typename Hook>
+__device__ __forceinline__ int detect_tail_h(const c32 *sig, int sig_len, c32 *cz, const float *hdr, int N, float thresh,
+					      int start, int len, int bidx, const float *sincv, const PeakConst &pc, int lane,
+					      float *toa_out, c32 *amp_out, float *ci_out, Hook on_toa, int slice DIAG_ARG)
 {
 	if ((bidx < 3) || (bidx > len - 3))               // :1683
 		return 0;
@@ -565,7 +569,10 @@ __device__ __forceinline__ int detect_tail(const c32 *sig, int sig_len, c32 *cz,
 		const float avg = lane_val(acc, 7);
 		// number of in-range terms (:1555-1562).  The edge gate above left 3 <= bidx <= len - 3, so the four terms at
 		// distance 2 and 3 always exist except peak + 3 == len: 7 or 8 >= 5 ("num < 5: return 0" can never fire here)
-		const int num = 3 + (bidx + 3 < len) + (bidx >= 4) + (bidx + 4 < len) + (bidx >= 5) + (bidx + 5 < len);
+		// = 3 + (bidx + 3 < len) + (bidx >= 4) + (bidx + 4 < len) + (bidx >= 5) + (bidx + 5 < len), as scalar min / add:
+		// terms at distance 2..5 exist on the left while bidx - d >= 0, on the right while bidx + d < len
+		const int nl = bidx - 1, nr = len - 2 - bidx;
+		const int num = (nl < 4 ? nl : 4) + (nr < 4 ? nr : 4);
 		// The gate "|amp| / (sqrtf(avg/num) + 1e-5) < thresh" is a decision, so it must round as the reference
 		// does -- but two IEEE divisions, two correctly rounded square roots and an fp64 add cost ~45 VALU ops.
 		// A 1-ulp-per-op estimate (total error < 1e-6) decides every burst whose ratio is not within 4e-6 of
@@ -602,6 +609,7 @@ __device__ __forceinline__ int detect_tail(const c32 *sig, int sig_len, c32 *cz,
 	xcorr.x = unif(xcorr.x);
 	xcorr.y = unif(xcorr.y);
 	const float toa = (float)toa512 * (1.0f / 512.0f);   // exact
+	on_toa(toa512);
 
 	DIAG_MARK(6);
 	// ---- computeCI (:1608-1639)
@@ -647,6 +655,14 @@ __device__ __forceinline__ int detect_tail(const c32 *sig, int sig_len, c32 *cz,
 	return 1;
 }
 
+__device__ __forceinline__ int detect_tail(const c32 *sig, int sig_len, c32 *cz, const float *hdr, int N, float thresh,
+					    int start, int len, int bidx, const float *sincv, const PeakConst &pc, int lane,
+					    float *toa_out, c32 *amp_out, float *ci_out, int slice DIAG_ARG)
+{
+	return detect_tail_h(sig, sig_len, cz, hdr, N, thresh, start, len, bidx, sincv, pc, lane, toa_out, amp_out, ci_out,
+			     NoToaHook(), slice DIAG_PASS);
+}
+
 // ------------------------------------------------------------------------------------------------
 // detectBurst() on the 1-SPS signal `sig` (sigProcLib.cpp:1649-1709); correlation kept in LDS (cz).
 //   PADDED: sig is readable (zero) over the whole correlation window, no range checks (4 SPS: dec[])
@@ -658,10 +674,10 @@ __device__ __forceinline__ int detect_tail(const c32 *sig, int sig_len, c32 *cz,
 //           recomputed for the tail, exactly as the SCH buffer search does (trx_sch.hip)
 //   unit_slot >= 0: the sequence is the GMSK one of that LDS slot and every sample the window reads passed
 //           unit_unsafe(): correlate with corr_unit() (additions only, same bits); < 0: multiply as written
-template <bool PADDED, bool NARROW>
-__device__ __forceinline__ int detect_burst(const c32 *sig, int sig_len, c32 *cz, const c32 *taps, const float *hdr,
-					     int N, float thresh, int start, int len, const float *sincv, const PeakConst &pc, int lane,
-					     float *toa_out, c32 *amp_out, float *ci_out, int slice, int unit_slot DIAG_ARG)
+template <bool PADDED, bool NARROW, typename Hook>
+__device__ __forceinline__ int detect_burst_h(const c32 *sig, int sig_len, c32 *cz, const c32 *taps, const float *hdr,
+					       int N, float thresh, int start, int len, const float *sincv, const PeakConst &pc, int lane,
+					       float *toa_out, c32 *amp_out, float *ci_out, Hook on_toa, int slice, int unit_slot DIAG_ARG)
 {
 	const bool wide = NARROW && (len > TRX_CORR_NARROW || start + len > TRX_DEC_NARROW);
 	// corr[i] with range-checked reads, taps in order (cold: wide windows only)
@@ -753,14 +769,23 @@ __device__ __forceinline__ int detect_burst(const c32 *sig, int sig_len, c32 *cz
 		}
 		czp = win - (bidx - TRX_CZ_PAD);
 	}
-	const int r = detect_tail(sig, sig_len, czp, hdr, N, thresh, start, len, bidx, sincv, pc, lane, toa_out, amp_out, ci_out,
-				  slice DIAG_PASS);
+	const int r = detect_tail_h(sig, sig_len, czp, hdr, N, thresh, start, len, bidx, sincv, pc, lane, toa_out, amp_out, ci_out,
+				    on_toa, slice DIAG_PASS);
 	if (wide) {
 		wave_sync();
 		if (lane < TRX_CZ_PAD)
 			cz[lane - TRX_CZ_PAD] = make_float2(0.0f, 0.0f);     // the window covered cz's left zero pad: restore it
 	}
 	return r;
+}
+
+template <bool PADDED, bool NARROW>
+__device__ __forceinline__ int detect_burst(const c32 *sig, int sig_len, c32 *cz, const c32 *taps, const float *hdr,
+					     int N, float thresh, int start, int len, const float *sincv, const PeakConst &pc, int lane,
+					     float *toa_out, c32 *amp_out, float *ci_out, int slice, int unit_slot DIAG_ARG)
+{
+	return detect_burst_h<PADDED, NARROW>(sig, sig_len, cz, taps, hdr, N, thresh, start, len, sincv, pc, lane, toa_out, amp_out,
+					      ci_out, NoToaHook(), slice, unit_slot DIAG_PASS);
 }
 
 

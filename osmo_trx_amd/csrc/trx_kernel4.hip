@@ -88,6 +88,38 @@ __device__ __forceinline__ PhBase ph_bases(const c32 *P, int ph0, int m0)
 // the end of the launch (work claiming, below) another 13 % in round 2.
 #define K4_WPB(CF_, EX_) ((CF_) ? 12 : 16)
 
+// The fused demodulator's main filter: three ADJACENT outputs per lane over the composite taps u = 8 .. 31 (24 of 35: see the
+// kernel).  pb addresses the lane's first sample (tap u = 8 of its first output), c4 its tap row from u = 8 on -- a per-lane
+// LDS address, wave-uniform for the ordinary lanes.  Taps outer, a ring of 16 samples loaded D ahead of use; one
+// sched_barrier per tap keeps the order and the register footprint.
+#define K4_U0 8
+#define K4_NT 24
+__device__ __forceinline__ void fir24x3(const PhBase &pb, const float4 *c4, v2f (&acc)[3])
+{
+	constexpr int D = 4, NV = K4_NT + 8;                            // samples v = 0 .. 31
+	c32 xw[16];
+	float4 cq[2];
+	cq[0] = c4[0];
+#pragma unroll
+	for (int v = 0; v < 8 + D; v++)
+		xw[v] = lds_c32(pb.p[v & 3] + (v >> 2));
+#pragma unroll
+	for (int u = 0; u < K4_NT; u++) {
+		if ((u & 3) == 0 && u + 4 < K4_NT)
+			cq[((u >> 2) + 1) & 1] = c4[(u >> 2) + 1];
+		if (u + 8 + D < NV)
+			xw[(u + 8 + D) & 15] = lds_c32(pb.p[(u + 8 + D) & 3] + ((u + 8 + D) >> 2));
+		const float4 ca = cq[(u >> 2) & 1];
+		const v2f hp = (u & 2) ? (v2f){ ca.z, ca.w } : (v2f){ ca.x, ca.y };
+#pragma unroll
+		for (int j = 0; j < 3; j++) {
+			const v2f xv = { xw[(u + 4 * j) & 15].x, xw[(u + 4 * j) & 15].y };
+			acc[j] = (u & 1) ? pk_fma_tap<1>(xv, hp, acc[j]) : pk_fma_tap<0>(xv, hp, acc[j]);
+		}
+		__builtin_amdgcn_sched_barrier(0);
+	}
+}
+
 // One output of the /4 decimator (downsampleBurst, :1587-1601) on the polyphase layout: y = sum_k x[4i-15+k] * g[k], product
 // then sum, k ascending (the reference's order).  All 16 samples are fetched before the first multiply -- the compiler's own
 // schedule interleaves reads and waits with 2-5 reads in flight and exposes the LDS latency six times -- and the taps come as
@@ -317,12 +349,35 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 		const int type = prm0 & 0xff;
 		const int tsc = (prm0 >> 8) & 0xff;
 		const int max_toa = prm0 >> 16;
+#ifdef TRX_HOT_ONLY   /* reading aid (tools/): the instruction stream of a normal burst alone; not a product build */
+		__builtin_assume(type == TRXHIP_TSC);
+		__builtin_assume(tsc < 8);
+		__builtin_assume(max_toa == 3);
+#endif
 
 		int rc = 0;
 		float toa = 0.0f, ci = 0.0f, energy = 0.0f, rssi = 0.0f;
 		c32 amp = make_float2(0.0f, 0.0f);
 		int out_tsc = 0, clip = 0, idle = 1, nbits = 0;
 		float *so = (COMMON || soft) ? soft + (size_t)b * soft_stride : nullptr;
+		// Fused demodulator, usual geometry (COMMON launches; 0 <= TOA <= 9 symbols, GMSK): the four low-edge outputs are
+		// computed INSIDE the main filter loop by eight otherwise idle lanes, each with its own tap row (trx_tables.edge8).
+		// The rows (768 bytes for the burst's delay filter) are fetched from L2 as soon as detection knows the TOA -- behind
+		// computeCI -- and parked in dec[0..95] once computeCI has read its samples.
+		float4 fast_rows = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		int fast_nk = 1 << 30;                                       // -TOA in 1/512 symbol when the fast path applies
+		auto fast_fetch = [&](int k512) {
+			if (!COMMON || EXACT)
+				return;
+			const int nk = -k512;
+			if ((unsigned)(-(nk >> 7)) > 36u)                        // w = nk >> 7 in [-36, 0]
+				return;
+			fast_nk = nk;
+			const int fr = nk & 127;
+			const int fidx = (fr >= 2) ? (fr >> 1) : TRX_DELAY_FILTS;
+			if (lane < 48)
+				fast_rows = reinterpret_cast<const float4 *>(&tab->edge8[fidx][0][0])[lane];
+		};
 
 		// ---- phase 0: registers -> fp32 polyphase LDS; clip scan and energyDetect partial sums on the fly
 		float amax = 0.0f, epart = 0.0f;
@@ -408,8 +463,12 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 						wave_sync();
 					}
 					DIAG_MARK(2);
-					const int hit = detect_burst<true, true>(dec, 156, cz, lseq + LSEQ_TSC(tsc), lhdr + 8 * tsc, 16, thresh, 71, len, sincv,
-										 pkc, lane, &toa, &amp, &ci, slice, unit_bad ? -1 : tsc DIAG_PASS);
+					// as soon as the refined position is known: the burst's TOA in 1/512 symbol (position - sync->toa - head,
+					// all multiples of 1/512) and, in the usual geometry, the fetch of its low-edge tap rows (fast_fetch)
+					const float *const hdr = lhdr + 8 * tsc;
+					auto on_toa = [&](int toa512) { fast_fetch(toa512 - (int)(hdr[5] * 512.0f) - 10 * 512); };
+					const int hit = detect_burst_h<true, true>(dec, 156, cz, lseq + LSEQ_TSC(tsc), hdr, 16, thresh, 71, len, sincv,
+										   pkc, lane, &toa, &amp, &ci, on_toa, slice, unit_bad ? -1 : tsc DIAG_PASS);
 					wave_sync();
 					rc = hit ? TRXHIP_TSC : (clip ? -TRXHIP_SIGERR_CLIP : 0);                 // :1764, :1953-1954
 					toa -= 10.0f;                                                              // :1768
@@ -481,7 +540,54 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 		}
 #endif
 		// ---- demodAnyBurst -> demodGmskBurst (:2055-2072) ----
-		if (rc > 0 && !ABL(0)) {
+		bool fast_done = false;
+		if (COMMON && !EXACT && rc == TRXHIP_TSC && fast_nk != (1 << 30) && !ABL(0)) {
+			// ================= FUSED, usual geometry, straight-line =================
+			// (the general form below, with n_lo = 0, four low-edge outputs, no high-edge output among the 148 stored, every
+			// window inside the padded arrays: nothing left to decide per burst but the delay filter and the shift)
+			const int nk = fast_nk;
+			const int w = nk >> 7;                                      // integer shift, -36 .. 0
+			const int fr = nk & 127;
+			const int fidx = (fr >= 2) ? (fr >> 1) : TRX_DELAY_FILTS;   // delay filter row (64 = none)
+			const float ian = __builtin_amdgcn_rcpf(norm2(amp));
+			const c32 scale = make_float2(amp.x * ian, -amp.y * ian);   // 1 / amp (Complex.h:75,144-150), 1-ulp reciprocal
+			nbits = 148;
+			idle = 0;
+			// park the low-edge rows: lane l < 48 holds floats 4l .. 4l+3 of the 8 x 24 block
+			float *const stage = reinterpret_cast<float *>(dec);
+			if (lane < 48)
+				*reinterpret_cast<float4 *>(stage + 4 * lane) = fast_rows;
+			wave_sync();
+			// lanes 0..49: outputs 3l .. 3l+2 with the burst's composite row; lanes 52..55: output l - 52, main part of its
+			// truncated row; lanes 56..59: the same outputs' taps u < 8 (window 8 samples = 2 outputs earlier); the rest idle
+			const bool sp = (lane >= 52) && (lane < 60);
+			const float *const tp = sp ? stage + (lane - 52) * 24 : comp + fidx * 36 + K4_U0;
+			int ic = (lane < 50) ? 3 * lane : 150;
+			if (sp) ic = (lane < 56) ? lane - 52 : lane - 58;
+			const int c = -16 - w;                                      // tap u = 8 of output i reads sample 4i + c
+			const PhBase pb = ph_bases(P, c & 3, ic + (c >> 2));
+			v2f acc[3] = { { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f } };
+			fir24x3(pb, reinterpret_cast<const float4 *>(tp), acc);
+			// low-edge outputs: main part (lane 52 + i) + taps u < 8 (lane 56 + i), row_shl:4 inside the last row of 16
+			float er = acc[0].x, ei = acc[0].y;
+			asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0xf\n\t"
+				     "v_add_f32_dpp %1, %1, %1 row_shl:4 row_mask:0xf bank_mask:0xf" : "+v"(er), "+v"(ei));
+			wave_sync();                                                // (every lane has read its taps from dec[0..95])
+			if (lane < 50) {
+#pragma unroll
+				for (int j = 0; j < 3; j++)
+					dec[3 * lane + j] = cmul(make_float2(acc[j].x, acc[j].y), scale);
+			}
+			if (lane >= 52 && lane < 56)
+				dec[lane - 52] = cmul(make_float2(er, ei), scale);      // after lanes 0, 1 wrote their (partial) versions
+			wave_sync();
+			pend_mode = 1;
+			pend_so = so;
+			pend_nwrite = 148;
+			fast_done = true;
+		}
+		if (fast_done) {
+		} else if (rc > 0 && !ABL(0)) {
 			// demodCommon (:2030-2048): delayVector(burst, -toa*sps) -> scaleVector(1/amp) -> downsampleBurst
 			// delay = -toa * 4 samples: whole = floor(delay), frac = delay - whole, filter floorf(frac * 64) if frac > 0.01
 			// (:1049-1057).  A detected TOA is a multiple of 1/512 symbol (bisection step, table toa, integer head), so
@@ -658,7 +764,6 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 					// filter as a pure delay, so comp_f is the decimator shifted by 9 + frac and the taps outside carry
 					// < 1.1e-6 (u < 8) of the filter's absolute sum in every one of the 65 rows (tests/test_capi_cpu.py).
 					// The filter runs over u = K4_U0 .. K4_U0 + K4_NT - 1 = 8 .. 31: 24 taps instead of 36.
-					constexpr int K4_U0 = 8, K4_NT = 24;
 					const float4 *c4 = reinterpret_cast<const float4 *>(comp + fidx * 36 + K4_U0);   // broadcast reads
 					const int c_full = -24 - w;                                 // sample of tap 0 of output i: 4i + c_full
 					const int c = c_full + K4_U0;
@@ -670,30 +775,8 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 					if (ic > i_max - 2) ic = i_max - 2;
 					const PhBase pb = ph_bases(P, c & 3, ic + (c >> 2));
 					v2f acc[3] = { { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f } };
-					if (!ABL(5)) {
-						constexpr int D = 4, NV = K4_NT + 8;                    // samples v = 0 .. 31
-						c32 xw[16];
-						float4 cq[2];
-						cq[0] = c4[0];
-#pragma unroll
-						for (int v = 0; v < 8 + D; v++)
-							xw[v] = lds_c32(pb.p[v & 3] + (v >> 2));
-#pragma unroll
-						for (int u = 0; u < K4_NT; u++) {
-							if ((u & 3) == 0 && u + 4 < K4_NT)
-								cq[((u >> 2) + 1) & 1] = c4[(u >> 2) + 1];
-							if (u + 8 + D < NV)
-								xw[(u + 8 + D) & 15] = lds_c32(pb.p[(u + 8 + D) & 3] + ((u + 8 + D) >> 2));
-							const float4 ca = cq[(u >> 2) & 1];
-							const v2f hp = (u & 2) ? (v2f){ ca.z, ca.w } : (v2f){ ca.x, ca.y };
-#pragma unroll
-							for (int j = 0; j < 3; j++) {
-								const v2f xv = { xw[(u + 4 * j) & 15].x, xw[(u + 4 * j) & 15].y };
-								acc[j] = (u & 1) ? pk_fma_tap<1>(xv, hp, acc[j]) : pk_fma_tap<0>(xv, hp, acc[j]);
-							}
-							__builtin_amdgcn_sched_barrier(0);
-						}
-					}
+					if (!ABL(5))
+						fir24x3(pb, c4, acc);
 					DIAG_MARK(10);
 					// the 1-SPS symbols go through dec[] (free once detection is done; the 8-PSK tail wants them there
 					// anyway): FIR lanes write theirs, the edge rounds overwrite the few partial ones, then every lane

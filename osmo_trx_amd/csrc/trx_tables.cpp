@@ -431,6 +431,13 @@ private:
 					}
 					t_->edge_lo[f][t0 - 1][u] = (u < 35) ? (float)acc : 0.0f;
 				}
+		// the four rows of the usual geometry, re-packed for the main filter loop (trx_tables.h)
+		for (int f = 0; f <= TRX_DELAY_FILTS; f++)
+			for (int i = 0; i < 4; i++)
+				for (int k = 0; k < 24; k++) {
+					t_->edge8[f][i][k] = t_->edge_lo[f][14 - 4 * i][8 + k];
+					t_->edge8[f][4 + i][k] = (k < 8) ? t_->edge_lo[f][14 - 4 * i][k] : 0.0f;
+				}
 	}
 
 	// EDGE 8-PSK demodulator constants, with the float/double steps of the reference

@@ -10,6 +10,7 @@
 //   * gain_inv, ci_den per sequence (Complex.h:144-150 inv(); sigProcLib.cpp:1629)
 // ~23 KB, generated once on the host (rank 0), broadcast over RCCL, resident in HBM/L2.
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 struct trx_c32 { float re, im; };
@@ -66,10 +67,18 @@ struct trx_tables {
 	// sees the delayed samples n >= n_lo, i.e. decimator taps t >= t0 = n_lo + 15 - 4i (1..15).  Composite of delay
 	// filter f with the decimator truncated to t >= t0:  edge_lo[f][t0-1][u] = sum_{t>=t0, t+k=u} g[t]*h_f[k], u < 35
 	float    edge_lo[TRX_DELAY_FILTS + 1][15][36];
+	// The same four rows re-packed for the usual geometry (n_lo = 0: outputs 0..3 see decimator taps t >= 15, 11, 7, 3),
+	// in the form the main filter loop of the 4-SPS kernel consumes -- 24 taps per lane, tap u = 8..31 of the lane's row:
+	//   edge8[f][i][0..23]     = edge_lo[f][14 - 4i][8..31]              main part of output i (lanes 52..55)
+	//   edge8[f][4 + i][0..23] = edge_lo[f][14 - 4i][0..7], then zeros   its taps u < 8, for a lane whose window starts 8
+	//                                                                     samples early (lanes 56..59); taps u >= 32 are 0
+	float    edge8_pad[2];                              // (edge8 at a multiple of 16 bytes)
+	float    edge8[TRX_DELAY_FILTS + 1][8][24];
 };
+static_assert(offsetof(trx_tables, edge8) % 16 == 0, "edge8 rows are fetched as float4");
 
 #define TRX_TABLES_MAGIC   0x54585254u
-#define TRX_TABLES_VERSION 4u
+#define TRX_TABLES_VERSION 5u
 
 // XOR swizzle of the sincv index: conflict-free LDS gathers both for lanes whose positions differ
 // by multiples of 16/512 (coarse bisection levels) and by 1/512 steps (fine levels).

@@ -45,7 +45,7 @@ BLOB = np.dtype([("magic", "<u4"), ("version", "<u4"), ("dec_taps", "<f4", 16), 
                  ("comp_filt", "<f4", (65, 36)), ("edge_derot", "<c8", 16), ("edge_ideal", "<c8", 9),
                  ("edge_rot2", "<c8", 2), ("edge_step", "<f4"), ("edge_pad", "<f4"),
                  ("unit_neg", "<u8", 21), ("unit_ok", "<u4"), ("unit_pad", "<u4"),
-                 ("edge_lo", "<f4", (65, 15, 36))])
+                 ("edge_lo", "<f4", (65, 15, 36)), ("edge8_pad", "<f4", 2), ("edge8", "<f4", (65, 8, 24))])
 
 
 def test_tables_bit_identical_to_oracle(lib):
@@ -101,6 +101,14 @@ def test_tables_bit_identical_to_oracle(lib):
             np.testing.assert_allclose(t["edge_lo"][f][t0 - 1][:35], ref, rtol=1e-7, atol=1e-12)
             assert t["edge_lo"][f][t0 - 1][35] == 0
     assert np.array_equal(t["edge_lo"][64][6][9 + 7:25], o["dec_taps"][7:]) and not t["edge_lo"][64][6][:16].any()
+    # the usual-geometry repack the main filter loop consumes (trx_tables.h, edge8): rows of outputs 0..3 from tap 8 on,
+    # their taps below 8 as separate rows; nothing is lost by the 32-tap window (tap 0 and taps >= 32 are exactly zero)
+    assert not t["edge_lo"][:, :, 32:].any() and not t["edge_lo"][:, :, 0].any()
+    for i in range(4):
+        assert np.array_equal(t["edge8"][:, i, :], t["edge_lo"][:, 14 - 4 * i, 8:32])
+        assert np.array_equal(t["edge8"][:, 4 + i, :8], t["edge_lo"][:, 14 - 4 * i, :8]) and not t["edge8"][:, 4 + i, 8:].any()
+    # the straight-line decimator mirrors taps 0..7 (trx_kernel4.hip, decimate16_sym): bitwise symmetric filter
+    assert np.array_equal(t["dec_taps"].view(np.uint32), t["dec_taps"][::-1].view(np.uint32))
     # resampler / channelizer partitions against the oracle's restatements
     L = O.lib()
     r = L.orc_resampler_new(65, 48, 16, 1.0)
