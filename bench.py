@@ -258,7 +258,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,
-                "kernel": "burst_pull4_kernel<false, false>", "kernel_ms": round(kernel_ms, 4),
+                "kernel": "burst_pull4_kernel<false, false, true>", "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_bytes_per_burst": BYTES_PER_BURST, "bursts_per_launch": n,
             },
         }

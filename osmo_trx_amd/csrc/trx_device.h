@@ -122,6 +122,16 @@ __device__ __forceinline__ int write_lane(int word, int sval)
 	return word;
 }
 
+// the (wave-uniform but vector-resident) value `vval` into lane LANE of `word`: one v_cndmask under a constant lane mask, where
+// v_readfirstlane + v_writelane would be two vector instructions
+template <int LANE>
+__device__ __forceinline__ int put_lane(int word, float vval)
+{
+	const unsigned long long m = 1ull << LANE;
+	asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(word) : "v"(vval), "s"(m));
+	return word;
+}
+
 // DPP move: lanes without a valid source keep their own value
 // Work claiming from a workgroup-wide LDS counter, split in two so that the atomic's latency is covered by whatever runs
 // between issue and use: lane 0 alone executes one ds_add_rtn_u32 (exec is narrowed around it -- both calls sit in
@@ -202,6 +212,19 @@ __device__ __forceinline__ void wave_max_and_sum(float &m, float &s)
 #undef TRX_DPP_PAIR
 	m = lane_val(m, 63);
 	s = lane_val(s, 63);
+}
+
+// wave sum of the values held by the lanes = 0 mod 4 (what the other lanes hold is ignored): the quad's lane 0 is broadcast
+// to its quad, then four DPP adds -- five instructions where zeroing the other lanes and the full tree take seven
+__device__ __forceinline__ float wave_sum_quad0(float v)
+{
+	asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %0 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+		     TRX_DPP_STEP("v_add_f32_dpp", "row_half_mirror row_mask:0xf bank_mask:0xf")
+		     TRX_DPP_STEP("v_add_f32_dpp", "row_mirror row_mask:0xf bank_mask:0xf")
+		     TRX_DPP_STEP("v_add_f32_dpp", "row_bcast:15 row_mask:0xa bank_mask:0xf")
+		     TRX_DPP_STEP("v_add_f32_dpp", "row_bcast:31 row_mask:0xc bank_mask:0xf")
+		     : "+v"(v));
+	return lane_val(v, 63);
 }
 
 // sum over each row of 16 lanes (every lane of the row gets the total)
@@ -405,6 +428,24 @@ __device__ __forceinline__ c32 interp_taps(const c32 *c, const float *sa, const 
 	return p;
 }
 
+// the same with the 16 weights handed over in registers (tap order: i = fl-7 .. fl+8), for positions whose weights the caller
+// keeps per lane (round A of the speculative bisection: functions of the lane only)
+__device__ __forceinline__ c32 interp_taps_w(const c32 *c, const float4 &w0, const float4 &w1, const float4 &w2, const float4 &w3)
+{
+	typedef const volatile trx_v2f __attribute__((address_space(3))) *lds_ptr;
+	lds_ptr cp = (lds_ptr)c;
+	asm("" : "+v"(cp));
+	const float w[16] = { w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w };
+	c32 p = make_float2(0.0f, 0.0f);
+#pragma unroll
+	for (int u = 0; u < 16; u++) {
+		const trx_v2f v = cp[u];
+		p.x += v.x * w[u];
+		p.y += v.y * w[u];
+	}
+	return p;
+}
+
 // LUT bases of a fractional position f (= ix512 & 511): taps i <= fl use q = 512*(fl-i) + f,
 // taps i > fl use q = 512*(i-fl-1) + (512 - f)
 __device__ __forceinline__ int sinc_base_lo(int f) { return trx_sincv_swz(f); }
@@ -497,8 +538,10 @@ __device__ __forceinline__ int walk_tree(float nv, int inc0, bool &tie)
 // peakDetect() (sigProcLib.cpp:1141-1186) with the early/late bisection expanded across lanes.
 // All lanes return the same (toa512, value).
 // ------------------------------------------------------------------------------------------------
+//   wa4 : optional (4-SPS fused kernel) LDS table of round A's weights, float4 q of lane l at wa4[64 q + l] (the weights of
+//         round A depend on the lane only): four conflict-free 16-byte reads instead of sixteen 4-byte gathers
 __device__ __forceinline__ void peak_detect_spec(const c32 *cz, int max_idx, const float *sincv, const PeakConst &pc,
-						  int lane, int *toa512_out, c32 *val_out)
+						  int lane, int *toa512_out, c32 *val_out, const float4 *wa4 = nullptr)
 {
 	int E = (max_idx - 1) * 512;                     // earlyIndex * 512
 	bool tie = false;
@@ -506,7 +549,9 @@ __device__ __forceinline__ void peak_detect_spec(const c32 *cz, int max_idx, con
 	// ---- round A: levels 0..4 (incr = 1/2 .. 1/32): heap node n on lanes 2n (early) and 2n+1 (late)
 	{
 		// ix = E + offA with E a multiple of 512: floor and fraction come from the lane constants
-		const float nv = norm2(interp_taps(cz + ((max_idx - 1) + pc.flA - 7), sincv + pc.loA, sincv + pc.hiA));
+		const c32 *const ca = cz + ((max_idx - 1) + pc.flA - 7);
+		const float nv = wa4 ? norm2(interp_taps_w(ca, wa4[lane], wa4[64 + lane], wa4[128 + lane], wa4[192 + lane]))
+				     : norm2(interp_taps(ca, sincv + pc.loA, sincv + pc.hiA));
 		// (lanes 62,63 evaluate a harmless extra node)
 		E += walk_tree<5>(nv, 256, tie);
 	}
@@ -547,7 +592,7 @@ struct NoToaHook { __device__ __forceinline__ void operator()(int) const {} };
 template <typename Hook>
 __device__ __forceinline__ int detect_tail_h(const c32 *sig, int sig_len, c32 *cz, const float *hdr, int N, float thresh,
 					      int start, int len, int bidx, const float *sincv, const PeakConst &pc, int lane,
-					      float *toa_out, c32 *amp_out, float *ci_out, Hook on_toa, int slice DIAG_ARG)
+					      float *toa_out, c32 *amp_out, float *ci_out, Hook on_toa, const float4 *wa4, int slice DIAG_ARG)
 {
 	if ((bidx < 3) || (bidx > len - 3))               // :1683
 		return 0;
@@ -604,7 +649,7 @@ __device__ __forceinline__ int detect_tail_h(const c32 *sig, int sig_len, c32 *c
 	wave_sync();
 	if (ABL(1)) { toa512 = bidx * 512; xcorr = amp0; }
 	else
-		peak_detect_spec(cz, bidx, sincv, pc, lane, &toa512, &xcorr);
+		peak_detect_spec(cz, bidx, sincv, pc, lane, &toa512, &xcorr, wa4);
 	toa512 = uni(toa512);
 	xcorr.x = unif(xcorr.x);
 	xcorr.y = unif(xcorr.y);
@@ -660,7 +705,7 @@ __device__ __forceinline__ int detect_tail(const c32 *sig, int sig_len, c32 *cz,
 					    float *toa_out, c32 *amp_out, float *ci_out, int slice DIAG_ARG)
 {
 	return detect_tail_h(sig, sig_len, cz, hdr, N, thresh, start, len, bidx, sincv, pc, lane, toa_out, amp_out, ci_out,
-			     NoToaHook(), slice DIAG_PASS);
+			     NoToaHook(), nullptr, slice DIAG_PASS);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -677,7 +722,7 @@ __device__ __forceinline__ int detect_tail(const c32 *sig, int sig_len, c32 *cz,
 template <bool PADDED, bool NARROW, typename Hook>
 __device__ __forceinline__ int detect_burst_h(const c32 *sig, int sig_len, c32 *cz, const c32 *taps, const float *hdr,
 					       int N, float thresh, int start, int len, const float *sincv, const PeakConst &pc, int lane,
-					       float *toa_out, c32 *amp_out, float *ci_out, Hook on_toa, int slice, int unit_slot DIAG_ARG)
+					       float *toa_out, c32 *amp_out, float *ci_out, Hook on_toa, const float4 *wa4, int slice, int unit_slot DIAG_ARG)
 {
 	const bool wide = NARROW && (len > TRX_CORR_NARROW || start + len > TRX_DEC_NARROW);
 	// corr[i] with range-checked reads, taps in order (cold: wide windows only)
@@ -770,7 +815,7 @@ __device__ __forceinline__ int detect_burst_h(const c32 *sig, int sig_len, c32 *
 		czp = win - (bidx - TRX_CZ_PAD);
 	}
 	const int r = detect_tail_h(sig, sig_len, czp, hdr, N, thresh, start, len, bidx, sincv, pc, lane, toa_out, amp_out, ci_out,
-				    on_toa, slice DIAG_PASS);
+				    on_toa, wa4, slice DIAG_PASS);
 	if (wide) {
 		wave_sync();
 		if (lane < TRX_CZ_PAD)
@@ -785,7 +830,7 @@ __device__ __forceinline__ int detect_burst(const c32 *sig, int sig_len, c32 *cz
 					     float *toa_out, c32 *amp_out, float *ci_out, int slice, int unit_slot DIAG_ARG)
 {
 	return detect_burst_h<PADDED, NARROW>(sig, sig_len, cz, taps, hdr, N, thresh, start, len, sincv, pc, lane, toa_out, amp_out,
-					      ci_out, NoToaHook(), slice, unit_slot DIAG_PASS);
+					      ci_out, NoToaHook(), nullptr, slice, unit_slot DIAG_PASS);
 }
 
 

@@ -171,7 +171,9 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 
 	// ---- LDS carve: [tables][per-wave slices]
 	float *sincv = reinterpret_cast<float *>(smem);                 // [4128] swizzled sinc LUT
-	float *dfilt = sincv + TRX_SINCV_LDS;                          // [65][20] fractional-delay filters + identity
+	float *dfilt = sincv + TRX_SINCV_LDS;                          // EXACT: [65][20] fractional-delay filters + identity;
+	                                                               // fused: [4][64] float4, round A's interpolation weights by lane
+	const float4 *const wa4 = EXACT ? nullptr : reinterpret_cast<const float4 *>(dfilt);
 	c32 *rrot = reinterpret_cast<c32 *>(dfilt + K4_DROWS * TRX_DELAY_HLEN);   // [160] reverse rotation
 	float *gdec = reinterpret_cast<float *>(rrot + 160);           // [16] decimator taps
 	c32 *lseq = reinterpret_cast<c32 *>(gdec + 16);                // [376] training sequences
@@ -187,9 +189,20 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 	// ---- one-time staging (workgroup-wide) of every table; zero this wave's slice (pads stay zero)
 	for (int i = threadIdx.x; i < TRX_SINCV_LDS; i += blockDim.x)
 		sincv[i] = (i < TRX_SINCV_LEN) ? tab->sincv[i] : 0.0f;
-	for (int i = threadIdx.x; i < K4_DROWS * TRX_DELAY_HLEN; i += blockDim.x)
-		dfilt[i] = (i < TRX_DELAY_FILTS * TRX_DELAY_HLEN) ? (&tab->delay_filt[0][0])[i]
-								  : ((i - TRX_DELAY_FILTS * TRX_DELAY_HLEN) == 9 ? 1.0f : 0.0f);
+	if (EXACT) {
+		for (int i = threadIdx.x; i < K4_DROWS * TRX_DELAY_HLEN; i += blockDim.x)
+			dfilt[i] = (i < TRX_DELAY_FILTS * TRX_DELAY_HLEN) ? (&tab->delay_filt[0][0])[i]
+									  : ((i - TRX_DELAY_FILTS * TRX_DELAY_HLEN) == 9 ? 1.0f : 0.0f);
+	} else {
+		// the fused kernel's hot path never needs a delay-filter row (its cold edge rounds read them from global memory):
+		// the space holds the 16 sinc weights of every lane's round-A position (peak_detect_spec), tap order fl-7 .. fl+8
+		for (int i = threadIdx.x; i < 16 * WAVE; i += blockDim.x) {
+			const int l = i & (WAVE - 1), u = i >> 6;
+			const PeakConst pcl = peak_const(l);
+			const int q = (u < 8) ? pcl.loA + 512 * (7 - u) : pcl.hiA + 512 * (u - 8);
+			dfilt[((u >> 2) * WAVE + l) * 4 + (u & 3)] = (q < TRX_SINCV_LEN) ? tab->sincv[q] : 0.0f;
+		}
+	}
 	for (int i = threadIdx.x; i < K4_DROWS * 36; i += blockDim.x)
 		comp[i] = (&tab->comp_filt[0][0])[i];
 	for (int i = threadIdx.x; i < 160; i += blockDim.x)
@@ -322,12 +335,12 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 		// result record: 32 bytes, one dword per lane 0..7.  Every field is wave-uniform: v_writelane drops it into
 		// its lane (one instruction per field instead of a compare and a select)
 		int word = pend_rc;
-		word = write_lane<1>(word, __float_as_int(pend_toa));
+		word = put_lane<1>(word, pend_toa);                         // results of vector arithmetic: still in vector registers
 		word = write_lane<2>(word, __float_as_int(pend_ax));
 		word = write_lane<3>(word, __float_as_int(pend_ay));
-		word = write_lane<4>(word, __float_as_int(pend_ci));
-		word = write_lane<5>(word, __float_as_int(pend_energy));
-		word = write_lane<6>(word, __float_as_int(pend_rssi));
+		word = put_lane<4>(word, pend_ci);
+		word = put_lane<5>(word, pend_energy);
+		word = put_lane<6>(word, pend_rssi);
 		word = write_lane<7>(word, (int)pend_flags);
 		if (lane < 8)
 			reinterpret_cast<int *>(results + pend_b)[lane] = word;
@@ -396,7 +409,6 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 					epart = fmaf(v.x, v.x, fmaf(v.y, v.y, epart));      // (tree-summed anyway: tolerance 3e-6, not an ordered sum)
 			}
 		}
-		epart = (lane & 3) ? 0.0f : epart;
 		DIAG_MARK(14);
 		flush(lane);                                               // the previous burst's output (its dec[] is still intact)
 		pend_mode = 0;
@@ -408,8 +420,9 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 		DIAG_MARK(15);
 
 		if (type != TRXHIP_OFF) {                                   // Transceiver.cpp:704-707
-			wave_max_and_sum(amax, epart);                          // maxAmplitude(), :1711-1722; energyDetect partial sums
-			clip = amax > TRX_CLIP_THRESH;
+			// maxAmplitude() > 30000 (:1711-1722, :1746): some lane saw a larger component -- a compare and a ballot, no wave max
+			clip = __ballot(amax > TRX_CLIP_THRESH) != 0ull;
+			epart = wave_sum_quad0(epart);                          // energyDetect partial sums (lanes = 0 mod 4 hold them)
 			energy = epart * 0.0125f;                               // energyDetect(burst, 20*sps): / 80
 			if (!ABL(2))
 				rssi = fs_db - 3.01029996f * __log2f(energy);       // 20*log10(fs/sqrt(e)), Transceiver.cpp:741,751
@@ -468,7 +481,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 					const float *const hdr = lhdr + 8 * tsc;
 					auto on_toa = [&](int toa512) { fast_fetch(toa512 - (int)(hdr[5] * 512.0f) - 10 * 512); };
 					const int hit = detect_burst_h<true, true>(dec, 156, cz, lseq + LSEQ_TSC(tsc), hdr, 16, thresh, 71, len, sincv,
-										   pkc, lane, &toa, &amp, &ci, on_toa, slice, unit_bad ? -1 : tsc DIAG_PASS);
+										   pkc, lane, &toa, &amp, &ci, on_toa, wa4, slice, unit_bad ? -1 : tsc DIAG_PASS);
 					wave_sync();
 					rc = hit ? TRXHIP_TSC : (clip ? -TRXHIP_SIGERR_CLIP : 0);                 // :1764, :1953-1954
 					toa -= 10.0f;                                                              // :1768
@@ -490,15 +503,15 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 					unit_bad |= (__ballot(bad) != 0ull) ? 1 : 0;
 					wave_sync();
 					DIAG_MARK(2);
-					int hit = detect_burst<true, true>(dec, 156, cz, lseq + LSEQ_RACH(0), lhdr + 8 * 8, 40, thresh, 39, len, sincv,
-									   pkc, lane, &toa, &amp, &ci, slice, unit_bad ? -1 : 8 DIAG_PASS);
+					int hit = detect_burst_h<true, true>(dec, 156, cz, lseq + LSEQ_RACH(0), lhdr + 8 * 8, 40, thresh, 39, len, sincv,
+									     pkc, lane, &toa, &amp, &ci, NoToaHook(), wa4, slice, unit_bad ? -1 : 8 DIAG_PASS);
 					wave_sync();
 					out_tsc = 0;                                                               // ebp->tsc = i (:1797)
 					if (!hit && type == TRXHIP_EXT_RACH) {
 						// extended access bursts: TS1, then TS2 over the same window, first hit wins (:1791-1800)
 						for (int c = 1; c < 3 && !hit; c++) {
-							hit = detect_burst<true, true>(dec, 156, cz, lseq + LSEQ_RACH(c), lhdr + 8 * (8 + c), 40, thresh, 39, len,
-										       sincv, pkc, lane, &toa, &amp, &ci, slice, unit_bad ? -1 : 8 + c DIAG_PASS);
+							hit = detect_burst_h<true, true>(dec, 156, cz, lseq + LSEQ_RACH(c), lhdr + 8 * (8 + c), 40, thresh, 39, len,
+											 sincv, pkc, lane, &toa, &amp, &ci, NoToaHook(), wa4, slice, unit_bad ? -1 : 8 + c DIAG_PASS);
 							wave_sync();
 							out_tsc = c;
 						}
@@ -631,11 +644,17 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 
 			float hh[TRX_DELAY_HLEN];                                      // delay filter taps (LDS broadcast reads)
 			auto load_hh = [&]() {
-				const float4 *hf4 = reinterpret_cast<const float4 *>(dfilt + fidx * TRX_DELAY_HLEN);
+				if (EXACT) {
+					const float4 *hf4 = reinterpret_cast<const float4 *>(dfilt + fidx * TRX_DELAY_HLEN);
 #pragma unroll
-				for (int q = 0; q < TRX_DELAY_HLEN / 4; q++) {
-					const float4 h4 = hf4[q];
-					hh[4 * q + 0] = h4.x; hh[4 * q + 1] = h4.y; hh[4 * q + 2] = h4.z; hh[4 * q + 3] = h4.w;
+					for (int q = 0; q < TRX_DELAY_HLEN / 4; q++) {
+						const float4 h4 = hf4[q];
+						hh[4 * q + 0] = h4.x; hh[4 * q + 1] = h4.y; hh[4 * q + 2] = h4.z; hh[4 * q + 3] = h4.w;
+					}
+				} else {                                                    // (cold: the edge rounds of unusual geometries)
+#pragma unroll
+					for (int k = 0; k < TRX_DELAY_HLEN; k++)
+						hh[k] = (fidx < TRX_DELAY_FILTS) ? tab->delay_filt[fidx][k] : (k == 9 ? 1.0f : 0.0f);
 				}
 			};
 

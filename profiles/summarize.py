@@ -20,7 +20,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out")
-KERNEL = "burst_pull4_kernel<false, false>"
+KERNEL = "burst_pull4_kernel<false, false, true>"
 
 
 def counter(path, name):

@@ -19,7 +19,7 @@ n = 1 << 20
 for f in sorted(glob.glob(f"{O}/pmcq*/**/{tag}_counter_collection.csv", recursive=True)):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "burst_pull4_kernel<false, false>" in r["Kernel_Name"]:
+        if "burst_pull4_kernel<false, false, true>" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in acc.items():
         print(f"{k:26s} {sum(v) / len(v) / n:10.2f}")
