@@ -92,9 +92,60 @@ def _build_shim(out, inc_dirs, force):
             inc += ["-I", d]
         # -Wl,-z,undefs is the default for shared objects: the out-of-line members of the reference's signalVector
         # (signalVector.cpp) stay undefined here and are resolved by the process that loads the shim, as in osmo-trx
+        # -Bsymbolic-functions: the library's own calls to detectAnyBurst() & co. bind to its own definitions even inside
+        # an executable that defines functions of the same name (the --wrap recipe, build_wrap() below)
         _run(HOSTCXX + ["-shared"] + COMMON + ["-pthread"] + inc + ["-o", out] + srcs +
-             ["-L", LIBDIR, "-ltrxhip", "-Wl,-rpath,$ORIGIN"] + HOSTLINK)
+             ["-L", LIBDIR, "-ltrxhip", "-Wl,-rpath,$ORIGIN", "-Wl,-Bsymbolic-functions"] + HOSTLINK)
     return out
+
+
+WRAPPED = ("sigProcLibSetup", "sigProcLibDestroy", "detectAnyBurst", "demodAnyBurst", "energyDetect", "vectorSlicer",
+           "delayVector", "scaleVector", "detectSCHBurst")
+
+
+def build_wrap(force=False):
+    """libtrxwrap.a + trxwrap.ldflags: GNU ld --wrap interposition of the receive-side sigProcLib functions for an osmo-trx
+    binary that keeps its own sigProcLib.o (Tx-side modulators + their tables): no source change in osmo-trx.
+    trxwrap.cpp defines the nine functions under the reference's names; objcopy renames <mangled> -> __wrap_<mangled> and
+    trxwrap_real_X -> __real_<mangled X>.  Needs an osmo-trx checkout (reference headers) like libtrxsigproc.so."""
+    ref = ref_include_dirs()
+    lib = os.path.join(LIBDIR, "libtrxwrap.a")
+    flags = os.path.join(LIBDIR, "trxwrap.ldflags")
+    if not ref:
+        return [p for p in (lib, flags) if os.path.exists(p)]
+    src = os.path.join(HOST, "trxwrap.cpp")
+    if force or _stale(lib, [src, os.path.join(HOST, "trxWrap.h")]) or not os.path.exists(flags):
+        obj = os.path.join(LIBDIR, "trxwrap.o")
+        inc = []
+        for d in ref + [HOST]:
+            inc += ["-I", d]
+        _run([HOSTCXX[0]] + COMMON + inc + ["-c", "-o", obj, src])
+        syms = _run(["nm", obj]).splitlines()
+        names = {}          # function name -> mangled
+        for line in syms:
+            parts = line.split()
+            m = parts[-1]
+            for w in WRAPPED:
+                if parts[-2] == "T" and m.startswith("_Z%d%s" % (len(w), w)):
+                    names[w] = m
+        assert sorted(names) == sorted(WRAPPED), names
+        redef = os.path.join(LIBDIR, "trxwrap.redef")
+        with open(redef, "w") as f:
+            for w, m in names.items():
+                f.write("%s __wrap_%s\n" % (m, m))
+            for w in ("sigProcLibSetup", "sigProcLibDestroy"):
+                real = "_Z%d%s%s" % (len("trxwrap_real_" + w), "trxwrap_real_" + w, "v")
+                f.write("%s __real_%s\n" % (real, names[w]))
+        _run(["objcopy", "--redefine-syms=" + redef, obj])
+        if os.path.exists(lib):
+            os.remove(lib)
+        _run(["ar", "rcs", lib, obj])
+        with open(flags, "w") as f:       # for  g++ ... -Wl,@trxwrap.ldflags
+            for w in WRAPPED:
+                f.write("--wrap=%s\n" % names[w])
+        os.remove(obj)
+        os.remove(redef)
+    return [lib, flags]
 
 
 def build_host(force=False):
@@ -139,6 +190,7 @@ def build_arch(force=False):
 def build_all(force=False, verbose=False):
     out = [build_lib(force, verbose)]
     out += build_host(force)
+    out += build_wrap(force)
     out.append(build_arch(force))
     return out
 

@@ -527,4 +527,33 @@ int pullRadioVectorBatchVA(const BurstRequest *req, size_t n, int sps, size_t bu
 	return 0;
 }
 
+
 TRX_SHIM_NS_END
+
+#ifdef TRX_SHIM_REFERENCE_ABI
+/* The same functions under names of their own, for binaries that keep the reference's sigProcLib.o and interpose the
+ * receive side at link time (trxWrap.h, trxwrap.cpp).  The library is linked -Bsymbolic-functions: the
+ * calls below bind to this library's definitions even when the executable defines functions of the same name. */
+#include "trxWrap.h"
+namespace trxgpu {
+bool sigProcLibSetup() { return ::sigProcLibSetup(); }
+void sigProcLibDestroy() { ::sigProcLibDestroy(); }
+int detectAnyBurst(const signalVector &burst, unsigned tsc, float threshold, int sps, CorrType type, unsigned max_toa,
+		   struct estim_burst_params *ebp)
+{
+	return ::detectAnyBurst(burst, tsc, threshold, sps, type, max_toa, ebp);
+}
+SoftVector *demodAnyBurst(const signalVector &burst, CorrType type, int sps, struct estim_burst_params *ebp)
+{
+	return ::demodAnyBurst(burst, type, sps, ebp);
+}
+float energyDetect(const signalVector &rxBurst, unsigned windowLength) { return ::energyDetect(rxBurst, windowLength); }
+void vectorSlicer(float *dest, const float *src, size_t len) { ::vectorSlicer(dest, src, len); }
+signalVector *delayVector(const signalVector *in, signalVector *out, float delay) { return ::delayVector(in, out, delay); }
+void scaleVector(signalVector &x, complex scale) { ::scaleVector(x, scale); }
+int detectSCHBurst(signalVector &burst, float thresh, int sps, sch_detect_type state, struct estim_burst_params *ebp)
+{
+	return ::detectSCHBurst(burst, thresh, sps, state, ebp);
+}
+}
+#endif

@@ -14,6 +14,7 @@
 #define TRX_SHIM_NS_BEGIN
 #define TRX_SHIM_NS_END
 #define TRX_SHIM_ABI "reference"
+#define TRX_SHIM_REFERENCE_ABI 1
 #endif
 
 TRX_SHIM_NS_BEGIN
