@@ -19,6 +19,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+import re
+FUSED_SOFT_ATOL = float(re.search(r"#define\s+TRXHIP_FUSED_SOFT_ATOL\s+([0-9.eE+-]+)f?\b",       # the one tolerance statement
+                                  open(os.path.join(ROOT, "include", "trxhip.h")).read()).group(1))
 BYTES_PER_BURST = 3132          # 2500 B int16 IQ + 8 B params + 592 B soft bits + 32 B result
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -148,6 +151,141 @@ def side_legs(args, trx, synth, shard, step, iq, n, dev, rank, world, results, s
     return exact_ms, mixed_s, mixed_detected, host_fed
 
 
+def timed_passes(fn, shard, dev, world, passes=5):
+    """Wall time of `passes` calls of fn, barrier + synchronize on both sides, max over ranks; plus the mean HIP-event time."""
+    import torch
+    fn()
+    torch.cuda.synchronize()
+    shard.barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(passes)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    shard.barrier()
+    wall = shard.max_over_ranks(time.perf_counter() - t0, dev if world > 1 else None)
+    return wall, sum(a.elapsed_time(b) for a, b in ev) / passes
+
+
+def config_legs(args, trx, synth, shard, n, dev, rank, world):
+    """Driver-timed numbers for the other BASELINE.json configs (never `value`): configs[0] geometry, configs[2] (RACH and
+    EXT_RACH), configs[3] (multi-ARFCN front end, alone and with the per-channel detector behind it) and -- for N > 1 -- the
+    strong-scaling form of configs[4] (one fixed 8M-burst batch, contiguous shards, osmo_trx_amd.shard.shard_range)."""
+    import numpy as np
+    import torch
+    from osmo_trx_amd import trxhip
+    out = {}
+    want = set(("c0", "c2", "c3") + (("strong",) if world > 1 else ())) if args.legs == "all" else set(args.legs.split(","))
+    results = torch.empty((n, 32), dtype=torch.uint8, device=dev)
+    soft = torch.empty((n, 148), dtype=torch.float32, device=dev)
+
+    def roof(bytes_per_pass, ms):
+        gbs = bytes_per_pass / (ms * 1e-3) / 1e9
+        return {"achieved_GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+
+    def pull_leg(key, workload, iq, params, burst_len, sps=4):
+        dp = trx.params_tensor(params)
+        wall, ms = timed_passes(lambda: trx.detect_demod(iq, dp, sps=sps, soft_stride=148, slice_bits=True, results=results,
+                                                         soft=soft), shard, dev, world)
+        det = int((trx.results_to_numpy(results)["rc"] > 0).sum())
+        out[key] = {"workload": workload, "mbursts_per_s_all_gpus": round(5 * n * world / wall / 1e6, 2),
+                    "kernel_ms": round(ms, 4), "detected_fraction": round(det / n, 4),
+                    "roofline": roof(n * (burst_len * 4 + 8 + 32 + 592), ms)}
+
+    if "c0" in want:
+        # configs[0]: the reference's CPU-runnable case (1 SPS, TSC 0); on the GPU it is the generic kernel's geometry
+        iq, p, _ = synth.make_normal_bursts(n, dev, 1, seed=synth.SEED + 11 + 1000003 * rank, tsc=0, burst_len=156)
+        pull_leg("configs[0]", "normal bursts, 1 SPS, 156 samples, TSC 0, max_toa 3 (the reference's generic-C case; GPU: "
+                 "burst_pull_kernel<1,...>)", iq, p, 156, sps=1)
+        del iq
+    if "c2" in want:
+        # configs[2]: access bursts
+        iq, p, _ = synth.make_access_bursts(n, dev, seed=synth.SEED + 1 + 1000003 * rank)
+        pull_leg("configs[2]", "RACH bursts, 4 SPS, max_toa 63 (detectRACHBurst: 40 taps x 79 lags)", iq, p, 625)
+        del iq
+        iq, p, _ = synth.make_access_bursts(n, dev, seed=synth.SEED + 21 + 1000003 * rank, ext=True)
+        pull_leg("configs[2]_ext_rach", "EXT_RACH bursts (TS0/1/2 tried in turn), max_toa 63", iq, p, 625)
+        del iq
+    del results, soft
+    if "c3" in want:
+        config3_leg(trx, synth, shard, dev, rank, world, out, roof)
+    if "strong" in want:
+        strong_leg(trx, synth, shard, dev, rank, world, out)
+    return out
+
+
+def config3_leg(trx, synth, shard, dev, rank, world, out, roof):
+    import numpy as np
+    import torch
+    from osmo_trx_amd import trxhip
+    if True:
+        # configs[3]: 4-ARFCN front end over ~256k Channelizer blocks (a 416-timeslot, 3-carrier wideband capture repeated; the
+        # synthesis is circular, so the tiled stream is continuous), then the detector on each carrier's channel stream
+        tile_slots, reps = 52 * 8, 262
+        wide1, nb1, _, tsc1 = synth.make_multi_arfcn_wideband(tile_slots, dev, seed=synth.SEED + 5 + rank)
+        wide = wide1.repeat(reps, 1).contiguous()
+        nb, n_slots = nb1 * reps, tile_slots * reps
+        fe = trxhip.RxFrontEnd(trx)
+        chan = [None]
+
+        def front():
+            chan[0] = fe.pull(wide, nb)
+
+        wall_f, ms_f = timed_passes(front, shard, dev, world)
+        pp = np.zeros(n_slots, dtype=trxhip.PARAMS_DTYPE)
+        pp["type"], pp["tsc"], pp["max_toa"] = 1, np.tile(tsc1, reps), 20
+        dpp = trx.params_tensor(pp)
+        res_c = torch.empty((n_slots, 32), dtype=torch.uint8, device=dev)
+        soft_c = torch.empty((n_slots, 148), dtype=torch.float32, device=dev)
+        found = [0, 0]
+
+        def front_and_detect():
+            front()
+            for k in (0, 1, 3):                                     # the three carriers (filterbank channels 0, 1, 3)
+                trx.detect_demod(chan[0][k].view(n_slots, 625), dpp, sps=4, soft_stride=148, slice_bits=True, results=res_c, soft=soft_c)
+
+        wall_e, ms_e = timed_passes(front_and_detect, shard, dev, world, passes=3)
+        found = int((trx.results_to_numpy(res_c)["rc"] > 0).sum())
+        n_out = nb * 192 // 48 * 65
+        fe_bytes = nb * (768 * 4 + 2 * 4 * 192 * 8) + 4 * n_out * 8          # wideband in, channelizer out + in again, resampled out
+        out["configs[3]"] = {
+            "workload": f"4-ARFCN Channelizer(4,192,16) + Resampler(65,48) over {nb} blocks of 768 wideband int16 samples per GPU "
+                        f"(streaming, carried history), then detect+demod of the {3 * n_slots} timeslots of the 3 carriers",
+            "front_end_mblocks_per_s_all_gpus": round(5 * nb * world / wall_f / 1e6, 2), "front_end_ms": round(ms_f, 4),
+            "front_end_roofline": roof(fe_bytes, ms_f),
+            "with_per_channel_detect_mblocks_per_s_all_gpus": round(3 * nb * world / wall_e / 1e6, 2),
+            "with_per_channel_detect_ms": round(ms_e, 4),
+            "with_per_channel_detect_roofline": roof(fe_bytes + 3 * n_slots * (625 * 8 + 8 + 32 + 592), ms_e),
+            "detected_fraction_last_carrier": round(found / n_slots, 4)}
+        fe.close()
+        del wide, wide1, chan, res_c, soft_c
+
+
+
+def strong_leg(trx, synth, shard, dev, rank, world, out):
+    import torch
+    # configs[4], strong scaling: ONE fixed global batch of 8M mixed bursts, rank r owns shard_range(8M, r, N)
+    if True:
+        total = int(os.environ.get("TRXHIP_BENCH_STRONG_TOTAL", 8 << 20))     # (env: tests shrink the fixed batch)
+        lo, hi = shard.shard_range(total, rank, world)
+        m = hi - lo
+        iq, p = synth.make_mixed_bursts(m, dev, seed=synth.SEED + 2, offset=lo)
+        dp = trx.params_tensor(p)
+        res_s = torch.empty((m, 32), dtype=torch.uint8, device=dev)
+        soft_s = torch.empty((m, 148), dtype=torch.float32, device=dev)
+        wall, ms = timed_passes(lambda: trx.detect_demod(iq, dp, sps=4, soft_stride=148, slice_bits=True, results=res_s,
+                                                         soft=soft_s), shard, dev, world, passes=3)
+        det = shard.sum_over_ranks(int((trx.results_to_numpy(res_s)["rc"] > 0).sum()), dev if world > 1 else None)
+        out["configs[4]_strong"] = {
+            "workload": f"BASELINE.json configs[4]: ONE fixed batch of {total} mixed bursts (7:1 NB:RACH), contiguous shard "
+                        "[N*r/G, N*(r+1)/G) per rank, no data-path collective", "scaling": "strong",
+            "global_bursts": total, "bursts_this_rank": m, "mbursts_per_s_all_gpus": round(3 * total / wall / 1e6, 2),
+            "ms_per_pass": round(wall / 3 * 1e3, 4), "detected_fraction": round(det / total, 4)}
+        del iq, res_s, soft_s
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -160,6 +298,8 @@ def main():
                     help="profiling runs: only the timed configs[1] leg (no exact / mixed / host-fed side legs, no CPU baseline), "
                          "so that every launch of the hot kernel in a rocprofv3 trace is the one `value` is measured on")
     ap.add_argument("--cpu-sample", type=int, default=0, help="bursts for the CPU baseline (0 = auto)")
+    ap.add_argument("--legs", default="all", help="which other_configs legs run: all | none | comma list of c0,c2,c3,strong "
+                                                  "(strong = configs[4]'s fixed 8M batch; default only when N > 1)")
     args = ap.parse_args()
 
     import numpy as np
@@ -171,6 +311,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: osmo_trx_amd has no CPU path")
+    if os.environ.get("TRXHIP_ONE_DEVICE"):              # test hook: every rank on cuda:0 (with TRXHIP_DIST_BACKEND=gloo)
+        local_rank = 0
     dev = f"cuda:{local_rank}"
     torch.cuda.set_device(local_rank)
 
@@ -220,6 +362,10 @@ def main():
     if side:
         exact_ms, mixed_s, mixed_detected, host_fed = side_legs(args, trx, synth, shard, step, iq, n, dev, rank, world, results, soft)
     del iq
+    legs = {}
+    if side and args.legs != "none":
+        del results, soft
+        legs = config_legs(args, trx, synth, shard, n, dev, rank, world)
 
     if rank == 0:
         total_bursts = n * world * args.steps
@@ -248,12 +394,14 @@ def main():
                 "bursts_per_gpu": n, "global_bursts": n * world, "sps": 4, "burst_len": 625,
                 "parallelism": f"batch-sharded x{world} (no data-path collective; tables RCCL-broadcast once)",
                 "detected_fraction": round(detected / n, 4),
-                "demodulator": "fused delay-o-decimate composite filter, 24 of 35 taps (default); rc, TOA, amp bit-exact; soft bits <= 1e-5 absolute (full scale 1)",
+                "demodulator": "fused delay-o-decimate composite filter, 24 of 35 taps (default); rc, TOA, amp bit-exact; "
+                               f"soft bits <= {FUSED_SOFT_ATOL:g} absolute (full scale 1)",
                 "exact_demod_mbursts_per_gpu": round(n / exact_ms / 1e3, 2) if side else None,
                 "mixed_7to1_nb_rach": ({"workload": "BASELINE.json configs[4] per-GPU share: 7:1 NB:RACH, RACH max_toa 63",
                                         "mbursts_per_s_all_gpus": round(5 * n * world / mixed_s / 1e6, 3),
                                         "detected_fraction": round(mixed_detected / n, 4)} if side else None),
                 "host_fed": host_fed,
+                "other_configs": legs or None,
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -63,9 +63,22 @@ enum trxhip_signal_error {
 #define TRXHIP_FLAG_SLICE        1  /* soft bits through vectorSlicer(): 0..1, 148 per burst (else raw -1..+1) */
 #define TRXHIP_FLAG_EXACT_DEMOD  2  /* demodulate with the reference's two FIR stages in its operand order: soft bits
                                      * bit-identical to the generic-C reference.  Default (flag clear) is the fused
-                                     * 35-tap delay-o-decimate filter with FMA: same result to <= 2e-6 of full scale,
-                                     * ~3x fewer multiply-adds.  Detection (rc, TOA, amp, C/I) is bit-exact either way.
+                                     * delay-o-decimate filter with FMA (24 of its 35 taps): soft bits within
+                                     * TRXHIP_FUSED_SOFT_ATOL (below) of the reference's, ~4x fewer multiply-adds.
+                                     * Detection (rc, TOA, amp) is bit-exact either way.
                                      * Only the 4-SPS / 625-sample kernel has a fused path; others are always exact. */
+/* The one statement of the default (fused) demodulator's tolerance; tests/, tools/parity_campaign.py, bench.py and DESIGN.md
+ * quote these two numbers and nothing else.  ABSOLUTE error of a soft bit against the generic-C reference, on soft bits
+ * whose full scale is 1 (raw -1..+1 or sliced 0..1):
+ *     |soft - ref| <= TRXHIP_FUSED_SOFT_ATOL * max(1, rms / (4 |amp|))        GMSK, 148 / 156 soft bits
+ * rms = sqrt(energyDetect()), amp = the detector's amplitude estimate.  The filter's rounding error is relative to the
+ * SAMPLES while the soft bits are scaled by 1/amp: for every real detection rms <= 4 |amp| and the bound is the plain
+ * 1e-5; a noise-only slot that passes the detector at C/I < -12 dB has samples many times its amplitude estimate and the
+ * bound grows with that ratio (worst seen over 4 x 1M bursts: 1.14e-5 on one value in 155 M).  8-PSK rows (444 soft
+ * bits: equaliser gain ~2 behind the filter, three soft bits per symbol) and deliberately extreme inputs (tests' fuzz:
+ * saturation, impulses, silence): TRXHIP_FUSED_SOFT_ATOL_8PSK.  The north-star bar is 1e-4. */
+#define TRXHIP_FUSED_SOFT_ATOL       1e-5f
+#define TRXHIP_FUSED_SOFT_ATOL_8PSK  5e-5f
 
 /* Per-burst input: what pullRadioVector() knows before calling detectAnyBurst()
  * (expectedCorrType() Transceiver.cpp:513-601, mTSC, mMaxExpectedDelayAB/NB :757-758). 8 bytes. */

@@ -15,8 +15,9 @@
 //         windows share LDS reads, and the symbols go through the (by then free) decimation buffer for a
 //         coalesced store.  The reference truncates the intermediate
 //         signal (zero outside [0, L) after the delay, zero history in front of the decimator): the <= 8
-//         outputs whose decimator window straddles those edges are recomputed with the exact masked two-stage
-//         sum, so the result differs from the reference only by rounding (<= 2e-6 of full scale; bar 1e-4).
+//         outputs whose decimator window straddles those edges come from truncated-composite tables (or, in unusual
+//         geometries, the exact masked two-stage sum), so the result differs from the reference only by rounding and the
+//         dropped taps: TRXHIP_FUSED_SOFT_ATOL (include/trxhip.h: 1e-5 absolute on full scale 1; bar 1e-4).
 //     Detection (rc, TOA, amp, C/I) is shared and bit-exact in both modes.
 //   * occupancy: 16 waves per CU (4 per SIMD) -- per-wave LDS is cut to 7.7 KB (NARROW buffers, trx_device.h) and the
 //     kernel kept at 128 VGPRs.  A wave is one serial program per burst and a SIMD runs four: what counts is that all

@@ -23,7 +23,9 @@ def init_distributed(backend=None):
     rank, local_rank, world = env_world()
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # TRXHIP_DIST_BACKEND=gloo: ranks that share one GPU (tests/test_gpu_sharded.py runs bench.py's N = 2 path on
+            # a 1-GPU box; RCCL refuses two ranks on one device, gloo moves the same device tensors through the host)
+            backend = os.environ.get("TRXHIP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":

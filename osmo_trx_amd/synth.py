@@ -220,9 +220,11 @@ def _gen(seed, device):
 
 def make_normal_bursts(n, device="cpu", sps=4, seed=SEED, max_toa=3, tsc=None, amp_range=(500.0, 20000.0),
                        snr_range=(5.0, 30.0), delay_sym=(0.0, 4.0), p_noise=0.05, p_clip=0.01, burst_len=None,
-                       chunk=65536):
+                       chunk=65536, chunk0=0):
     """BASELINE.json configs[1] (sps=4: all 8 TSCs, burst i uses TSC i%8) / configs[0] (sps=1).
-    Returns (iq int16[n, L, 2] on `device`, params PARAMS_DTYPE[n] numpy, truth dict of numpy arrays)."""
+    Returns (iq int16[n, L, 2] on `device`, params PARAMS_DTYPE[n] numpy, truth dict of numpy arrays).
+    The batch is generated in independently seeded chunks; chunk0 = index of the first one, so that a rank can generate
+    bursts [chunk0 * chunk, chunk0 * chunk + n) of a larger batch without the rest (bench.py's strong-scaling leg)."""
     device = torch.device(device)
     L = burst_len or (625 if sps == 4 else 156)
     iq = torch.empty((n, L, 2), dtype=torch.int16, device=device)
@@ -237,7 +239,7 @@ def make_normal_bursts(n, device="cpu", sps=4, seed=SEED, max_toa=3, tsc=None, a
     for c0 in range(0, n, chunk):
         c1 = min(n, c0 + chunk)
         m = c1 - c0
-        gen = _gen(seed + 7919 * (c0 // chunk), device)
+        gen = _gen(seed + 7919 * (chunk0 + c0 // chunk), device)
         t = torch.from_numpy(all_tsc[c0:c1]).to(device)
         bits = normal_burst_bits(m, t, gen, device)
         wave = modulate_laurent_4sps(bits) if sps == 4 else modulate_basic_1sps(bits, L)
@@ -257,7 +259,7 @@ def make_normal_bursts(n, device="cpu", sps=4, seed=SEED, max_toa=3, tsc=None, a
 
 
 def make_access_bursts(n, device="cpu", seed=SEED + 1, max_toa=63, ext=False, amp_range=(500.0, 20000.0),
-                       snr_range=(5.0, 30.0), p_noise=0.05, chunk=65536):
+                       snr_range=(5.0, 30.0), p_noise=0.05, chunk=65536, chunk0=0):
     """BASELINE.json configs[2]: access bursts, integer+fractional delay in [0, 63] symbols, 4 SPS."""
     device = torch.device(device)
     L = 625
@@ -270,7 +272,7 @@ def make_access_bursts(n, device="cpu", seed=SEED + 1, max_toa=63, ext=False, am
     for c0 in range(0, n, chunk):
         c1 = min(n, c0 + chunk)
         m = c1 - c0
-        gen = _gen(seed + 104729 * (c0 // chunk), device)
+        gen = _gen(seed + 104729 * (chunk0 + c0 // chunk), device)
         ts = (torch.randint(0, 3, (m,), generator=gen, device=device) if ext
               else torch.zeros(m, dtype=torch.int64, device=device))
         bits = access_burst_bits(m, ts, gen, device)
@@ -287,12 +289,17 @@ def make_access_bursts(n, device="cpu", seed=SEED + 1, max_toa=63, ext=False, am
     return iq, params, truth
 
 
-def make_mixed_bursts(n, device="cpu", seed=SEED + 2, chunk=65536):
-    """BASELINE.json configs[4]: 7:1 NB:RACH interleaved (every 8th burst is an access burst)."""
+def make_mixed_bursts(n, device="cpu", seed=SEED + 2, chunk=65536, offset=0):
+    """BASELINE.json configs[4]: 7:1 NB:RACH interleaved (every 8th burst is an access burst).
+    offset: generate bursts [offset, offset + n) of a larger batch (a multiple of 8 * chunk, so that both the normal-burst
+    chunks and the access-burst chunks of the global batch start on a chunk boundary): concatenating the shards of all
+    ranks gives exactly the batch one call with offset 0 would."""
     device = torch.device(device)
-    iq_nb, p_nb, _ = make_normal_bursts(n, device, 4, seed, chunk=chunk)
+    if offset % (8 * chunk):
+        raise ValueError("offset must be a multiple of 8 * chunk")
+    iq_nb, p_nb, _ = make_normal_bursts(n, device, 4, seed, chunk=chunk, chunk0=offset // chunk)
     n_r = (n + 7) // 8
-    iq_r, p_r, _ = make_access_bursts(n_r, device, seed + 1, chunk=chunk)
+    iq_r, p_r, _ = make_access_bursts(n_r, device, seed + 1, chunk=chunk, chunk0=offset // (8 * chunk))
     sel = torch.arange(7, n, 8, device=device)
     iq_nb[sel] = iq_r[: len(sel)]
     p_nb[7::8] = p_r[: len(sel)]

@@ -35,10 +35,23 @@ def run_gpu(trx, iq, params, sps, soft_stride=148, slice_bits=True, exact=True, 
     return trx.results_to_numpy(res), soft.cpu().numpy()
 
 
-FUSED_SOFT_ATOL = 1e-5      # fused demodulator vs reference soft bits (full scale ~1); north-star bar: 1e-4
+def header_constant(name):
+    """The tolerance statement lives in include/trxhip.h and nowhere else: read it from there."""
+    import re
+    txt = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "trxhip.h")).read()
+    return float(re.search(r"#define\s+" + name + r"\s+([0-9.eE+-]+)f?\b", txt).group(1))
+
+
+FUSED_SOFT_ATOL = header_constant("TRXHIP_FUSED_SOFT_ATOL")             # fused demodulator, GMSK soft bits (full scale 1)
+FUSED_SOFT_ATOL_8PSK = header_constant("TRXHIP_FUSED_SOFT_ATOL_8PSK")   # 8-PSK rows and the fuzz inputs
 
 
 def check_parity(g_res, g_soft, o_res, o_soft, soft_atol=0.0):
+    """GPU against oracle.  soft_atol = 0: everything bit-identical (exact demodulator).  Otherwise the fused
+    demodulator's statement of include/trxhip.h, both clauses: |soft - ref| <= soft_atol * max(1, rms / (4 |amp|)) with
+    rms = sqrt(energy) and amp the amplitude estimate -- the plain bar on every real detection, amplitude-aware on noise
+    slots detected far below their samples' level -- and identical hard decisions wherever the reference is not within
+    10 bars of the decision threshold."""
     for f in ("rc", "tsc", "clip", "idle", "nbits_div4"):
         assert np.array_equal(g_res[f], o_res[f]), f
     for f in ("toa", "amp_re", "amp_im"):
@@ -46,8 +59,12 @@ def check_parity(g_res, g_soft, o_res, o_soft, soft_atol=0.0):
     if soft_atol == 0.0:
         assert np.array_equal(g_soft, o_soft)
     else:
-        np.testing.assert_allclose(g_soft, o_soft, rtol=0, atol=soft_atol)
-        sure = np.abs(o_soft - (0.5 if o_soft.min() >= 0 else 0.0)) > 10 * soft_atol
+        amp = np.hypot(o_res["amp_re"], o_res["amp_im"])
+        ratio = np.where(amp > 0, np.sqrt(np.maximum(o_res["energy"], 0)) / np.maximum(amp, 1e-30), 1.0)
+        bar = (soft_atol * np.maximum(1.0, ratio / 4.0))[:, None]
+        err = np.abs(g_soft - o_soft)
+        assert (err <= bar).all(), float((err / bar).max())
+        sure = np.abs(o_soft - (0.5 if o_soft.min() >= 0 else 0.0)) > 10 * bar
         ref_mid = 0.5 if o_soft.min() >= 0 else 0.0
         assert np.array_equal((g_soft > ref_mid)[sure], (o_soft > ref_mid)[sure])      # same hard decisions
     np.testing.assert_allclose(g_res["energy"], o_res["energy"], rtol=3e-6, atol=0)       # 80-term tree sum vs serial sum
@@ -249,7 +266,7 @@ def test_edge_8psk_bursts(trx):
         g_res, g_soft = run_gpu(trx, iq, params, 4, soft_stride=444, slice_bits=slice_bits, exact=True)
         check_parity(g_res, g_soft, o_res, o_soft)
         f_res, f_soft = run_gpu(trx, iq, params, 4, soft_stride=444, slice_bits=slice_bits, exact=False)
-        check_parity(f_res, f_soft, o_res, o_soft, soft_atol=5e-5)     # equaliser gain ~2 on top of the fused demod
+        check_parity(f_res, f_soft, o_res, o_soft, soft_atol=FUSED_SOFT_ATOL_8PSK)     # equaliser gain ~2 on top of the fused demod
     det = o_res["rc"] == O.EDGE
     mid = 0.5
     assert ((g_soft[det] > mid).astype(np.uint8) != bits[det]).mean() < 0.03    # static equaliser: ~1 % raw BER
@@ -323,7 +340,7 @@ def test_fuzz_against_oracle(trx, L, soft_stride):
         g_res, g_soft = run_gpu(trx, iq, params, 4, soft_stride=soft_stride, slice_bits=slice_bits, exact=True)
         check_parity(g_res, g_soft, o_res, o_soft)
         f_res, f_soft = run_gpu(trx, iq, params, 4, soft_stride=soft_stride, slice_bits=slice_bits, exact=False)
-        check_parity(f_res, f_soft, o_res, o_soft, soft_atol=5e-5)
+        check_parity(f_res, f_soft, o_res, o_soft, soft_atol=FUSED_SOFT_ATOL_8PSK)
 
 
 def test_no_soft_output_pointer(trx):

@@ -1,0 +1,109 @@
+"""Sharded == unsharded on the HIP path, and bench.py's N > 1 code path executed.
+
+A 1-GPU box is enough: two fresh processes, both on cuda:0, rendezvous over gloo (RCCL refuses two ranks on one device;
+gloo carries the same device tensors through the host), each runs  broadcast_tables -> TrxHip(tables_blob=...) ->
+detect_demod  on ITS shard_range() of one seeded 65536-burst mixed batch (normal + access bursts), generated shard-wise
+with synth.make_mixed_bursts(offset=...).  The concatenation of the two ranks' result records and soft bits must equal
+the single-process result bit for bit; max_over_ranks / sum_over_ranks / barrier run on device tensors.  Then bench.py
+itself is launched the way the driver launches it for N = 2 (torch.distributed.run) with both ranks on cuda:0."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+N = 65536
+CHUNK = 4096            # 8 * CHUNK divides N / 2: both shards start on chunk boundaries of both generators
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from osmo_trx_amd import TrxHip, shard, synth
+N, CHUNK, out = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+rank, _, world = shard.init_distributed("gloo")
+dev = "cuda:0"
+torch.cuda.set_device(0)
+blob = shard.broadcast_tables(dev)                                   # device tensors through the collective
+trx = TrxHip(0, tables_blob=blob)
+lo, hi = shard.shard_range(N, rank, world)
+iq, params = synth.make_mixed_bursts(hi - lo, dev, seed=1234, chunk=CHUNK, offset=lo)
+res, soft = trx.detect_demod(iq, trx.params_tensor(params), sps=4, soft_stride=148, slice_bits=True)
+torch.cuda.synchronize()
+shard.barrier()
+tot = shard.sum_over_ranks(hi - lo, dev)
+mx = shard.max_over_ranks(float(rank + 1), dev)
+det = shard.sum_over_ranks(int((trx.results_to_numpy(res)["rc"] > 0).sum()), dev)
+np.savez(out + f".{rank}.npz", res=res.cpu().numpy(), soft=soft.cpu().numpy(), lo=lo, hi=hi, tot=tot, mx=mx, det=det)
+dist.destroy_process_group()
+'''
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_shards_on_the_gpu_equal_the_unsharded_batch(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from osmo_trx_amd import TrxHip, synth
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(N), str(CHUNK), str(tmp_path / "shard")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        o, e = p.communicate(timeout=600)
+        assert p.returncode == 0, e[-3000:]
+    parts = [np.load(str(tmp_path / f"shard.{r}.npz")) for r in range(2)]
+    assert int(parts[0]["lo"]) == 0 and int(parts[0]["hi"]) == int(parts[1]["lo"]) == N // 2 and int(parts[1]["hi"]) == N
+    assert float(parts[0]["tot"]) == float(parts[1]["tot"]) == N and float(parts[0]["mx"]) == float(parts[1]["mx"]) == 2.0
+    # the same batch in one process, one launch
+    trx = TrxHip(0)
+    iq, params = synth.make_mixed_bursts(N, "cuda:0", seed=1234, chunk=CHUNK)
+    res, soft = trx.detect_demod(iq, trx.params_tensor(params), sps=4, soft_stride=148, slice_bits=True)
+    torch.cuda.synchronize()
+    res, soft = res.cpu().numpy(), soft.cpu().numpy()
+    assert np.array_equal(np.concatenate([parts[0]["res"], parts[1]["res"]]), res)          # 32-byte records, bit for bit
+    assert np.array_equal(np.concatenate([parts[0]["soft"], parts[1]["soft"]]).view(np.uint32), soft.view(np.uint32))
+    r = trx.results_to_numpy(torch.from_numpy(res))
+    det = int((r["rc"] > 0).sum())
+    assert float(parts[0]["det"]) == det and det > 0.8 * N
+    assert ((r["rc"] == 3) | (r["rc"] == 1)).sum() == det                                   # normal and access bursts both found
+
+
+def test_bench_py_two_ranks_code_path(tmp_path):
+    """bench.py --gpus 2 launched as the driver launches it (torch.distributed.run, one process per rank), both ranks on
+    cuda:0 over gloo: the N > 1 branch -- device-tensor broadcast of the tables, barriers, max-over-ranks timing, the
+    weak-scaling value and the strong-scaling configs[4] leg on shard_range() -- runs end to end."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, TRXHIP_DIST_BACKEND="gloo", TRXHIP_ONE_DEVICE="1", TRXHIP_BENCH_STRONG_TOTAL=str(1 << 20))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--bursts", str(1 << 16), "--no-host-fed", "--legs", "strong"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(line) == 1, r.stdout[-2000:]                      # rank 0 alone prints
+    j = json.loads(line[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["scaling"] == "weak"
+    assert j["config"]["global_bursts"] == 2 << 16 and 0.9 < j["config"]["detected_fraction"] < 1.0
+    assert j["value"] > 0 and j["roofline"]["kernel_ms"] > 0 and "cpu_baseline" not in j
+    s = j["config"]["other_configs"]["configs[4]_strong"]
+    assert s["scaling"] == "strong" and s["global_bursts"] == 1 << 20 and s["bursts_this_rank"] == 1 << 19
+    assert 0.85 < s["detected_fraction"] < 1.0

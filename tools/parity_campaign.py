@@ -8,7 +8,7 @@ sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import numpy as np
 import oracle_lib as O
 from osmo_trx_amd import TrxHip, synth
-from test_gpu_parity import run_gpu, check_parity, FUSED_SOFT_ATOL
+from test_gpu_parity import run_gpu, check_parity, FUSED_SOFT_ATOL, FUSED_SOFT_ATOL_8PSK
 
 n_nb = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 19
 n_ab = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 17
@@ -22,19 +22,12 @@ for name, (iq, params) in (("normal, max_toa 3", synth.make_normal_bursts(n_nb, 
     g_res, g_soft = run_gpu(trx, iq, params, 4, exact=True)
     check_parity(g_res, g_soft, o_res, o_soft)
     f_res, f_soft = run_gpu(trx, iq, params, 4, exact=False)
-    # The fused demodulator's error is relative to the SAMPLES, the soft bits are relative to the amplitude estimate: on a
-    # noise slot that passes the detector at C/I -20 dB the scaled samples are ~25x full scale and so is the error.  Bar:
-    # 1e-5 of full scale where the burst's RMS is within 4x of |amp| (every real detection), 1e-5 x RMS / (4 |amp|) beyond.
-    amp = np.hypot(o_res["amp_re"], o_res["amp_im"])
-    ratio = np.where(amp > 0, np.sqrt(o_res["energy"]) / np.maximum(amp, 1e-30), 1.0)
-    bar = FUSED_SOFT_ATOL * np.maximum(1.0, ratio / 4.0)
+    # both clauses of the tolerance statement (include/trxhip.h) are check_parity's: 1e-5 of full scale where the burst's RMS
+    # is within 4x of |amp| (every real detection), 1e-5 x RMS / (4 |amp|) beyond (noise slots detected at C/I < -12 dB)
+    check_parity(f_res, f_soft, o_res, o_soft, soft_atol=FUSED_SOFT_ATOL)
     err = np.abs(f_soft - o_soft)
-    assert (err <= bar[:, None]).all(), (name, float(err.max()))
     worst = float(err.max())
     n_over = int((err > FUSED_SOFT_ATOL).sum())
-    ok = bar <= FUSED_SOFT_ATOL
-    check_parity(f_res[ok], f_soft[ok], o_res[ok], o_soft[ok], soft_atol=FUSED_SOFT_ATOL)
-    check_parity(f_res, f_soft, o_res, o_soft, soft_atol=1.0)          # records + hard decisions where they are certain
     print(f"{name:22s} {len(params):8d} bursts, {int((o_res['rc'] > 0).sum()):8d} detected: bit-exact (exact) / fused max {worst:.2e}, "
           f"{n_over} of {err.size} values above {FUSED_SOFT_ATOL:g} (noise slots detected at C/I < -12 dB)  [{time.time() - t0:.0f} s]", flush=True)
 
@@ -44,7 +37,7 @@ o_res, o_soft = O.pull_batch(iq.numpy(), 4, params, soft_stride=444, slice_bits=
 g_res, g_soft = run_gpu(trx, iq, params, 4, soft_stride=444, slice_bits=False, exact=True)
 check_parity(g_res, g_soft, o_res, o_soft)
 f_res, f_soft = run_gpu(trx, iq, params, 4, soft_stride=444, slice_bits=False, exact=False)
-check_parity(f_res, f_soft, o_res, o_soft, soft_atol=5e-5)
+check_parity(f_res, f_soft, o_res, o_soft, soft_atol=FUSED_SOFT_ATOL_8PSK)
 print(f"{'EDGE 8-PSK':22s} {len(params):8d} bursts, {int((o_res['rc'] > 0).sum()):8d} detected: bit-exact (exact) / <= 5e-05 (fused)", flush=True)
 for bl in (156, 157):
     iq, params, _ = synth.make_normal_bursts(1 << 16, "cpu", 1, seed=0xCA16 + bl, burst_len=bl, delay_sym=(0, 3))
