@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TRXHIP_ABI_VERSION 2
+#define TRXHIP_ABI_VERSION 3
 
 /* error codes */
 #define TRXHIP_OK          0
@@ -149,6 +149,20 @@ int trxhip_detect_demod_batch(trxhip_ctx *ctx,
 			      size_t n_bursts, int burst_len, int sps,
 			      float threshold, float full_scale,
 			      int soft_stride, int flags, void *stream);
+
+/* Diversity-path selection in front of the hot path (Transceiver.cpp:723-741): every burst arrives on n_paths receive
+ * paths (radioVector::chans()); pullRadioVector() measures energyDetect(path, 20*sps) on each, demodulates the FIRST path
+ * with the highest energy and reports rssi / noise from avg = sqrt(sum of the path energies / n_paths).
+ *   d_iq_paths   : n_bursts x n_paths x burst_len x 2 int16 (the paths of one burst back to back), 4-byte aligned
+ *   d_iq_sel     : n_bursts x burst_len x 2 int16: the chosen path of every burst -> trxhip_detect_demod_batch()
+ *   d_avg_energy : n_bursts floats, sum_i pow_i / n_paths (= avg^2)
+ *   d_path       : n_bursts chosen path indices (may be NULL)
+ * trxhip_apply_diversity_power() then writes energy = avg^2 and rssi = 20*log10(full_scale / avg) into the result records
+ * of the detect/demod launch over d_iq_sel (slots that are OFF keep their zeros).  1 <= n_paths <= 8. */
+int trxhip_select_diversity_batch(trxhip_ctx *ctx, const int16_t *d_iq_paths, size_t n_bursts, int n_paths, int burst_len, int sps,
+				  int16_t *d_iq_sel, float *d_avg_energy, uint8_t *d_path, void *stream);
+int trxhip_apply_diversity_power(trxhip_ctx *ctx, trxhip_burst_result *d_results, const trxhip_burst_params *d_params,
+				 const float *d_avg_energy, size_t n_bursts, float full_scale, void *stream);
 
 /* Same, from complex64 device samples (the form sigProcLib's detectAnyBurst()/demodAnyBurst() take). */
 int trxhip_detect_demod_batch_cf32(trxhip_ctx *ctx,
@@ -274,9 +288,12 @@ typedef struct trxhip_hostpipe_cfg {
 	float    threshold;    /* TRXHIP_BURST_THRESH */
 	float    full_scale;
 	float    rssi_offset;  /* enters the TRXD rssi byte only; result.rssi stays without it */
+	int32_t  n_paths;      /* diversity paths per burst (0 or 1: none).  > 1: a slot's iq holds max_bursts x n_paths x burst_len
+	                        * samples, every submit runs trxhip_select_diversity_batch() first and
+	                        * trxhip_apply_diversity_power() behind the detector (Transceiver.cpp:723-751) */
 } trxhip_hostpipe_cfg;
 typedef struct trxhip_hostpipe_slot {      /* pinned host memory, valid until trxhip_hostpipe_destroy() */
-	int16_t             *iq;       /* in : max_bursts x burst_len x 2 */
+	int16_t             *iq;       /* in : max_bursts x [n_paths x] burst_len x 2 */
 	trxhip_burst_params *params;   /* in : max_bursts */
 	trxhip_trxd_meta    *meta;     /* in : max_bursts (NULL without TRXD packing) */
 	trxhip_burst_result *results;  /* out: max_bursts */
@@ -340,6 +357,14 @@ typedef struct trxhip_rx_frontend trxhip_rx_frontend;
 int  trxhip_rx_frontend_create(trxhip_ctx *ctx, int block_len, int p, int q, trxhip_rx_frontend **out);
 void trxhip_rx_frontend_destroy(trxhip_rx_frontend *f);
 int  trxhip_rx_frontend_reset(trxhip_rx_frontend *f, void *stream);           /* zero the carried history */
+/* Start mid-stream (a stream is sharded in time, one shard per GPU, with overlap at the shard edges): make the
+ * carried state what it would be had the stream been processed up to the shard's first block.  d_wide_prev = the
+ * n_blocks_prev >= 1 blocks (n_blocks_prev * block_len * 4 wideband int16 IQ samples, 16-byte aligned) that immediately
+ * precede the shard; one block is enough, because both filters are FIR -- the channelizer carries 15 time steps
+ * (Channelizer::hist, Channelizer.cpp:86-88), the resampler 15 channel samples (history[lchan],
+ * radioInterfaceMulti.cpp:283-300).  The shard's output is then bit-identical to the same blocks' output of an unsharded
+ * run.  n_blocks_prev = 0 (stream start) is trxhip_rx_frontend_reset(). */
+int  trxhip_rx_frontend_seed(trxhip_rx_frontend *f, const int16_t *d_wide_prev, size_t n_blocks_prev, void *stream);
 /* d_wide: n_blocks * block_len * 4 wideband int16 IQ samples (16-byte aligned);
  * d_out : 4 channels x (n_blocks*block_len*p/q) complex64, channel c at d_out + 2*c*out_stride floats */
 int  trxhip_rx_frontend_pull(trxhip_rx_frontend *f, const int16_t *d_wide, size_t n_blocks, float *d_out,

@@ -1165,6 +1165,46 @@ void orc_pull_batch(const int16_t *iq, size_t n_bursts, int burst_len, int sps,
 	free(burst);
 }
 
+/* ----------------------------------------------------------------------------------------
+ * pullRadioVector() with diversity paths (Transceiver.cpp:669-671, :723-751): the burst arrives on n_paths receive
+ * paths; each path's energy is measured, the first path with the highest energy is the one detected and demodulated,
+ * and the power levels come from the path average:
+ *     float max = -1.0, avg = 0.0; int max_i = -1;
+ *     for (i < chans()) { pow = energyDetect(path i, 20 * sps); if (pow > max) { max = pow; max_i = i; } avg += pow; }
+ *     avg = sqrt(avg / chans());   rssi = 20 log10(rxFullScale / avg)
+ * iq: n_bursts x n_paths x burst_len x 2 int16.  res[b].energy = avg * avg's argument (sum pow / chans), path[b] = max_i.
+ * ---------------------------------------------------------------------------------------- */
+void orc_pull_batch_div(const int16_t *iq, size_t n_bursts, int n_paths, int burst_len, int sps,
+			const orc_burst_params *params, float threshold, double full_scale,
+			orc_burst_result *res, float *soft, int soft_stride, int slice, uint8_t *path)
+{
+	orc_cf *burst = malloc((size_t)burst_len * sizeof(orc_cf));
+	for (size_t b = 0; b < n_bursts; b++) {
+		const int16_t *paths = &iq[b * (size_t)n_paths * burst_len * 2];
+		float max = -1.0f, avg = 0.0f;
+		int max_i = -1;
+		for (int i = 0; i < n_paths; i++) {
+			orc_convert_short_float((float *)burst, &paths[(size_t)i * burst_len * 2], burst_len * 2);
+			float pow = orc_energy_detect(burst, burst_len, 20 * sps);
+			if (pow > max) {
+				max = pow;
+				max_i = i;
+			}
+			avg += pow;
+		}
+		if (max_i < 0) max_i = 0;                         /* "Received empty burst": not reachable with finite samples */
+		if (path) path[b] = (uint8_t)max_i;
+		orc_pull_batch(&paths[(size_t)max_i * burst_len * 2], 1, burst_len, sps, &params[b], threshold, full_scale,
+			       &res[b], soft ? &soft[b * (size_t)soft_stride] : NULL, soft_stride, slice);
+		if (params[b].type == ORC_OFF)
+			continue;
+		res[b].energy = avg / (float)n_paths;
+		avg = sqrtf(avg / (float)n_paths);                /* :741 */
+		res[b].rssi = (float)(20.0 * log10(full_scale / avg));   /* :751 without rssi_offset */
+	}
+	free(burst);
+}
+
 /* proto_trxd.c:36-45 */
 int orc_trxd_toa256(double toa)
 {

@@ -139,6 +139,10 @@ typedef struct {
 void orc_pull_batch(const int16_t *iq, size_t n_bursts, int burst_len, int sps,
 		    const orc_burst_params *params, float threshold, double full_scale,
 		    orc_burst_result *res, float *soft, int soft_stride, int slice);
+/* the same with n_paths diversity paths per burst (Transceiver.cpp:723-751): iq is n_bursts x n_paths x burst_len x 2 */
+void orc_pull_batch_div(const int16_t *iq, size_t n_bursts, int n_paths, int burst_len, int sps,
+			const orc_burst_params *params, float threshold, double full_scale,
+			orc_burst_result *res, float *soft, int soft_stride, int slice, uint8_t *path);
 
 /* Viterbi alternative (cfg->use_va): Transceiver.cpp:620-645, :782-784 over grgsm_vitac/ */
 int   orc_demod_any_burst_va(const orc_cf *burst, int n, int type, int tsc, int max_toa, float scale, float *soft);

@@ -684,6 +684,94 @@ extern "C" int trx_launch_energy_detect(const float *d_x, size_t n_bursts, int b
 	return hipGetLastError() == hipSuccess ? 0 : TRXHIP_EIO;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Diversity-path selection of pullRadioVector() (Transceiver.cpp:723-741): a burst arrives on n_paths receive paths;
+//   for each path i: pow = energyDetect(path i, 20 * sps); the FIRST path with the highest energy is demodulated
+//   ("if (pow > max)" from max = -1, path order); avg += pow;  avg = sqrt(avg / chans) feeds rssi and the noise average.
+// The selection is a decision, so each path's energy is the reference's serial sum (:1573-1585: energy += norm2 in
+// sample order, one division) evaluated by one lane per path; then the whole wave copies the chosen path into the compact
+// [n][burst_len] array the detector reads.  One wave per burst.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+diversity_select_kernel(const uint32_t *__restrict__ iq_paths, size_t n_bursts, int n_paths, int burst_len, unsigned window,
+			uint32_t *__restrict__ iq_sel, float *__restrict__ avg_energy, uint8_t *__restrict__ path_out)
+{
+	const int lane = threadIdx.x & 63;
+	const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
+	const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+	if (window > (unsigned)burst_len) window = burst_len;
+	for (size_t b = wave; b < n_bursts; b += nwaves) {
+		const uint32_t *src = iq_paths + b * (size_t)n_paths * burst_len;
+		float pow = 0.0f;
+		if (lane < n_paths) {
+			const uint32_t *x = src + (size_t)lane * burst_len;
+			float e = 0.0f;
+			for (unsigned i = 0; i < window; i++) {
+				const uint32_t w = x[4 * (size_t)i];
+				const float re = (float)(int16_t)(w & 0xffffu), im = (float)(int16_t)(w >> 16);
+				e += im * im + re * re;                                 /* Complex.h:113 norm2(): i*i + r*r */
+			}
+			pow = window ? e / (float)window : 0.0f;
+		}
+		float mx = -1.0f, avg = 0.0f;
+		int sel = -1;
+		for (int i = 0; i < n_paths; i++) {                                 /* wave-uniform: readlane per path */
+			const float pi = __shfl(pow, i, 64);
+			if (pi > mx) { mx = pi; sel = i; }
+			avg += pi;
+		}
+		if (sel < 0) sel = 0;                                                   /* (cannot happen for finite input: pow >= 0 > -1) */
+		const uint32_t *from = src + (size_t)sel * burst_len;
+		uint32_t *to = iq_sel + b * (size_t)burst_len;
+		for (int i = lane; i < burst_len; i += 64)
+			to[i] = from[i];
+		if (lane == 0) {
+			avg_energy[b] = avg / (float)n_paths;                           /* avg^2 of Transceiver.cpp:741 */
+			if (path_out) path_out[b] = (uint8_t)sel;
+		}
+	}
+}
+
+// result records of a detect/demod launch over the selected paths: energy and rssi from the path average
+// (Transceiver.cpp:741,751: avg = sqrt(sum pow / chans); rssi = 20 log10(rxFullScale / avg)); OFF slots keep their zeros
+__global__ void __launch_bounds__(256)
+diversity_power_kernel(trxhip_burst_result *__restrict__ res, const trxhip_burst_params *__restrict__ params,
+		       const float *__restrict__ avg_energy, size_t n_bursts, float full_scale)
+{
+	for (size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x; b < n_bursts; b += (size_t)gridDim.x * blockDim.x) {
+		if (params[b].type == TRXHIP_OFF)
+			continue;
+		const float e = avg_energy[b];
+		res[b].energy = e;
+		res[b].rssi = 6.02059991f * __log2f(full_scale) - 3.01029996f * __log2f(e);
+	}
+}
+
+extern "C" int trx_launch_diversity_select(const int16_t *d_iq_paths, size_t n_bursts, int n_paths, int burst_len, int sps,
+					   int16_t *d_iq_sel, float *d_avg_energy, uint8_t *d_path, hipStream_t stream)
+{
+	if (n_bursts == 0)
+		return 0;
+	size_t blocks = (n_bursts + 3) / 4;
+	if (blocks > 4096) blocks = 4096;
+	hipLaunchKernelGGL(diversity_select_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
+			   reinterpret_cast<const uint32_t *>(d_iq_paths), n_bursts, n_paths, burst_len, (unsigned)(20 * sps),
+			   reinterpret_cast<uint32_t *>(d_iq_sel), d_avg_energy, d_path);
+	return hipGetLastError() == hipSuccess ? 0 : TRXHIP_EIO;
+}
+
+extern "C" int trx_launch_diversity_power(trxhip_burst_result *d_res, const trxhip_burst_params *d_params, const float *d_avg_energy,
+					  size_t n_bursts, float full_scale, hipStream_t stream)
+{
+	if (n_bursts == 0)
+		return 0;
+	size_t blocks = (n_bursts + 255) / 256;
+	if (blocks > 2048) blocks = 2048;
+	hipLaunchKernelGGL(diversity_power_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d_res, d_params, d_avg_energy,
+			   n_bursts, full_scale);
+	return hipGetLastError() == hipSuccess ? 0 : TRXHIP_EIO;
+}
+
 // vectorSlicer() (sigProcLib.cpp:546-556): dest = clamp(0.5 * (src + 1), 0, 1)
 __global__ void __launch_bounds__(256)
 vector_slicer_kernel(float *__restrict__ dst, const float *__restrict__ src, size_t len)

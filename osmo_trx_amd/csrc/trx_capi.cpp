@@ -199,6 +199,41 @@ static int pull_common(trxhip_ctx *ctx, const void *d_iq, int cf32, const trxhip
 			       threshold, full_scale, soft_stride, flags, ctx->n_cu, static_cast<hipStream_t>(stream));
 }
 
+extern "C" int trx_launch_diversity_select(const int16_t *d_iq_paths, size_t n_bursts, int n_paths, int burst_len, int sps,
+					   int16_t *d_iq_sel, float *d_avg_energy, uint8_t *d_path, hipStream_t stream);
+extern "C" int trx_launch_diversity_power(trxhip_burst_result *d_res, const trxhip_burst_params *d_params, const float *d_avg_energy,
+					  size_t n_bursts, float full_scale, hipStream_t stream);
+
+int trxhip_select_diversity_batch(trxhip_ctx *ctx, const int16_t *d_iq_paths, size_t n_bursts, int n_paths, int burst_len, int sps,
+				  int16_t *d_iq_sel, float *d_avg_energy, uint8_t *d_path, void *stream)
+{
+	if (!ctx || n_paths < 1 || n_paths > 8 || (sps != 1 && sps != 4) || burst_len < 1 || burst_len > TRXHIP_MAX_BURST_LEN)
+		return TRXHIP_EINVAL;
+	if (n_bursts == 0)
+		return TRXHIP_OK;
+	if (!d_iq_paths || !d_iq_sel || !d_avg_energy || (reinterpret_cast<uintptr_t>(d_iq_paths) & 3) ||
+	    (reinterpret_cast<uintptr_t>(d_iq_sel) & 3))
+		return TRXHIP_EINVAL;
+	if (with_device(ctx))
+		return TRXHIP_EIO;
+	return trx_launch_diversity_select(d_iq_paths, n_bursts, n_paths, burst_len, sps, d_iq_sel, d_avg_energy, d_path,
+					   static_cast<hipStream_t>(stream));
+}
+
+int trxhip_apply_diversity_power(trxhip_ctx *ctx, trxhip_burst_result *d_results, const trxhip_burst_params *d_params,
+				 const float *d_avg_energy, size_t n_bursts, float full_scale, void *stream)
+{
+	if (!ctx || !(full_scale > 0.0f))
+		return TRXHIP_EINVAL;
+	if (n_bursts == 0)
+		return TRXHIP_OK;
+	if (!d_results || !d_params || !d_avg_energy)
+		return TRXHIP_EINVAL;
+	if (with_device(ctx))
+		return TRXHIP_EIO;
+	return trx_launch_diversity_power(d_results, d_params, d_avg_energy, n_bursts, full_scale, static_cast<hipStream_t>(stream));
+}
+
 int trxhip_detect_demod_batch(trxhip_ctx *ctx, const int16_t *d_iq, const trxhip_burst_params *d_params,
 			      trxhip_burst_result *d_results, float *d_soft, size_t n_bursts, int burst_len, int sps,
 			      float threshold, float full_scale, int soft_stride, int flags, void *stream)
@@ -491,6 +526,28 @@ int trxhip_rx_frontend_reset(trxhip_rx_frontend *f, void *stream)
 	    hipMemsetAsync(f->d_chan_hist, 0, 4 * 16 * 8, static_cast<hipStream_t>(stream)) != hipSuccess)
 		return TRXHIP_EIO;
 	return TRXHIP_OK;
+}
+
+int trxhip_rx_frontend_seed(trxhip_rx_frontend *f, const int16_t *d_wide_prev, size_t n_blocks_prev, void *stream)
+{
+	if (!f)
+		return TRXHIP_EINVAL;
+	int rc = trxhip_rx_frontend_reset(f, stream);
+	if (rc || n_blocks_prev == 0)
+		return rc;
+	if (!d_wide_prev)
+		return TRXHIP_EINVAL;
+	/* run the preceding blocks through the very same two launches (their output is discarded): what they leave in
+	 * d_wide_hist / d_chan_hist is the state of a stream processed up to here */
+	const size_t n_out = n_blocks_prev * (size_t)f->block_len / f->q * f->p;
+	float *scratch = nullptr;
+	if (hipMalloc((void **)&scratch, 4 * n_out * 8) != hipSuccess)
+		return TRXHIP_ENOMEM;
+	rc = trxhip_rx_frontend_pull(f, d_wide_prev, n_blocks_prev, scratch, n_out, stream);
+	if (hipStreamSynchronize(static_cast<hipStream_t>(stream)) != hipSuccess && rc == TRXHIP_OK)
+		rc = TRXHIP_EIO;
+	(void)hipFree(scratch);
+	return rc;
 }
 
 int trxhip_rx_frontend_pull(trxhip_rx_frontend *f, const int16_t *d_wide, size_t n_blocks, float *d_out,

@@ -86,7 +86,13 @@ static __device__ unsigned long long g_trx_diag[TRX_DIAG_WAVES * 24];   // per w
 		}                                                                               \
 	} while (0)
 #else
+// tools/pmc_phase_r03.sh: per-phase instruction counts of the PRODUCT kernel (the COMMON instantiation takes no run-time
+// flags) come from measurement builds with a compile-time ablation mask; the product library is built without it
+#ifdef TRX_ABL_MASK
+#define ABL(bit) ((TRX_ABL_MASK >> (bit)) & 1)
+#else
 #define ABL(bit) 0
+#endif
 #define DIAG_DECL
 #define DIAG_ARG
 #define DIAG_PASS

@@ -23,6 +23,8 @@ struct trxhip_hostpipe {
 		size_t n;
 		trxhip_hostpipe_slot h;        /* pinned host */
 		int16_t *d_iq;
+		int16_t *d_iq_sel;             /* n_paths > 1: the chosen path of every burst */
+		float *d_avg;                  /* n_paths > 1: path-averaged energy */
 		trxhip_burst_params *d_params;
 		trxhip_trxd_meta *d_meta;
 		trxhip_burst_result *d_results;
@@ -51,6 +53,8 @@ int trxhip_hostpipe_create(trxhip_ctx *ctx, const trxhip_hostpipe_cfg *c, trxhip
 		return TRXHIP_EINVAL;
 	if (c->soft_stride == 0 && c->pkt_stride == 0)
 		return TRXHIP_EINVAL;
+	if (c->n_paths < 0 || c->n_paths > 8)
+		return TRXHIP_EINVAL;
 	if (with_device(ctx))
 		return TRXHIP_EIO;
 
@@ -65,14 +69,16 @@ int trxhip_hostpipe_create(trxhip_ctx *ctx, const trxhip_hostpipe_cfg *c, trxhip
 	/* device rows: what the caller downloads, or -- TRXD only -- what the packer can consume */
 	p->dev_soft_stride = c->soft_stride ? c->soft_stride : (c->pkt_stride >= TRXHIP_TRXD_V1_HDR + 444 ? 444 : 148);
 	const size_t nb = c->max_bursts;
+	const size_t np = c->n_paths > 1 ? (size_t)c->n_paths : 1;
 	bool ok = true;
 	for (int s = 0; s < c->depth && ok; s++) {
 		trxhip_hostpipe::Slot &sl = p->slot[s];
 		ok = hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) == hipSuccess &&
 		     hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) == hipSuccess &&
-		     pin((void **)&sl.h.iq, nb * c->burst_len * 4) && pin((void **)&sl.h.params, nb * sizeof(trxhip_burst_params)) &&
+		     pin((void **)&sl.h.iq, nb * np * c->burst_len * 4) && pin((void **)&sl.h.params, nb * sizeof(trxhip_burst_params)) &&
 		     pin((void **)&sl.h.results, nb * sizeof(trxhip_burst_result)) &&
-		     dev((void **)&sl.d_iq, nb * c->burst_len * 4) && dev((void **)&sl.d_params, nb * sizeof(trxhip_burst_params)) &&
+		     dev((void **)&sl.d_iq, nb * np * c->burst_len * 4) && dev((void **)&sl.d_params, nb * sizeof(trxhip_burst_params)) &&
+		     (np == 1 || (dev((void **)&sl.d_iq_sel, nb * c->burst_len * 4) && dev((void **)&sl.d_avg, nb * sizeof(float)))) &&
 		     dev((void **)&sl.d_results, nb * sizeof(trxhip_burst_result)) &&
 		     dev((void **)&sl.d_soft, nb * p->dev_soft_stride * sizeof(float));
 		if (ok && c->soft_stride)
@@ -100,7 +106,7 @@ void trxhip_hostpipe_destroy(trxhip_hostpipe *p)
 		if (sl.stream) (void)hipStreamSynchronize(sl.stream);
 		void *hp[] = { sl.h.iq, sl.h.params, sl.h.meta, sl.h.results, sl.h.soft, sl.h.pkt, sl.h.pkt_len };
 		for (void *q : hp) if (q) (void)hipHostFree(q);
-		void *dp[] = { sl.d_iq, sl.d_params, sl.d_meta, sl.d_results, sl.d_soft, sl.d_pkt, sl.d_pkt_len };
+		void *dp[] = { sl.d_iq, sl.d_iq_sel, sl.d_avg, sl.d_params, sl.d_meta, sl.d_results, sl.d_soft, sl.d_pkt, sl.d_pkt_len };
 		for (void *q : dp) if (q) (void)hipFree(q);
 		if (sl.done) (void)hipEventDestroy(sl.done);
 		if (sl.stream) (void)hipStreamDestroy(sl.stream);
@@ -141,13 +147,22 @@ int trxhip_hostpipe_submit(trxhip_hostpipe *p, int slot, size_t n)
 	if (with_device(p->ctx))
 		return TRXHIP_EIO;
 	hipStream_t st = sl.stream;
-	bool ok = hipMemcpyAsync(sl.d_iq, sl.h.iq, n * c.burst_len * 4, hipMemcpyHostToDevice, st) == hipSuccess &&
+	const size_t np = c.n_paths > 1 ? (size_t)c.n_paths : 1;
+	bool ok = hipMemcpyAsync(sl.d_iq, sl.h.iq, n * np * c.burst_len * 4, hipMemcpyHostToDevice, st) == hipSuccess &&
 		  hipMemcpyAsync(sl.d_params, sl.h.params, n * sizeof(trxhip_burst_params), hipMemcpyHostToDevice, st) == hipSuccess;
 	if (ok && c.pkt_stride)
 		ok = hipMemcpyAsync(sl.d_meta, sl.h.meta, n * sizeof(trxhip_trxd_meta), hipMemcpyHostToDevice, st) == hipSuccess;
-	int rc = ok ? trxhip_detect_demod_batch(p->ctx, sl.d_iq, sl.d_params, sl.d_results, sl.d_soft, n, c.burst_len, c.sps,
-						c.threshold, c.full_scale, p->dev_soft_stride, c.flags, st)
-		    : TRXHIP_EIO;
+	int rc = ok ? TRXHIP_OK : TRXHIP_EIO;
+	const int16_t *d_bursts = sl.d_iq;
+	if (rc == TRXHIP_OK && np > 1) {                              /* Transceiver.cpp:723-741: the path with the highest energy */
+		rc = trxhip_select_diversity_batch(p->ctx, sl.d_iq, n, (int)np, c.burst_len, c.sps, sl.d_iq_sel, sl.d_avg, nullptr, st);
+		d_bursts = sl.d_iq_sel;
+	}
+	if (rc == TRXHIP_OK)
+		rc = trxhip_detect_demod_batch(p->ctx, d_bursts, sl.d_params, sl.d_results, sl.d_soft, n, c.burst_len, c.sps,
+					       c.threshold, c.full_scale, p->dev_soft_stride, c.flags, st);
+	if (rc == TRXHIP_OK && np > 1)                                /* :741, :751: rssi from the path average */
+		rc = trxhip_apply_diversity_power(p->ctx, sl.d_results, sl.d_params, sl.d_avg, n, c.full_scale, st);
 	if (rc == TRXHIP_OK && c.pkt_stride)
 		rc = trxhip_pack_trxd_wire_batch(p->ctx, sl.d_results, sl.d_params, sl.d_soft, p->dev_soft_stride, sl.d_meta, sl.d_pkt,
 						 c.pkt_stride, sl.d_pkt_len, n, c.rssi_offset, st);
@@ -200,7 +215,7 @@ int trxhip_hostpipe_run(trxhip_hostpipe *p, const int16_t *h_iq, const trxhip_bu
 	for (int s = 0; s < c.depth; s++)
 		if (p->slot[s].busy)
 			return TRXHIP_EINVAL;
-	const size_t chunk = c.max_bursts, burst_bytes = (size_t)c.burst_len * 4;
+	const size_t chunk = c.max_bursts, burst_bytes = (size_t)c.burst_len * 4 * (c.n_paths > 1 ? (size_t)c.n_paths : 1);
 	const size_t n_chunks = (n + chunk - 1) / chunk;
 	int rc = TRXHIP_OK;
 	/* chunk k uses slot k % depth: stage k, submit k, then collect chunk k - depth + 1 (oldest in flight) */
@@ -221,7 +236,7 @@ int trxhip_hostpipe_run(trxhip_hostpipe *p, const int16_t *h_iq, const trxhip_bu
 		const int s = (int)(k % c.depth);
 		const size_t off = k * chunk, m = (off + chunk <= n) ? chunk : n - off;
 		const trxhip_hostpipe_slot &h = p->slot[s].h;
-		memcpy(h.iq, h_iq + off * c.burst_len * 2, m * burst_bytes);
+		memcpy(h.iq, reinterpret_cast<const char *>(h_iq) + off * burst_bytes, m * burst_bytes);
 		memcpy(h.params, h_params + off, m * sizeof(trxhip_burst_params));
 		if (c.pkt_stride) memcpy(h.meta, h_meta + off, m * sizeof(trxhip_trxd_meta));
 		const int r = trxhip_hostpipe_submit(p, s, m);

@@ -581,7 +581,8 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 			const int c = -16 - w;                                      // tap u = 8 of output i reads sample 4i + c
 			const PhBase pb = ph_bases(P, c & 3, ic + (c >> 2));
 			v2f acc[3] = { { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f } };
-			fir24x3(pb, reinterpret_cast<const float4 *>(tp), acc);
+			if (!ABL(5))
+				fir24x3(pb, reinterpret_cast<const float4 *>(tp), acc);
 			// low-edge outputs: main part (lane 52 + i) + taps u < 8 (lane 56 + i), row_shl:4 inside the last row of 16
 			float er = acc[0].x, ei = acc[0].y;
 			asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0xf\n\t"

@@ -325,6 +325,9 @@ bool BurstGatherer::start()
 	c.threshold = BURST_THRESH;
 	c.full_scale = (float)m.cfg.rxFullScale;
 	c.rssi_offset = (float)m.cfg.rssi_offset;
+	if (m.cfg.n_paths < 0 || m.cfg.n_paths > 8)
+		return false;
+	c.n_paths = m.cfg.n_paths > 1 ? m.cfg.n_paths : 0;
 	if (m.pipe) {                                                  /* restart: the previous run's staging slots, streams, events */
 		trxhip_hostpipe_destroy(m.pipe);
 		m.pipe = nullptr;
@@ -483,7 +486,8 @@ size_t BurstGatherer::pushSlot(const size_t *chans, const BurstRequest *rqs, siz
 			r.tn = rq.tn;
 			r.fn = rq.fn;
 			/* the burst goes straight into the pinned slot the DMA engine reads from */
-			memcpy(b.h.iq + (size_t)idx * m.cfg.burst_len * 2, rq.iq, m.cfg.burst_len * 2 * sizeof(int16_t));
+			const size_t burst_i16 = m.cfg.burst_len * 2 * (m.cfg.n_paths > 1 ? (size_t)m.cfg.n_paths : 1);
+			memcpy(b.h.iq + (size_t)idx * burst_i16, rq.iq, burst_i16 * sizeof(int16_t));
 			trxhip_burst_params &p = b.h.params[idx];
 			p.type = (uint8_t)rq.type;
 			p.tsc = (uint8_t)rq.tsc;

@@ -26,7 +26,8 @@ SoftVector *demodAnyBurst_va(const signalVector &burst, CorrType type, int sps, 
 
 /* ---- batched form of the pullRadioVector() DSP core (Transceiver.cpp:724-803) ---- */
 struct BurstRequest {
-	const int16_t *iq;     /* burst_len x (I,Q) as delivered by RadioDevice::readSamples */
+	const int16_t *iq;     /* burst_len x (I,Q) as delivered by RadioDevice::readSamples; with diversity (BurstGathererConfig::
+	                        * n_paths > 1): the n_paths paths of the burst back to back (radioVector::getVector(i)) */
 	CorrType type;         /* expectedCorrType() for the slot */
 	unsigned tsc;
 	unsigned max_toa;
@@ -88,6 +89,8 @@ struct BurstGathererConfig {
 	int trxd_version;         /* -1: float soft bits in BurstIndication::rx_burst; 0 / 1: TRXD datagrams packed on the GPU
 	                           * (the initial header version of every channel, see setTrxdVersion()) */
 	int depth;                /* staging batches in flight (>= 2) */
+	int n_paths;              /* diversity paths per burst, radioVector::chans() (0 / 1: none): the path with the highest energy is
+	                           * demodulated, rssi and energy come from the path average (Transceiver.cpp:723-751) */
 };
 class BurstGatherer {
 public:

@@ -64,6 +64,8 @@ SYMBOLS = {
     "trxhip_vector_slicer": (_I, [_VP, _VP, _VP, _SZ, _VP]),
     "trxhip_pack_trxd_batch": (_I, [_VP, _VP, _VP, _I, _VP, _SZ, _F, _VP]),
     "trxhip_pack_trxd_wire_batch": (_I, [_VP, _VP, _VP, _VP, _I, _VP, _VP, _I, _VP, _SZ, _F, _VP]),
+    "trxhip_select_diversity_batch": (_I, [_VP, _VP, _SZ, _I, _I, _I, _VP, _VP, _VP, _VP]),
+    "trxhip_apply_diversity_power": (_I, [_VP, _VP, _VP, _VP, _SZ, C.c_float, _VP]),
     "trxhip_hostpipe_create": (_I, [_VP, _VP, C.POINTER(_VP)]),
     "trxhip_hostpipe_destroy": (None, [_VP]),
     "trxhip_hostpipe_slot_buffers": (_I, [_VP, _I, _VP]),
@@ -82,6 +84,7 @@ SYMBOLS = {
     "trxhip_rx_frontend_create": (_I, [_VP, _I, _I, _I, C.POINTER(_VP)]),
     "trxhip_rx_frontend_destroy": (None, [_VP]),
     "trxhip_rx_frontend_reset": (_I, [_VP, _VP]),
+    "trxhip_rx_frontend_seed": (_I, [_VP, _VP, _SZ, _VP]),
     "trxhip_rx_frontend_pull": (_I, [_VP, _VP, _SZ, _VP, _SZ, _VP]),
 }
 
@@ -181,6 +184,25 @@ class TrxHip:
         torch = self.torch
         a = np.ascontiguousarray(params_np, dtype=PARAMS_DTYPE).view(np.uint8).reshape(-1, 8)
         return torch.from_numpy(a.copy()).to(f"cuda:{self.device}")
+
+    def select_diversity(self, iq_paths, sps=4, stream=None):
+        """Transceiver.cpp:723-741.  iq_paths: int16[n, n_paths, burst_len, 2] -> (iq_sel int16[n, burst_len, 2],
+        avg_energy float32[n], path uint8[n])."""
+        torch = self.torch
+        n, n_paths, burst_len = iq_paths.shape[0], iq_paths.shape[1], iq_paths.shape[2]
+        dev = iq_paths.device
+        sel = torch.empty((n, burst_len, 2), dtype=torch.int16, device=dev)
+        avg = torch.empty(n, dtype=torch.float32, device=dev)
+        path = torch.empty(n, dtype=torch.uint8, device=dev)
+        _check(self.L.trxhip_select_diversity_batch(self.h, self._dev(iq_paths, torch.int16), n, n_paths, burst_len, sps,
+                                                    self._dev(sel), self._dev(avg), self._dev(path), self._stream(stream)),
+               "trxhip_select_diversity_batch")
+        return sel, avg, path
+
+    def apply_diversity_power(self, results, params, avg_energy, full_scale=32767.0, stream=None):
+        _check(self.L.trxhip_apply_diversity_power(self.h, self._dev(results), self._dev(params), self._dev(avg_energy),
+                                                   results.shape[0], full_scale, self._stream(stream)),
+               "trxhip_apply_diversity_power")
 
     # ---- hot path ------------------------------------------------------------------------------
     def detect_demod(self, iq, params, sps=4, threshold=4.0, full_scale=32767.0, soft_stride=148, slice_bits=True,
@@ -361,6 +383,11 @@ class RxFrontEnd:
     def reset(self, stream=None):
         _check(self.trx.L.trxhip_rx_frontend_reset(self.h, self.trx._stream(stream)), "trxhip_rx_frontend_reset")
 
+    def seed(self, wide_prev, n_blocks_prev, stream=None):
+        """Start mid-stream: wide_prev = the n_blocks_prev >= 1 blocks preceding the shard (trxhip_rx_frontend_seed)."""
+        ptr = self.trx._dev(wide_prev, self.trx.torch.int16) if n_blocks_prev else None
+        _check(self.trx.L.trxhip_rx_frontend_seed(self.h, ptr, n_blocks_prev, self.trx._stream(stream)), "trxhip_rx_frontend_seed")
+
     def pull(self, wide_iq, n_blocks, stream=None):
         """wide_iq: int16[n_blocks*block_len*4, 2] -> complex64[4, n_blocks*block_len*p/q]"""
         torch = self.trx.torch
@@ -385,7 +412,7 @@ class RxFrontEnd:
 class _HostPipeCfg(C.Structure):
     _fields_ = [("max_bursts", C.c_uint32), ("depth", C.c_int32), ("burst_len", C.c_int32), ("sps", C.c_int32),
                 ("soft_stride", C.c_int32), ("pkt_stride", C.c_int32), ("flags", C.c_int32), ("threshold", C.c_float),
-                ("full_scale", C.c_float), ("rssi_offset", C.c_float)]
+                ("full_scale", C.c_float), ("rssi_offset", C.c_float), ("n_paths", C.c_int32)]
 
 
 class _HostPipeSlot(C.Structure):
@@ -399,10 +426,10 @@ class HostPipe:
     results/soft/pkt.  run() is the convenience form for ordinary numpy arrays."""
 
     def __init__(self, trx, max_bursts, depth=3, burst_len=625, sps=4, soft_stride=148, pkt_stride=0, flags=FLAG_SLICE,
-                 threshold=4.0, full_scale=32767.0, rssi_offset=0.0):
+                 threshold=4.0, full_scale=32767.0, rssi_offset=0.0, n_paths=1):
         self.trx = trx
         self.cfg = _HostPipeCfg(max_bursts, depth, burst_len, sps, soft_stride, pkt_stride, flags, threshold, full_scale,
-                                rssi_offset)
+                                rssi_offset, n_paths)
         h = _VP()
         _check(trx.L.trxhip_hostpipe_create(trx.h, C.byref(self.cfg), C.byref(h)), "trxhip_hostpipe_create")
         self.h = h
@@ -421,7 +448,8 @@ class HostPipe:
             buf = (C.c_ubyte * nbytes).from_address(ptr)
             return np.frombuffer(buf, dtype=dtype).reshape(shape)
         return {
-            "iq": view(s.iq, n * c.burst_len * 4, np.int16, (n, c.burst_len, 2)),
+            "iq": (view(s.iq, n * c.burst_len * 4, np.int16, (n, c.burst_len, 2)) if c.n_paths <= 1 else
+                   view(s.iq, n * c.n_paths * c.burst_len * 4, np.int16, (n, c.n_paths, c.burst_len, 2))),
             "params": view(s.params, n * 8, PARAMS_DTYPE, (n,)),
             "meta": view(s.meta, n * 8, TRXD_META_DTYPE, (n,)),
             "results": view(s.results, n * 32, RESULT_DTYPE, (n,)),

@@ -96,6 +96,8 @@ def lib():
     L.orc_modulate_edge_burst.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.orc_pull_batch.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_double,
                                  C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.orc_pull_batch_div.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_double,
+                                     C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.orc_trxd_toa256.restype = C.c_int
     L.orc_trxd_toa256.argtypes = [C.c_double]
     L.orc_trxd_ci_cb.restype = C.c_int16
@@ -209,6 +211,19 @@ def pull_batch(iq, sps, params, threshold=4.0, full_scale=32767.0, soft_stride=1
     lib().orc_pull_batch(_ptr(iq), n, burst_len, sps, _ptr(params), threshold, full_scale,
                          _ptr(res), _ptr(soft), soft_stride, 1 if slice_bits else 0)
     return res, soft
+
+
+def pull_batch_div(iq_paths, sps, params, threshold=4.0, full_scale=32767.0, soft_stride=148, slice_bits=True):
+    """iq_paths: int16[n, n_paths, burst_len, 2] (Transceiver.cpp:723-751). Returns (results, soft, path uint8[n])."""
+    iq = np.ascontiguousarray(iq_paths, dtype=np.int16)
+    n, n_paths, burst_len = iq.shape[0], iq.shape[1], iq.shape[2]
+    params = np.ascontiguousarray(params, dtype=PARAMS_DTYPE)
+    res = np.zeros(n, dtype=RESULT_DTYPE)
+    soft = np.zeros((n, soft_stride), dtype=np.float32)
+    path = np.zeros(n, dtype=np.uint8)
+    lib().orc_pull_batch_div(_ptr(iq), n, n_paths, burst_len, sps, _ptr(params), C.c_float(threshold), C.c_double(full_scale),
+                             _ptr(res), _ptr(soft), soft_stride, 1 if slice_bits else 0, _ptr(path))
+    return res, soft, path
 
 
 def modulate_burst(bits, guard, sps, empty=False):

@@ -340,3 +340,35 @@ def test_delay_vector_batch_bit_exact(trx):
     re = x.real * np.float32(0.25) - x.imag * np.float32(-2.0)
     im = x.real * np.float32(-2.0) + x.imag * np.float32(0.25)
     assert np.array_equal(y.real, re) and np.array_equal(y.imag, im)
+
+
+def test_rx_frontend_time_shards_seeded_mid_stream(trx):
+    """SURVEY.md 8e, the channelizer's shard edge: a stream cut into time shards, each on its own front end started
+    mid-stream with trxhip_rx_frontend_seed() (the one block preceding the shard is enough: both filters are FIR with 15
+    samples of memory, Channelizer.cpp:86-88, radioInterfaceMulti.cpp:283-300), gives -- concatenated -- exactly the
+    output of one front end that saw the whole stream; an unseeded second shard does not.  All three resampling ratios."""
+    from osmo_trx_amd import synth, trxhip
+    for (p, q, bl) in ((65, 48, 192), (65, 96, 192), (52, 75, 300)):
+        n_blocks = 4096
+        wide = synth.make_wideband_stream(n_blocks, "cuda:0", seed=77 + p, block_len=bl)
+        one = trxhip.RxFrontEnd(trx, block_len=bl, p=p, q=q)
+        full = one.pull(wide, n_blocks)
+        torch.cuda.synchronize()
+        cuts = [0, 1000, 1001, 3000, n_blocks]                    # shard edges (one shard is a single block)
+        parts = []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            fe = trxhip.RxFrontEnd(trx, block_len=bl, p=p, q=q)
+            if a:
+                fe.seed(wide[(a - 1) * bl * 4:a * bl * 4].contiguous(), 1)
+            else:
+                fe.seed(None, 0)
+            parts.append(fe.pull(wide[a * bl * 4:b * bl * 4].contiguous(), b - a))
+            fe.close()
+        torch.cuda.synchronize()
+        cat = torch.cat(parts, dim=1)
+        assert torch.equal(cat.view(torch.float32), full.view(torch.float32)), (p, q)
+        cold = trxhip.RxFrontEnd(trx, block_len=bl, p=p, q=q)      # the same shard without the seed: differs at its start
+        unseeded = cold.pull(wide[1000 * bl * 4:1001 * bl * 4].contiguous(), 1)
+        torch.cuda.synchronize()
+        assert not torch.equal(unseeded.view(torch.float32), parts[1].view(torch.float32))
+        one.close(); cold.close()

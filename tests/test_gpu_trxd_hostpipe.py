@@ -243,3 +243,42 @@ def test_host_trxd_packer_equals_oracle(trx, tmp_path):
                                      int(a["tsc"][i]), float(a["ci"][i]), row.ctypes.data, 0 if a["idle"][i] else int(a["nbits"][i]))
                 assert got["len"][i] == ln
                 assert np.array_equal(got["pkt"][i][:ln], buf[:ln]), (ver, i)
+
+
+def test_diversity_path_selection(trx):
+    """SURVEY.md 8a row a4, the diversity half of pullRadioVector() (Transceiver.cpp:723-751): every burst on n_paths
+    receive paths, energyDetect() on each, the FIRST path with the highest energy demodulated, rssi / energy from
+    avg = sqrt(sum pow / chans).  Device-resident calls and the host pipeline against the oracle's restatement: chosen
+    path, all record fields and exact-demodulator soft bits identical; OFF / IDLE slots and equal-energy paths included."""
+    from osmo_trx_amd import synth
+    from osmo_trx_amd.trxhip import HostPipe, FLAG_SLICE, FLAG_EXACT_DEMOD
+    n, n_paths = 1024, 3
+    rng = np.random.default_rng(99)
+    iq, params, _ = synth.make_mixed_bursts(n, "cpu", seed=31, chunk=128)
+    iq = iq.numpy()
+    params = synth.make_idle_off_mix(params)
+    paths = np.empty((n, n_paths, 625, 2), dtype=np.int16)
+    good = rng.integers(0, n_paths, n)
+    for k in range(n_paths):                                   # one path carries the burst, the others an attenuated copy + noise
+        att = np.where(good == k, 1.0, rng.uniform(0.05, 0.9, n))[:, None, None]
+        paths[:, k] = np.clip(np.rint(iq * att + rng.normal(0, 30, iq.shape)), -32768, 32767).astype(np.int16)
+    paths[5::64, 1] = paths[5::64, 0]                          # exact ties: the first of the equal paths wins
+    paths[5::64, 2] = paths[5::64, 0]
+    o_res, o_soft, o_path = O.pull_batch_div(paths, 4, params)
+    d_paths = torch.from_numpy(paths).to("cuda:0")
+    sel, avg, path = trx.select_diversity(d_paths)
+    d_p = trx.params_tensor(params)
+    res, soft = trx.detect_demod(sel, d_p, sps=4, exact=True)
+    trx.apply_diversity_power(res, d_p, avg)
+    torch.cuda.synchronize()
+    assert np.array_equal(path.cpu().numpy(), o_path)
+    assert (o_path[5::64] == 0).all() and len(set(o_path.tolist())) == n_paths
+    r = trx.results_to_numpy(res)
+    from test_gpu_parity import check_parity
+    check_parity(r, soft.cpu().numpy(), o_res, o_soft)         # incl. energy (3e-6 rel) and rssi (2e-5 dB) of the path average
+    assert (o_res["rc"] > 0).sum() > 0.8 * n * 14 / 16
+    # the same through the pinned host pipeline (what BurstGatherer with n_paths = 3 submits)
+    pipe = HostPipe(trx, 256, depth=3, soft_stride=148, flags=FLAG_SLICE | FLAG_EXACT_DEMOD, n_paths=n_paths)
+    out = pipe.run(paths, params)
+    pipe.close()
+    check_parity(out["results"], out["soft"], o_res, o_soft)

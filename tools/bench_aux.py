@@ -35,8 +35,8 @@ def report(kernel, what, units, unit, algo_bytes, ms):
                       "event_ms": round(ms, 4)}), flush=True)
 
 
-# ---- hot kernel on the other workloads (burst_pull4_kernel<false, false> unless stated) -- each its own launch size
-def pull(name, iq, params, stride=148, exact=False, kernel="burst_pull4_kernel<false, false>"):
+# ---- hot kernel on the other workloads (burst_pull4_kernel<false, false, true>, the COMMON instantiation, unless stated)
+def pull(name, iq, params, stride=148, exact=False, kernel="burst_pull4_kernel<false, false, true>"):
     n = iq.shape[0]
     dp = trx.params_tensor(params)
     res = torch.empty((n, 32), dtype=torch.uint8, device=dev)
@@ -47,7 +47,7 @@ def pull(name, iq, params, stride=148, exact=False, kernel="burst_pull4_kernel<f
 
 
 iq, p, _ = synth.make_normal_bursts(N, dev, 4)
-res, soft, dp = pull("configs[1] NB max_toa 3, exact demodulator", iq, p, exact=True, kernel="burst_pull4_kernel<false, true>")
+res, soft, dp = pull("configs[1] NB max_toa 3, exact demodulator", iq, p, exact=True, kernel="burst_pull4_kernel<false, true, true>")
 
 # ---- TRXD packers on that launch's output
 meta = np.zeros(N, dtype=trxhip.TRXD_META_DTYPE)
@@ -73,7 +73,7 @@ pull("configs[2] EXT_RACH (TS0/1/2) max_toa 63", iq, p)
 iq, p = synth.make_mixed_bursts(N, dev)
 pull("configs[4] share: 7:1 NB:RACH", iq, p)
 iq, p, _ = synth.make_edge_bursts(N, dev)
-pull("EDGE 8-PSK, 444 soft bits", iq, p, stride=444)
+pull("EDGE 8-PSK, 444 soft bits", iq, p, stride=444, kernel="burst_pull4_kernel<false, false, false>")
 iq1, p1, _ = synth.make_normal_bursts(N, dev, 1, burst_len=156)
 pull("configs[0] geometry: NB 1 SPS, 156 samples", iq1, p1, kernel="burst_pull_kernel<1, false, 3>")
 del iq, iq1
