@@ -254,7 +254,7 @@ def test_diversity_path_selection(trx):
     from osmo_trx_amd.trxhip import HostPipe, FLAG_SLICE, FLAG_EXACT_DEMOD
     n, n_paths = 1024, 3
     rng = np.random.default_rng(99)
-    iq, params, _ = synth.make_mixed_bursts(n, "cpu", seed=31, chunk=128)
+    iq, params = synth.make_mixed_bursts(n, "cpu", seed=31, chunk=128)
     iq = iq.numpy()
     params = synth.make_idle_off_mix(params)
     paths = np.empty((n, n_paths, 625, 2), dtype=np.int16)
