@@ -19,6 +19,8 @@ for seed in range(n_seeds):
     L = int(rng.choice([625, 625, 625, 624, 626, 628]))
     ss = int(rng.choice([148, 156, 444]))
     sl = bool(rng.integers(0, 2))
+    if seed % 2 == 0:                              # every other seed in the geometry of the COMMON instantiation (the product's hot kernel)
+        L, ss, sl = 625, 148, True
     iq, params = _fuzz_batch(n, L, rng)
     o_res, o_soft = O.pull_batch(iq.numpy(), 4, params, soft_stride=ss, slice_bits=sl)
     big = params["max_toa"] > 112
