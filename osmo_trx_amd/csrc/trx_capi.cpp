@@ -12,7 +12,7 @@
 #include "trx_tables.h"
 
 // kernel launchers (trx_kernels.hip, trx_aux_kernels.hip)
-extern "C" int trx_launch_pull(const void *d_iq, int cf32, const trxhip_burst_params *d_params,
+extern "C" int trx_launch_pull(unsigned *d_pool_ctr, const void *d_iq, int cf32, const trxhip_burst_params *d_params,
 			       trxhip_burst_result *d_results, float *d_soft, const trx_tables *d_tab, const float *d_ebp_in,
 			       size_t n_bursts, int L, int sps, float thresh, float full_scale,
 			       int soft_stride, int slice, int n_cu, hipStream_t stream);
@@ -120,6 +120,8 @@ int trxhip_create_from_tables(trxhip_ctx **out, int device, const void *h_blob, 
 	ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 	ctx->d_tables = nullptr;
 	ctx->no_unit = trx_unit_masks_match(t) ? 0 : 1;
+	ctx->d_pool = nullptr;
+	ctx->pool_next = 0;
 	ctx->no_sym = 0;                                           /* the straight-line decimator reads taps 0..7 and mirrors them */
 	for (int k = 0; k < 8; k++)
 		if (memcmp(&t->dec_taps[k], &t->dec_taps[15 - k], sizeof(float)) != 0)
@@ -133,6 +135,8 @@ int trxhip_create_from_tables(trxhip_ctx **out, int device, const void *h_blob, 
 		delete ctx;
 		return TRXHIP_EIO;
 	}
+	if (hipMalloc(reinterpret_cast<void **>(&ctx->d_pool), TRX_POOL_SLOTS * 64) != hipSuccess)
+		ctx->d_pool = nullptr;                                 /* (the kernels run without the pool) */
 	*out = ctx;
 	return TRXHIP_OK;
 }
@@ -155,8 +159,10 @@ void trxhip_destroy(trxhip_ctx *ctx)
 {
 	if (!ctx)
 		return;
-	if (hipSetDevice(ctx->device) == hipSuccess && ctx->d_tables)
-		(void)hipFree(ctx->d_tables);
+	if (hipSetDevice(ctx->device) == hipSuccess) {
+		if (ctx->d_tables) (void)hipFree(ctx->d_tables);
+		if (ctx->d_pool) (void)hipFree(ctx->d_pool);
+	}
 	delete ctx;
 }
 
@@ -195,7 +201,15 @@ static int pull_common(trxhip_ctx *ctx, const void *d_iq, int cf32, const trxhip
 		flags |= TRXHIP_IFLAG_NO_UNIT;
 	if (ctx->no_sym)
 		flags |= TRXHIP_IFLAG_NO_SYM;
-	return trx_launch_pull(d_iq, cf32, d_params, d_results, d_soft, ctx->d_tables, d_ebp_in, n_bursts, burst_len, sps,
+	/* a zeroed pool counter for this launch (the kernel ignores it for small batches) */
+	unsigned *pool = nullptr;
+	if (ctx->d_pool && n_bursts >= (size_t)ctx->n_cu * 128) {
+		const unsigned slot = __atomic_fetch_add(&ctx->pool_next, 1u, __ATOMIC_RELAXED) % TRX_POOL_SLOTS;
+		pool = ctx->d_pool + slot * 16;
+		if (hipMemsetAsync(pool, 0, sizeof(unsigned), static_cast<hipStream_t>(stream)) != hipSuccess)
+			return TRXHIP_EIO;
+	}
+	return trx_launch_pull(pool, d_iq, cf32, d_params, d_results, d_soft, ctx->d_tables, d_ebp_in, n_bursts, burst_len, sps,
 			       threshold, full_scale, soft_stride, flags, ctx->n_cu, static_cast<hipStream_t>(stream));
 }
 

@@ -11,7 +11,12 @@ struct trxhip_ctx {
 	trx_tables *d_tables;
 	int no_unit;        /* tables do not have the compiled-in unit structure: keep the multiplying correlation */
 	int no_sym;         /* decimator taps not bitwise symmetric: the kernels' straight-line paths (mirrored taps) are off */
+	/* cross-die work pool of the 4-SPS kernel (trx_kernel4.hip): one 64-byte counter per launch in flight, handed out
+	 * round-robin so that concurrent launches of one context (several host threads, several streams) never share one */
+	unsigned *d_pool;
+	unsigned pool_next;
 };
+#define TRX_POOL_SLOTS 64
 
 static inline int with_device(const trxhip_ctx *ctx)
 {

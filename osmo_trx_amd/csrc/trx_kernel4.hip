@@ -35,6 +35,11 @@
 #define K4_PKC_INTS (5 * WAVE)                                  // lane constants of the TOA bisection (PeakConst), one copy per CU
 #define K4_TABLES_FLOATS (TRX_SINCV_LDS + K4_DROWS * TRX_DELAY_HLEN + 2 * 160 + 16 + 2 * LSEQ_TAPS + 8 * LSEQ_NHDR + K4_DROWS * 36 + K4_PKC_INTS)
 #define K4_TABLES_BYTES (K4_TABLES_FLOATS * 4)
+#define K4_POOL_RING 64                     // ring of dynamic-group ids per workgroup (at most 3 groups are in flight at a time)
+#define K4_POOL_UNSET (-1)
+#define K4_POOL_END (-2)
+#define K4_NO_BURST 0xffffffffu
+#define K4_LDS_TAIL (16 + 4 * K4_POOL_RING)  // work counter + pool ring behind the per-wave slices
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
@@ -156,7 +161,8 @@ __global__ void __launch_bounds__(K4_WPB(CF32, EXACT) * WAVE)
 burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__restrict__ params,
 		   trxhip_burst_result *__restrict__ results, float *__restrict__ soft_arg,
 		   const trx_tables *__restrict__ tab, const float4 *__restrict__ ebp_arg,
-		   unsigned n_bursts, int L_arg, float thresh, float full_scale, int soft_stride_arg, int slice_arg)
+		   unsigned n_bursts, int L_arg, float thresh, float full_scale, int soft_stride_arg, int slice_arg,
+		   unsigned *__restrict__ pool_ctr)
 {
 	static_assert(!(COMMON && CF32), "the common instantiation reads int16 bursts");
 	const int L = COMMON ? 625 : L_arg;
@@ -183,6 +189,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 	int *pkcl = reinterpret_cast<int *>(comp + K4_DROWS * 36);     // [5][64] PeakConst fields by lane
 	c32 *wbase = reinterpret_cast<c32 *>(smem + K4_TABLES_BYTES) + (size_t)wave * K4_SLICE;
 	int *const wg_next = reinterpret_cast<int *>(reinterpret_cast<c32 *>(smem + K4_TABLES_BYTES) + (size_t)waves_per_block * K4_SLICE);   // work counter
+	int *const pool_g = wg_next + 4;                               // [64] ring: pool group claimed for this workgroup's k-th dynamic group
 	c32 *const P = wbase;                                          // polyphase burst: P[r*PH_A + PH_M0 + m] = x[4m + r]
 	c32 *const dec = wbase + K4_XS;                                // 1-SPS (decimated) burst, zero tail
 	c32 *const cz = dec + TRX_DEC_NARROW + TRX_CZ_PAD;             // zero-padded correlation
@@ -237,6 +244,8 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 		wbase[i] = make_float2(0.0f, 0.0f);
 	if (threadIdx.x == 0)
 		*wg_next = waves_per_block;                                 // items 0 .. waves-1 are the waves' first ones
+	if (threadIdx.x < K4_POOL_RING)
+		pool_g[threadIdx.x] = K4_POOL_UNSET;
 	__syncthreads();
 
 	const float fs_db = 6.02059991f * __log2f(full_scale);          // 20*log10(full_scale)
@@ -250,11 +259,53 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 	// items are handed out in groups of 16 CONSECUTIVE bursts (group g belongs to workgroup g % gridDim.x): neighbouring
 	// bursts share the 128-byte line their boundary falls in, and with them on one CU that line is fetched from HBM once
 	const unsigned n_groups = (n_bursts + 15u) >> 4;
-	const unsigned my_groups = (blockIdx.x < n_groups) ? (n_groups - blockIdx.x + n_wg - 1) / n_wg : 0u;
-	unsigned items = my_groups << 4;
-	if (my_groups && (my_groups - 1) * n_wg + blockIdx.x == n_groups - 1)
+	// The eight dies do not run this kernel at the same speed (tools/wave_timeline.py, round 3: all workgroups of a die end
+	// within 17 us of each other, the dies up to 110 us = 7 % apart, 3.7 % of the chip idle on average).  With a pool counter
+	// (large batches) only 7/8 of the groups are dealt statically -- the same number to every workgroup -- and the rest is
+	// drawn group by group from ONE device-wide atomic counter by whichever workgroup gets there: the wave that takes the
+	// first burst of a group draws the NEXT group (k + 1) and publishes it through the LDS ring pool_g[], so that the global
+	// atomic's latency is paid once per 16 bursts by one wave, a burst-time before anybody needs the answer.
+	const bool pooled = pool_ctr != nullptr;
+	const unsigned n_static_groups = pooled ? ((n_groups - (n_groups >> 3)) / n_wg) * n_wg : n_groups;
+	const unsigned n_pool_groups = n_groups - n_static_groups;
+	const unsigned my_groups = (blockIdx.x < n_static_groups) ? (n_static_groups - blockIdx.x + n_wg - 1) / n_wg : 0u;
+	unsigned items = my_groups << 4;                               // statically owned items of this workgroup
+	if (!pooled && my_groups && (my_groups - 1) * n_wg + blockIdx.x == n_groups - 1)
 		items -= (n_groups << 4) - n_bursts;                        // the batch's last group may be short
-	auto burst_of = [&](unsigned jj) { return (((jj >> 4) * n_wg + blockIdx.x) << 4) + (jj & 15u); };
+	// burst index of item jj, or K4_NO_BURST when the work has run out (dynamic items wait for their group to be published)
+	auto burst_of = [&](unsigned jj) -> unsigned {
+		if (jj < items)
+			return (((jj >> 4) * n_wg + blockIdx.x) << 4) + (jj & 15u);
+		if (!pooled)
+			return K4_NO_BURST;
+		const unsigned k = (jj - items) >> 4;
+		volatile int *slot = pool_g + (k & (K4_POOL_RING - 1));
+		int g;
+		while ((g = *slot) == K4_POOL_UNSET)
+			__builtin_amdgcn_s_sleep(2);
+		g = uni(g);
+		if (g < 0)
+			return K4_NO_BURST;
+		const unsigned bb = ((n_static_groups + (unsigned)g) << 4) + (jj & 15u);
+		return bb < n_bursts ? bb : K4_NO_BURST;
+	};
+	// the wave holding the first item of (static or dynamic) group kk draws dynamic group kk + 1; `ended`: its own group is
+	// already past the end of the pool -- publish that, no atomic.  Also clears the ring entry half a ring ahead.
+	auto pool_draw = [&](unsigned jj, bool ended, int lane) {
+		const unsigned k = (jj + 16u - items) >> 4;
+		int g = K4_POOL_END;
+		if (!ended) {
+			unsigned p = 0;
+			if (lane == 0)
+				p = __hip_atomic_fetch_add(pool_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			p = (unsigned)uni((int)p);
+			g = (p < n_pool_groups) ? (int)p : K4_POOL_END;
+		}
+		if (lane == 0) {
+			pool_g[(k + K4_POOL_RING / 2) & (K4_POOL_RING - 1)] = K4_POOL_UNSET;
+			pool_g[k & (K4_POOL_RING - 1)] = g;
+		}
+	};
 
 	// Software prefetch of the next burst (see burst_pull_kernel)
 	uint32_t pre_i[NLD];
@@ -278,8 +329,9 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 			}
 		}
 	};
-	if ((unsigned)wave < items)
-		prefetch(burst_of((unsigned)wave));
+	unsigned b_first = burst_of((unsigned)wave);                   // (static: pooled launches give every workgroup >= 7 groups)
+	if (b_first != K4_NO_BURST)
+		prefetch(b_first);
 
 	// loader address: sample r*64 + lane -> phase lane&3, m = 16r + lane>>2
 	c32 *const pload = P + (lane & 3) * PH_A + PH_M0 + (lane >> 2);
@@ -349,9 +401,8 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 	};
 
 	DIAG_DECL;
-	unsigned j_next = 0;
-	for (unsigned j = (unsigned)wave; j < items; j = j_next) {
-		const unsigned b = burst_of(j);
+	unsigned j_next = 0, b_next = K4_NO_BURST;
+	for (unsigned b = b_first; b != K4_NO_BURST; b = b_next) {
 		// Re-materialise the lane id per burst (2 VALU ops): otherwise every lane-derived address, tree-node
 		// offset and LUT base of every phase is hoisted out of this loop and kept live across it, which
 		// costs ~50 VGPRs and spills.
@@ -416,8 +467,11 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 		DIAG_MARK(16);
 		j_next = (unsigned)claim_take(ticket);
 		DIAG_MARK(17);
-		if (j_next < items)
-			prefetch(burst_of(j_next));
+		b_next = burst_of(j_next);
+		if (pooled && (j_next & 15u) == 0u && j_next + 16u >= items)
+			pool_draw(j_next, b_next == K4_NO_BURST && j_next >= items, lane);
+		if (b_next != K4_NO_BURST)
+			prefetch(b_next);
 		DIAG_MARK(15);
 
 		if (type != TRXHIP_OFF) {                                   // Transceiver.cpp:704-707
@@ -937,7 +991,7 @@ extern "C" int trx_unit_masks_match(const trx_tables *t)
 	return 1;
 }
 
-extern "C" int trx_launch_pull4(const void *d_iq, int cf32, const trxhip_burst_params *d_params,
+extern "C" int trx_launch_pull4(unsigned *d_pool_ctr, const void *d_iq, int cf32, const trxhip_burst_params *d_params,
 				trxhip_burst_result *d_results, float *d_soft, const trx_tables *d_tab, const float *d_ebp_in,
 				size_t n_bursts, int L, float thresh, float full_scale, int soft_stride, int flags, int n_cu,
 				hipStream_t stream)
@@ -949,7 +1003,7 @@ extern "C" int trx_launch_pull4(const void *d_iq, int cf32, const trxhip_burst_p
 #ifdef TRX_DIAG
 	if (const char *e = getenv("TRXHIP_WPB")) { const int v = atoi(e); if (v >= 1 && v <= wpb) wpb = v; }   // occupancy scan
 #endif
-	const size_t lds = K4_TABLES_BYTES + (size_t)wpb * K4_SLICE * sizeof(c32) + 16;     // + the workgroup's work counter
+	const size_t lds = K4_TABLES_BYTES + (size_t)wpb * K4_SLICE * sizeof(c32) + K4_LDS_TAIL;   // + work counter + pool ring
 	size_t need = (n_bursts + 15) / 16;                             // work is handed out in groups of 16 bursts
 	size_t grid = (size_t)n_cu;
 #ifdef TRX_DIAG
@@ -969,14 +1023,16 @@ extern "C" int trx_launch_pull4(const void *d_iq, int cf32, const trxhip_burst_p
 		const unsigned long long bit = 1ull << (dev & 63);                                              \
 		if (!(armed.load(std::memory_order_acquire) & bit)) {                                           \
 			if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize,        \
-						(int)(K4_TABLES_BYTES + (size_t)K4_WPB(CF_, EX_) * K4_SLICE * sizeof(c32) + 16)) != hipSuccess) \
+						(int)(K4_TABLES_BYTES + (size_t)K4_WPB(CF_, EX_) * K4_SLICE * sizeof(c32) + K4_LDS_TAIL)) != hipSuccess) \
 				return TRXHIP_EIO;                                                                  \
 			armed.fetch_or(bit, std::memory_order_release);                                             \
 		}                                                                                               \
 		hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(wpb * WAVE), lds, stream, d_iq, d_params, d_results, \
 				   d_soft, d_tab, reinterpret_cast<const float4 *>(d_ebp_in), (unsigned)n_bursts, L, thresh, \
-				   full_scale, soft_stride, flags);                                             \
+				   full_scale, soft_stride, flags, pool);                                       \
 	} while (0)
+	/* the cross-die pool needs every workgroup to own >= 7 static groups and the grid to be the persistent one */
+	unsigned *const pool = (d_pool_ctr && grid == (size_t)n_cu && need >= 8 * grid && !getenv("TRXHIP_NO_POOL")) ? d_pool_ctr : nullptr;
 	if (cf32)        { if (exact) LAUNCH4(true, true, false); else LAUNCH4(true, false, false); }
 	else if (common) { if (exact) LAUNCH4(false, true, true); else LAUNCH4(false, false, true); }
 	else             { if (exact) LAUNCH4(false, true, false); else LAUNCH4(false, false, false); }

@@ -406,12 +406,12 @@ extern "C" size_t trx_pull_lds_bytes(int L, int waves_per_block)
 	return TRX_TABLES_LDS_BYTES + (size_t)waves_per_block * slice_c32 * sizeof(c32) + 16;   // + the workgroup's work counter
 }
 
-extern "C" int trx_launch_pull4(const void *d_iq, int cf32, const trxhip_burst_params *d_params,
+extern "C" int trx_launch_pull4(unsigned *d_pool_ctr, const void *d_iq, int cf32, const trxhip_burst_params *d_params,
 				trxhip_burst_result *d_results, float *d_soft, const trx_tables *d_tab, const float *d_ebp_in,
 				size_t n_bursts, int L, float thresh, float full_scale, int soft_stride, int flags, int n_cu,
 				hipStream_t stream);
 
-extern "C" int trx_launch_pull(const void *d_iq, int cf32, const trxhip_burst_params *d_params,
+extern "C" int trx_launch_pull(unsigned *d_pool_ctr, const void *d_iq, int cf32, const trxhip_burst_params *d_params,
 			       trxhip_burst_result *d_results, float *d_soft, const trx_tables *d_tab, const float *d_ebp_in,
 			       size_t n_bursts, int L, int sps, float thresh, float full_scale,
 			       int soft_stride, int slice, int n_cu, hipStream_t stream)
@@ -420,7 +420,7 @@ extern "C" int trx_launch_pull(const void *d_iq, int cf32, const trxhip_burst_pa
 		return 0;
 	// the transceiver's 4-SPS burst size gets the production kernel (polyphase LDS layout, fused or exact demod)
 	if (sps == 4 && L >= 624 && L <= 628)
-		return trx_launch_pull4(d_iq, cf32, d_params, d_results, d_soft, d_tab, d_ebp_in, n_bursts, L, thresh, full_scale,
+		return trx_launch_pull4(d_pool_ctr, d_iq, cf32, d_params, d_results, d_soft, d_tab, d_ebp_in, n_bursts, L, thresh, full_scale,
 					soft_stride, slice, n_cu, stream);
 	// as many waves per workgroup as the 160 KB of LDS admit (12 at L = 625), one workgroup per CU
 	int wpb = TRX_WPB;

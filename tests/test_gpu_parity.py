@@ -521,3 +521,44 @@ def test_results_do_not_depend_on_the_batch_size(trx, sps):
             assert torch.equal(res[sl], r2) and torch.equal(soft[sl], s2), (sps, exact, m, off)
             off += m
         assert off <= n
+
+
+def test_cross_die_pool_equals_static_split(trx):
+    """Large batches deal 7/8 of the 16-burst groups statically and let the workgroups draw the rest from a device-wide
+    counter (trx_kernel4.hip, cross-die pool).  Which CU processes a burst must not matter: for batch sizes around the
+    pool's threshold and with ragged tails, pooled and static (TRXHIP_NO_POOL) launches give bit-identical records and soft
+    bits, no burst skipped or done twice (every record of a sentinel-filled output is written), also for back-to-back
+    launches on two streams (each launch has its own counter)."""
+    from osmo_trx_amd import synth
+    n_max = 3 * 65536 + 77
+    iq, params = synth.make_mixed_bursts(n_max, "cuda:0", seed=808, chunk=8192)
+    d_p = trx.params_tensor(params)
+    for n in (32768 - 1, 32768, 65536 + 15, 131072 + 1, n_max):
+        outs = []
+        for no_pool in ("1", None):
+            if no_pool:
+                os.environ["TRXHIP_NO_POOL"] = no_pool
+            else:
+                os.environ.pop("TRXHIP_NO_POOL", None)
+            res = torch.full((n, 32), 0xA5, dtype=torch.uint8, device="cuda:0")
+            soft = torch.full((n, 148), float("nan"), dtype=torch.float32, device="cuda:0")
+            for exact in (False, True):
+                trx.detect_demod(iq[:n], d_p[:n], sps=4, soft_stride=148, slice_bits=True, results=res, soft=soft, exact=exact)
+                torch.cuda.synchronize()
+                outs.append((res.cpu().numpy().copy(), soft.cpu().numpy().copy()))
+        assert not np.isnan(outs[2][1]).any() and not np.isnan(outs[3][1]).any()
+        for k in (0, 1):
+            assert np.array_equal(outs[k][0], outs[k + 2][0]), (n, k)
+            assert np.array_equal(outs[k][1].view(np.uint32), outs[k + 2][1].view(np.uint32)), (n, k)
+    # two streams, launches interleaved: every launch draws from its own counter
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    ref_res, ref_soft = trx.detect_demod(iq, d_p, sps=4)
+    torch.cuda.synchronize()
+    outs = []
+    for rep in range(4):
+        for s in (s1, s2):
+            with torch.cuda.stream(s):
+                outs.append(trx.detect_demod(iq, d_p, sps=4, stream=s))
+    torch.cuda.synchronize()
+    for r, so in outs:
+        assert torch.equal(r, ref_res) and torch.equal(so.view(torch.int32), ref_soft.view(torch.int32))
