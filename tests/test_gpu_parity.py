@@ -550,6 +550,13 @@ def test_cross_die_pool_equals_static_split(trx):
         for k in (0, 1):
             assert np.array_equal(outs[k][0], outs[k + 2][0]), (n, k)
             assert np.array_equal(outs[k][1].view(np.uint32), outs[k + 2][1].view(np.uint32)), (n, k)
+    # many launches at random sizes (pooled and not): always terminates, always the same records as the full-batch run
+    full_res, _ = trx.detect_demod(iq, d_p, sps=4)
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(5)
+    for n in rng.integers(1, n_max + 1, 150).tolist() + [n_max, 32768 + 16, 65536]:
+        res, _ = trx.detect_demod(iq[:n], d_p[:n], sps=4)
+        assert torch.equal(res, full_res[:n]), n
     # two streams, launches interleaved: every launch draws from its own counter
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
     ref_res, ref_soft = trx.detect_demod(iq, d_p, sps=4)
