@@ -56,7 +56,7 @@ meta["tn"] = np.arange(N) & 7
 meta["version"] = 1
 d_meta = torch.from_numpy(meta.view(np.uint8).reshape(-1, 8).copy()).to(dev)
 ms = timeit(lambda: trx.pack_trxd_wire(res, dp, soft, d_meta))
-report("pack_trxd_wire_kernel", "TRXD v1 datagrams, 160-byte rows", N, "bursts", N * (32 + 8 + 8 + 592 + 160 + 2), ms)
+report("pack_trxd_wire16_kernel", "TRXD v1 datagrams, 160-byte rows", N, "bursts", N * (32 + 8 + 8 + 592 + 160 + 2), ms)
 ms = timeit(lambda: trx.pack_trxd(res, soft))
 report("pack_trxd_kernel", "156-byte device records", N, "bursts", N * (32 + 592 + 156), ms)
 
