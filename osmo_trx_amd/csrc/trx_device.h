@@ -371,6 +371,50 @@ struct UnitCorr {
 	}
 };
 
+// Access bursts: 40 taps over up to 80 lags.  Lane l < 40 takes the two ADJACENT lags 2l and 2l + 1: their windows share 39
+// of 41 samples, so the lane reads 21 aligned sample PAIRS (ds_read_b128, conflict-free at a 16-byte lane stride) where two
+// rounds of one lag per lane read 80 samples -- the correlation is bound by LDS bytes, not by its 80 additions.  Each lag
+// still accumulates its taps k = 0 .. 39 in order.  p = &sig[2l + start - 39], 16-byte aligned.
+template <unsigned long long NEGMASK>
+struct UnitCorrPair40 {
+	static __device__ __forceinline__ void run(const c32 *p, trx_v2f &a0, trx_v2f &a1)
+	{
+		typedef float v4f_t __attribute__((ext_vector_type(4)));
+		typedef const volatile v4f_t __attribute__((address_space(3))) *lds_ptr4;
+		a0 = (trx_v2f){ 0.0f, 0.0f };
+		a1 = (trx_v2f){ 0.0f, 0.0f };
+#pragma unroll
+		for (int m0 = 0; m0 < 20; m0 += 4) {
+			v4f_t x[4];
+#pragma unroll
+			for (int u = 0; u < 4; u++)
+				x[u] = *(lds_ptr4)(p + 2 * (m0 + u));
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				const int m = m0 + u;                                // samples 2m (a) and 2m + 1 (b) of the lane's window
+				const trx_v2f a = { x[u].x, x[u].y }, b = { x[u].z, x[u].w };
+				if (m >= 1)
+					a1 = unit_mac_k(a1, a, NEGMASK, 2 * m - 1);
+				a0 = unit_mac_k(a0, a, NEGMASK, 2 * m);
+				a0 = unit_mac_k(a0, b, NEGMASK, 2 * m + 1);
+				a1 = unit_mac_k(a1, b, NEGMASK, 2 * m);
+			}
+			__builtin_amdgcn_sched_barrier(0);
+		}
+		const c32 last = lds_c32(p + 40);
+		a1 = unit_mac_k(a1, (trx_v2f){ last.x, last.y }, NEGMASK, 39);
+	}
+};
+
+__device__ __forceinline__ void corr_unit_pair40(int slot, const c32 *p, trx_v2f &a0, trx_v2f &a1)
+{
+	switch (slot) {                                                 // wave-uniform: a scalar jump
+	case 8: UnitCorrPair40<TRX_UNIT_NEG_RACH0>::run(p, a0, a1); break;
+	case 9: UnitCorrPair40<TRX_UNIT_NEG_RACH1>::run(p, a0, a1); break;
+	default: UnitCorrPair40<TRX_UNIT_NEG_RACH2>::run(p, a0, a1); break;
+	}
+}
+
 // corr value for the sequence in LDS slot `slot` (0..7 TSC, 8..10 RACH, 19 dummy), p = &sig[i + start - (N-1)]
 __device__ __forceinline__ trx_v2f corr_unit(int slot, const c32 *p)
 {
@@ -749,11 +793,30 @@ __device__ __forceinline__ int detect_burst_h(const c32 *sig, int sig_len, c32 *
 	// N is 16 (TSC/EDGE) or 40 (RACH): tap loop unrolled by 8 so the LDS reads pipeline
 	float best = 0.0f;                               // fastPeakDetect state, fused into the same pass
 	int bidx = -1;
+	bool pair = false;                               // two adjacent lags per lane (access bursts)
 	if (wide) {
 		for (int i = lane; i < len; i += WAVE) {
 			const float v = norm2(corr_at(i));
 			if (v > best) { best = v; bidx = i; }
 		}
+	} else if (PADDED && unit_slot >= 8 && unit_slot <= 10 && N == 40 && len <= 80 && ((start - 39) & 1) == 0) {
+		// access bursts: lags 2 lane and 2 lane + 1 on lanes 0 .. 39 (corr_unit_pair40)
+		pair = true;
+		const int l2 = lane < 40 ? 2 * lane : 78;
+		trx_v2f a0, a1;
+		corr_unit_pair40(unit_slot, sig + (l2 + start - 39), a0, a1);
+		const bool in0 = lane < 40 && l2 < len, in1 = lane < 40 && l2 + 1 < len;
+		// lags >= len are not part of the correlation: zeros (cz[len ..] is the right zero pad)
+		const float4 y = make_float4(in0 ? a0.x : 0.0f, in0 ? a0.y : 0.0f, in1 ? a1.x : 0.0f, in1 ? a1.y : 0.0f);
+		if (lane < 40)
+			*reinterpret_cast<float4 *>(cz + l2) = y;
+		if (lane >= 40 && lane < 40 + TRX_CZ_PAD)
+			cz[80 + (lane - 40)] = make_float2(0.0f, 0.0f);          // with the zeros above: cz[len .. 91], the right zero pad
+		// fastPeakDetect: first strict maximum -- inside the lane lag 2l before 2l + 1, across lanes the lowest lane (below)
+		const float v0 = norm2(make_float2(y.x, y.y)), v1 = norm2(make_float2(y.z, y.w));
+		best = v0; bidx = l2;
+		if (v1 > v0) { best = v1; bidx = l2 + 1; }
+		if (!(best > 0.0f)) bidx = -1;
 	} else if (PADDED && unit_slot >= 0) {
 		for (int i = lane; i < len; i += WAVE) {
 			const trx_v2f acc = corr_unit(unit_slot, sig + (i + start - (N - 1)));
@@ -806,7 +869,10 @@ __device__ __forceinline__ int detect_burst_h(const c32 *sig, int sig_len, c32 *
 	const float m = wave_max(best);
 	if (!(m > 0.0f))
 		return 0;                                    // toa = -1 < 3
-	{
+	if (pair) {                                      // the lag index grows with the lane: the lowest lane holding the maximum
+		const unsigned long long hit = __ballot(best == m);
+		bidx = __builtin_amdgcn_readlane(bidx, __ffsll((unsigned long long)hit) - 1);
+	} else {
 		const unsigned long long hit = __ballot(best == m);
 		const unsigned long long hit_lo = __ballot(best == m && bidx == lane);
 		bidx = hit_lo ? (__ffsll((unsigned long long)hit_lo) - 1) : (64 + __ffsll((unsigned long long)hit) - 1);

@@ -165,6 +165,8 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 		   unsigned *__restrict__ pool_ctr)
 {
 	static_assert(!(COMMON && CF32), "the common instantiation reads int16 bursts");
+	static_assert(K4_TABLES_BYTES % 16 == 0 && (K4_SLICE * 8) % 16 == 0 && (K4_XS * 8) % 16 == 0 &&
+		      ((TRX_DEC_NARROW + TRX_CZ_PAD) * 8) % 16 == 0, "dec[] and cz[] are read / written 16 bytes at a time");
 	const int L = COMMON ? 625 : L_arg;
 	const int soft_stride = COMMON ? 148 : soft_stride_arg;
 	const int slice = COMMON ? TRXHIP_FLAG_SLICE : slice_arg;
@@ -349,6 +351,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 	unsigned pend_b = 0;
 	uint32_t pend_flags = 0u;
 	float pend_toa = 0.0f, pend_ax = 0.0f, pend_ay = 0.0f, pend_ci = 0.0f, pend_energy = 0.0f, pend_rssi = 0.0f;
+	int pend_word = 0;
 	auto flush = [&](int lane) {
 		if (!pend_any)
 			return;
@@ -387,16 +390,8 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 		}
 		// result record: 32 bytes, one dword per lane 0..7.  Every field is wave-uniform: v_writelane drops it into
 		// its lane (one instruction per field instead of a compare and a select)
-		int word = pend_rc;
-		word = put_lane<1>(word, pend_toa);                         // results of vector arithmetic: still in vector registers
-		word = write_lane<2>(word, __float_as_int(pend_ax));
-		word = write_lane<3>(word, __float_as_int(pend_ay));
-		word = put_lane<4>(word, pend_ci);
-		word = put_lane<5>(word, pend_energy);
-		word = put_lane<6>(word, pend_rssi);
-		word = write_lane<7>(word, (int)pend_flags);
-		if (lane < 8)
-			reinterpret_cast<int *>(results + pend_b)[lane] = word;
+		if (lane < 8)                                               // (assembled when the burst ended: one register waits, not eight)
+			reinterpret_cast<int *>(results + pend_b)[lane] = pend_word;
 		pend_any = false;
 	};
 
@@ -443,6 +438,57 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 			if (lane < 48)
 				fast_rows = reinterpret_cast<const float4 *>(&tab->edge8[fidx][0][0])[lane];
 		};
+		// The straight-line fused demodulator of the usual geometry (called below, behind detection).
+		// (Round 3 also ran access bursts through an extended form of it -- TOA up to 72 symbols, high-side partial outputs
+		// from trx_tables.edge_hi, called from the access-burst branch: + 3 % on access bursts over the general path with
+		// edge_hi, but the extra live values moved the normal burst's register allocation: + 12 vector / + 10 scalar
+		// instructions per normal burst, - 2 %.  Not kept; profiles/r03_ab_runs.txt.)
+		auto fast_demod = [&]() {
+			// ================= FUSED, usual geometry, straight-line =================
+			// (the general form below, with n_lo = 0, four low-edge outputs, no high-edge output among the 148 stored, every
+			// window inside the padded arrays: nothing left to decide per burst but the delay filter and the shift)
+			const int nk = fast_nk;
+			const int w = nk >> 7;                                      // integer shift, -36 .. 0
+			const int fr = nk & 127;
+			const int fidx = (fr >= 2) ? (fr >> 1) : TRX_DELAY_FILTS;   // delay filter row (64 = none)
+			const float ian = __builtin_amdgcn_rcpf(norm2(amp));
+			const c32 scale = make_float2(amp.x * ian, -amp.y * ian);   // 1 / amp (Complex.h:75,144-150), 1-ulp reciprocal
+			nbits = 148;
+			idle = 0;
+			// park the low-edge rows: lane l < 48 holds floats 4l .. 4l+3 of the 8 x 24 block
+			float *const stage = reinterpret_cast<float *>(dec);
+			if (lane < 48)
+				*reinterpret_cast<float4 *>(stage + 4 * lane) = fast_rows;
+			wave_sync();
+			// lanes 0..49: outputs 3l .. 3l+2 with the burst's composite row; lanes 52..55: output l - 52, main part of its
+			// truncated row; lanes 56..59: the same outputs' taps u < 8 (window 8 samples = 2 outputs earlier); the rest idle
+			const bool sp = (lane >= 52) && (lane < 60);
+			const float *const tp = sp ? stage + (lane - 52) * 24 : comp + fidx * 36 + K4_U0;
+			int ic = (lane < 50) ? 3 * lane : 150;
+			if (sp) ic = (lane < 56) ? lane - 52 : lane - 58;
+			const int c = -16 - w;                                      // tap u = 8 of output i reads sample 4i + c
+			const PhBase pb = ph_bases(P, c & 3, ic + (c >> 2));
+			v2f acc[3] = { { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f } };
+			if (!ABL(5))
+				fir24x3(pb, reinterpret_cast<const float4 *>(tp), acc);
+			// low-edge outputs: main part (lane 52 + i) + taps u < 8 (lane 56 + i), row_shl:4 inside the last row of 16
+			float er = acc[0].x, ei = acc[0].y;
+			asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0xf\n\t"
+				     "v_add_f32_dpp %1, %1, %1 row_shl:4 row_mask:0xf bank_mask:0xf" : "+v"(er), "+v"(ei));
+			wave_sync();                                                // (every lane has read its taps from dec[0..95])
+			if (lane < 50) {
+#pragma unroll
+				for (int j = 0; j < 3; j++)
+					dec[3 * lane + j] = cmul(make_float2(acc[j].x, acc[j].y), scale);
+			}
+			if (lane >= 52 && lane < 56)
+				dec[lane - 52] = cmul(make_float2(er, ei), scale);      // after lanes 0, 1 wrote their (partial) versions
+			wave_sync();
+			pend_mode = 1;
+			pend_so = so;
+			pend_nwrite = 148;
+		};
+		bool fast_done = false;
 
 		// ---- phase 0: registers -> fp32 polyphase LDS; clip scan and energyDetect partial sums on the fly
 		float amax = 0.0f, epart = 0.0f;
@@ -474,7 +520,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 			prefetch(b_next);
 		DIAG_MARK(15);
 
-		if (type != TRXHIP_OFF) {                                   // Transceiver.cpp:704-707
+		if (type != TRXHIP_OFF) {                        // Transceiver.cpp:704-707
 			// maxAmplitude() > 30000 (:1711-1722, :1746): some lane saw a larger component -- a compare and a ballot, no wave max
 			clip = __ballot(amax > TRX_CLIP_THRESH) != 0ull;
 			epart = wave_sum_quad0(epart);                          // energyDetect partial sums (lanes = 0 mod 4 hold them)
@@ -608,51 +654,8 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 		}
 #endif
 		// ---- demodAnyBurst -> demodGmskBurst (:2055-2072) ----
-		bool fast_done = false;
-		if (COMMON && !EXACT && rc == TRXHIP_TSC && fast_nk != (1 << 30) && !ABL(0)) {
-			// ================= FUSED, usual geometry, straight-line =================
-			// (the general form below, with n_lo = 0, four low-edge outputs, no high-edge output among the 148 stored, every
-			// window inside the padded arrays: nothing left to decide per burst but the delay filter and the shift)
-			const int nk = fast_nk;
-			const int w = nk >> 7;                                      // integer shift, -36 .. 0
-			const int fr = nk & 127;
-			const int fidx = (fr >= 2) ? (fr >> 1) : TRX_DELAY_FILTS;   // delay filter row (64 = none)
-			const float ian = __builtin_amdgcn_rcpf(norm2(amp));
-			const c32 scale = make_float2(amp.x * ian, -amp.y * ian);   // 1 / amp (Complex.h:75,144-150), 1-ulp reciprocal
-			nbits = 148;
-			idle = 0;
-			// park the low-edge rows: lane l < 48 holds floats 4l .. 4l+3 of the 8 x 24 block
-			float *const stage = reinterpret_cast<float *>(dec);
-			if (lane < 48)
-				*reinterpret_cast<float4 *>(stage + 4 * lane) = fast_rows;
-			wave_sync();
-			// lanes 0..49: outputs 3l .. 3l+2 with the burst's composite row; lanes 52..55: output l - 52, main part of its
-			// truncated row; lanes 56..59: the same outputs' taps u < 8 (window 8 samples = 2 outputs earlier); the rest idle
-			const bool sp = (lane >= 52) && (lane < 60);
-			const float *const tp = sp ? stage + (lane - 52) * 24 : comp + fidx * 36 + K4_U0;
-			int ic = (lane < 50) ? 3 * lane : 150;
-			if (sp) ic = (lane < 56) ? lane - 52 : lane - 58;
-			const int c = -16 - w;                                      // tap u = 8 of output i reads sample 4i + c
-			const PhBase pb = ph_bases(P, c & 3, ic + (c >> 2));
-			v2f acc[3] = { { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f } };
-			if (!ABL(5))
-				fir24x3(pb, reinterpret_cast<const float4 *>(tp), acc);
-			// low-edge outputs: main part (lane 52 + i) + taps u < 8 (lane 56 + i), row_shl:4 inside the last row of 16
-			float er = acc[0].x, ei = acc[0].y;
-			asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0xf\n\t"
-				     "v_add_f32_dpp %1, %1, %1 row_shl:4 row_mask:0xf bank_mask:0xf" : "+v"(er), "+v"(ei));
-			wave_sync();                                                // (every lane has read its taps from dec[0..95])
-			if (lane < 50) {
-#pragma unroll
-				for (int j = 0; j < 3; j++)
-					dec[3 * lane + j] = cmul(make_float2(acc[j].x, acc[j].y), scale);
-			}
-			if (lane >= 52 && lane < 56)
-				dec[lane - 52] = cmul(make_float2(er, ei), scale);      // after lanes 0, 1 wrote their (partial) versions
-			wave_sync();
-			pend_mode = 1;
-			pend_so = so;
-			pend_nwrite = 148;
+		if (COMMON && !EXACT && rc == TRXHIP_TSC && fast_nk != (1 << 30) && !fast_done && !ABL(0)) {
+			fast_demod();
 			fast_done = true;
 		}
 		if (fast_done) {
@@ -830,6 +833,21 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 					ct2 = (lt < 4) ? row[32] : 0.0f;
 				}
 
+				// High-side partial outputs the same way (trx_tables.edge_hi): a burst shifted left by w <= -2 ends at delayed
+				// sample n_hi = L - 1 + w and output i0h + e sees decimator taps t <= tm = n_hi + 15 - 4 (i0h + e) only.  Access
+				// bursts live here (TOA up to 63 symbols); the masked two-stage sum of edge_round() was a third of their time.
+								const bool hi_tab = need_hi && (w <= -2) && (n_lo <= 4 * i0h - 15) && (so || is_edge) && !ABL(6);
+				float ch0 = 0.0f, ch1 = 0.0f, ch2 = 0.0f;
+				const int hi_i = i0h + le;                                  // this row's output
+				const int htm = n_hi + 15 - 4 * hi_i;                       // last decimator tap that sees an existing sample
+				const bool hact = htm >= 0;
+				if (hi_tab) {
+					const float *row = &tab->edge_hi[fidx][hact ? htm : 0][lt];
+					ch0 = row[0];
+					ch1 = row[16];
+					ch2 = (lt < 4) ? row[32] : 0.0f;
+				}
+
 				if (so || is_edge) {
 					// ---- main filter.  Lane l owns the three ADJACENT outputs 3l, 3l+1, 3l+2 (52 lanes): their 35-tap
 					// windows overlap in 27 samples, so the lane reads 44 samples from LDS instead of 3 x 36 (sample
@@ -921,10 +939,21 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 						if (lt == 0 && lact)
 							dec[li] = cmul(make_float2(sr, si), scale);
 					}
-					if ((need_lo && !lo_tab) || need_hi)
+					if (hi_tab) {
+						const int s0 = 4 * hi_i - 24 - w + lt;
+						const c32 *pp = P + ((s0 & 3) * PH_A + PH_M0 + (s0 >> 2));
+						const c32 x0 = lds_c32(pp), x1 = lds_c32(pp + 4), x2 = lds_c32(pp + 8);
+						float ar = x0.x * ch0, ai = x0.y * ch0;
+						ar = fmaf(x1.x, ch1, ar); ai = fmaf(x1.y, ch1, ai);
+						ar = fmaf(x2.x, ch2, ar); ai = fmaf(x2.y, ch2, ai);
+						const float sr = row_sum(ar), si = row_sum(ai);
+						if (lt == 0 && hact && hi_i < 156)
+							dec[hi_i] = cmul(make_float2(sr, si), scale);
+					}
+					if ((need_lo && !lo_tab) || (need_hi && !hi_tab))
 						load_hh();                                          // only now: 20 registers the main filter does not carry
 					if (need_lo && !lo_tab && !ABL(6)) edge_round(i0l);
-					if (need_hi && !ABL(6)) edge_round(i0h);
+					if (need_hi && !hi_tab && !ABL(6)) edge_round(i0h);
 					DIAG_MARK(9);
 					wave_sync();
 
@@ -970,6 +999,17 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 			pend_ci = det ? ci : 0.0f;
 			pend_energy = energy;
 			pend_rssi = rssi;
+			{
+				int word = pend_rc;
+				word = put_lane<1>(word, pend_toa);                     // results of vector arithmetic: still in vector registers
+				word = write_lane<2>(word, __float_as_int(pend_ax));
+				word = write_lane<3>(word, __float_as_int(pend_ay));
+				word = put_lane<4>(word, pend_ci);
+				word = put_lane<5>(word, pend_energy);
+				word = put_lane<6>(word, pend_rssi);
+				word = write_lane<7>(word, (int)pend_flags);
+				pend_word = word;
+			}
 			pend_b = b;
 			pend_any = true;
 		}

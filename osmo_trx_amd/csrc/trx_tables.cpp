@@ -438,6 +438,20 @@ private:
 					t_->edge8[f][i][k] = t_->edge_lo[f][14 - 4 * i][8 + k];
 					t_->edge8[f][4 + i][k] = (k < 8) ? t_->edge_lo[f][14 - 4 * i][k] : 0.0f;
 				}
+		// high side: the decimator truncated to taps t <= tm
+		for (int f = 0; f <= TRX_DELAY_FILTS; f++)
+			for (int tm = 0; tm <= 14; tm++)
+				for (int u = 0; u < 36; u++) {
+					double acc = 0.0;
+					for (int t = 0; t <= tm; t++) {
+						const int k = u - t;
+						if (k < 0 || k >= TRX_DELAY_HLEN)
+							continue;
+						const double h = (f < TRX_DELAY_FILTS) ? (double)t_->delay_filt[f][k] : (k == 9 ? 1.0 : 0.0);
+						acc += (double)t_->dec_taps[t] * h;
+					}
+					t_->edge_hi[f][tm][u] = (u < 35) ? (float)acc : 0.0f;
+				}
 	}
 
 	// EDGE 8-PSK demodulator constants, with the float/double steps of the reference

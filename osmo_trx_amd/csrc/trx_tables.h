@@ -74,11 +74,15 @@ struct trx_tables {
 	//                                                                     samples early (lanes 56..59); taps u >= 32 are 0
 	float    edge8_pad[2];                              // (edge8 at a multiple of 16 bytes)
 	float    edge8[TRX_DELAY_FILTS + 1][8][24];
+	// high-side partial outputs (a burst delayed by a negative whole shift w <= -2 ends at delayed sample n_hi = L - 1 + w:
+	// output i only sees decimator taps t <= tm = n_hi + 15 - 4i, 0..14).  Composite of delay filter f with the decimator
+	// truncated to t <= tm:  edge_hi[f][tm][u] = sum_{t<=tm, t+k=u} g[t]*h_f[k]  (u <= tm + 19; 0 beyond)
+	float    edge_hi[TRX_DELAY_FILTS + 1][15][36];
 };
 static_assert(offsetof(trx_tables, edge8) % 16 == 0, "edge8 rows are fetched as float4");
 
 #define TRX_TABLES_MAGIC   0x54585254u
-#define TRX_TABLES_VERSION 5u
+#define TRX_TABLES_VERSION 6u
 
 // XOR swizzle of the sincv index: conflict-free LDS gathers both for lanes whose positions differ
 // by multiples of 16/512 (coarse bisection levels) and by 1/512 steps (fine levels).

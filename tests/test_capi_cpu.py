@@ -45,7 +45,8 @@ BLOB = np.dtype([("magic", "<u4"), ("version", "<u4"), ("dec_taps", "<f4", 16), 
                  ("comp_filt", "<f4", (65, 36)), ("edge_derot", "<c8", 16), ("edge_ideal", "<c8", 9),
                  ("edge_rot2", "<c8", 2), ("edge_step", "<f4"), ("edge_pad", "<f4"),
                  ("unit_neg", "<u8", 21), ("unit_ok", "<u4"), ("unit_pad", "<u4"),
-                 ("edge_lo", "<f4", (65, 15, 36)), ("edge8_pad", "<f4", 2), ("edge8", "<f4", (65, 8, 24))])
+                 ("edge_lo", "<f4", (65, 15, 36)), ("edge8_pad", "<f4", 2), ("edge8", "<f4", (65, 8, 24)),
+                 ("edge_hi", "<f4", (65, 15, 36))])
 
 
 def test_tables_bit_identical_to_oracle(lib):
@@ -101,6 +102,17 @@ def test_tables_bit_identical_to_oracle(lib):
             np.testing.assert_allclose(t["edge_lo"][f][t0 - 1][:35], ref, rtol=1e-7, atol=1e-12)
             assert t["edge_lo"][f][t0 - 1][35] == 0
     assert np.array_equal(t["edge_lo"][64][6][9 + 7:25], o["dec_taps"][7:]) and not t["edge_lo"][64][6][:16].any()
+    # ... and of the high-side ones (bursts shifted left by a large TOA: access bursts): decimator taps t <= tm only
+    for f in (0, 17, 63):
+        for tm in (0, 2, 7, 11, 14):
+            g = o["dec_taps"].astype(np.float64).copy()
+            g[tm + 1:] = 0.0
+            ref = np.convolve(g, o["delay_filt"][f].astype(np.float64))
+            np.testing.assert_allclose(t["edge_hi"][f][tm][:35], ref, rtol=1e-7, atol=1e-12)
+            assert t["edge_hi"][f][tm][35] == 0
+    assert np.array_equal(t["edge_hi"][64][6][9:16], o["dec_taps"][:7]) and not t["edge_hi"][64][6][16:].any()
+    # low + high truncations at the same cut add up to the full composite
+    np.testing.assert_allclose(t["edge_lo"][:, 7, :] + t["edge_hi"][:, 7, :], t["comp_filt"], rtol=0, atol=2e-7)
     # the usual-geometry repack the main filter loop consumes (trx_tables.h, edge8): rows of outputs 0..3 from tap 8 on,
     # their taps below 8 as separate rows; nothing is lost by the 32-tap window (tap 0 and taps >= 32 are exactly zero)
     assert not t["edge_lo"][:, :, 32:].any() and not t["edge_lo"][:, :, 0].any()
