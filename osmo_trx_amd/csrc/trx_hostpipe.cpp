@@ -5,6 +5,13 @@
 // HIP stream.  A submitted slot runs H2D -> detect/demod [-> TRXD wire packer] -> D2H on its own stream, so the
 // upload of one slot, the kernels of another and the download of a third overlap (the two DMA directions and the
 // compute queue are independent engines).  Everything is allocated in create(); submit() only enqueues.
+//
+// Round 3: a batch is FIVE enqueues, not ten.  A slot's inputs are one pinned block and one device block with the same
+// layout ([params][meta][bursts]: one H2D copy of the used prefix), its results and soft rows one device block and one
+// pinned block ([results][soft rows]: one D2H copy), and the TRXD packer writes datagrams and lengths straight into the
+// pinned buffers (they are device-visible; 160 bytes per burst over the link, posted writes).  A round trip of a
+// 256-burst batch through an idle pipe went from 86-100 us to what tools/bench_hostpipe_rt.py prints now -- the gather
+// stage under the reference's 32-deep FIFO rule is bound by exactly this latency.
 #include <hip/hip_runtime.h>
 
 #include <cstring>
@@ -16,12 +23,16 @@ struct trxhip_hostpipe {
 	trxhip_ctx *ctx;
 	trxhip_hostpipe_cfg cfg;
 	int dev_soft_stride;               /* stride of the device-side soft rows (>= what the packer needs) */
+	size_t in_iq_off, in_meta_off;     /* [params][meta][bursts] inside the input blocks */
+	size_t out_soft_off;               /* [results][soft rows] inside the output blocks */
 	struct Slot {
 		hipStream_t stream;
 		hipEvent_t done;
 		bool busy, failed;
 		size_t n;
-		trxhip_hostpipe_slot h;        /* pinned host */
+		trxhip_hostpipe_slot h;        /* pinned host (views into h_in / h_out; pkt, pkt_len separate) */
+		char *h_in, *d_in;             /* one block each: params, meta, bursts */
+		char *h_out, *d_out;           /* one block each: results, soft rows */
 		int16_t *d_iq;
 		int16_t *d_iq_sel;             /* n_paths > 1: the chosen path of every burst */
 		float *d_avg;                  /* n_paths > 1: path-averaged energy */
@@ -29,8 +40,8 @@ struct trxhip_hostpipe {
 		trxhip_trxd_meta *d_meta;
 		trxhip_burst_result *d_results;
 		float *d_soft;
-		uint8_t *d_pkt;
-		uint16_t *d_pkt_len;
+		uint8_t *dv_pkt;               /* device-side addresses of the pinned h.pkt / h.pkt_len */
+		uint16_t *dv_pkt_len;
 	} slot[16];
 };
 
@@ -70,23 +81,37 @@ int trxhip_hostpipe_create(trxhip_ctx *ctx, const trxhip_hostpipe_cfg *c, trxhip
 	p->dev_soft_stride = c->soft_stride ? c->soft_stride : (c->pkt_stride >= TRXHIP_TRXD_V1_HDR + 444 ? 444 : 148);
 	const size_t nb = c->max_bursts;
 	const size_t np = c->n_paths > 1 ? (size_t)c->n_paths : 1;
+	auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+	p->in_meta_off = up(nb * sizeof(trxhip_burst_params));
+	p->in_iq_off = p->in_meta_off + (c->pkt_stride ? up(nb * sizeof(trxhip_trxd_meta)) : 0);
+	const size_t in_bytes = p->in_iq_off + nb * np * c->burst_len * 4;
+	p->out_soft_off = up(nb * sizeof(trxhip_burst_result));
+	const size_t out_bytes_h = p->out_soft_off + (c->soft_stride ? nb * c->soft_stride * sizeof(float) : 0);
+	const size_t out_bytes_d = p->out_soft_off + nb * p->dev_soft_stride * sizeof(float);
 	bool ok = true;
 	for (int s = 0; s < c->depth && ok; s++) {
 		trxhip_hostpipe::Slot &sl = p->slot[s];
 		ok = hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) == hipSuccess &&
 		     hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) == hipSuccess &&
-		     pin((void **)&sl.h.iq, nb * np * c->burst_len * 4) && pin((void **)&sl.h.params, nb * sizeof(trxhip_burst_params)) &&
-		     pin((void **)&sl.h.results, nb * sizeof(trxhip_burst_result)) &&
-		     dev((void **)&sl.d_iq, nb * np * c->burst_len * 4) && dev((void **)&sl.d_params, nb * sizeof(trxhip_burst_params)) &&
-		     (np == 1 || (dev((void **)&sl.d_iq_sel, nb * c->burst_len * 4) && dev((void **)&sl.d_avg, nb * sizeof(float)))) &&
-		     dev((void **)&sl.d_results, nb * sizeof(trxhip_burst_result)) &&
-		     dev((void **)&sl.d_soft, nb * p->dev_soft_stride * sizeof(float));
-		if (ok && c->soft_stride)
-			ok = pin((void **)&sl.h.soft, nb * c->soft_stride * sizeof(float));
-		if (ok && c->pkt_stride)
-			ok = pin((void **)&sl.h.meta, nb * sizeof(trxhip_trxd_meta)) && pin((void **)&sl.h.pkt, nb * c->pkt_stride) &&
-			     pin((void **)&sl.h.pkt_len, nb * sizeof(uint16_t)) && dev((void **)&sl.d_meta, nb * sizeof(trxhip_trxd_meta)) &&
-			     dev((void **)&sl.d_pkt, nb * c->pkt_stride) && dev((void **)&sl.d_pkt_len, nb * sizeof(uint16_t));
+		     pin((void **)&sl.h_in, in_bytes) && dev((void **)&sl.d_in, in_bytes) &&
+		     pin((void **)&sl.h_out, out_bytes_h) && dev((void **)&sl.d_out, out_bytes_d) &&
+		     (np == 1 || (dev((void **)&sl.d_iq_sel, nb * c->burst_len * 4) && dev((void **)&sl.d_avg, nb * sizeof(float))));
+		if (!ok)
+			break;
+		sl.h.params = reinterpret_cast<trxhip_burst_params *>(sl.h_in);
+		sl.h.meta = c->pkt_stride ? reinterpret_cast<trxhip_trxd_meta *>(sl.h_in + p->in_meta_off) : nullptr;
+		sl.h.iq = reinterpret_cast<int16_t *>(sl.h_in + p->in_iq_off);
+		sl.d_params = reinterpret_cast<trxhip_burst_params *>(sl.d_in);
+		sl.d_meta = c->pkt_stride ? reinterpret_cast<trxhip_trxd_meta *>(sl.d_in + p->in_meta_off) : nullptr;
+		sl.d_iq = reinterpret_cast<int16_t *>(sl.d_in + p->in_iq_off);
+		sl.h.results = reinterpret_cast<trxhip_burst_result *>(sl.h_out);
+		sl.h.soft = c->soft_stride ? reinterpret_cast<float *>(sl.h_out + p->out_soft_off) : nullptr;
+		sl.d_results = reinterpret_cast<trxhip_burst_result *>(sl.d_out);
+		sl.d_soft = reinterpret_cast<float *>(sl.d_out + p->out_soft_off);
+		if (c->pkt_stride)
+			ok = pin((void **)&sl.h.pkt, nb * c->pkt_stride) && pin((void **)&sl.h.pkt_len, nb * sizeof(uint16_t)) &&
+			     hipHostGetDevicePointer((void **)&sl.dv_pkt, sl.h.pkt, 0) == hipSuccess &&
+			     hipHostGetDevicePointer((void **)&sl.dv_pkt_len, sl.h.pkt_len, 0) == hipSuccess;
 	}
 	if (!ok) {
 		trxhip_hostpipe_destroy(p);
@@ -104,9 +129,9 @@ void trxhip_hostpipe_destroy(trxhip_hostpipe *p)
 	for (int s = 0; s < 16; s++) {
 		trxhip_hostpipe::Slot &sl = p->slot[s];
 		if (sl.stream) (void)hipStreamSynchronize(sl.stream);
-		void *hp[] = { sl.h.iq, sl.h.params, sl.h.meta, sl.h.results, sl.h.soft, sl.h.pkt, sl.h.pkt_len };
+		void *hp[] = { sl.h_in, sl.h_out, sl.h.pkt, sl.h.pkt_len };
 		for (void *q : hp) if (q) (void)hipHostFree(q);
-		void *dp[] = { sl.d_iq, sl.d_iq_sel, sl.d_avg, sl.d_params, sl.d_meta, sl.d_results, sl.d_soft, sl.d_pkt, sl.d_pkt_len };
+		void *dp[] = { sl.d_in, sl.d_out, sl.d_iq_sel, sl.d_avg };
 		for (void *q : dp) if (q) (void)hipFree(q);
 		if (sl.done) (void)hipEventDestroy(sl.done);
 		if (sl.stream) (void)hipStreamDestroy(sl.stream);
@@ -148,10 +173,8 @@ int trxhip_hostpipe_submit(trxhip_hostpipe *p, int slot, size_t n)
 		return TRXHIP_EIO;
 	hipStream_t st = sl.stream;
 	const size_t np = c.n_paths > 1 ? (size_t)c.n_paths : 1;
-	bool ok = hipMemcpyAsync(sl.d_iq, sl.h.iq, n * np * c.burst_len * 4, hipMemcpyHostToDevice, st) == hipSuccess &&
-		  hipMemcpyAsync(sl.d_params, sl.h.params, n * sizeof(trxhip_burst_params), hipMemcpyHostToDevice, st) == hipSuccess;
-	if (ok && c.pkt_stride)
-		ok = hipMemcpyAsync(sl.d_meta, sl.h.meta, n * sizeof(trxhip_trxd_meta), hipMemcpyHostToDevice, st) == hipSuccess;
+	/* one upload: [params][meta][the n bursts] */
+	bool ok = hipMemcpyAsync(sl.d_in, sl.h_in, p->in_iq_off + n * np * c.burst_len * 4, hipMemcpyHostToDevice, st) == hipSuccess;
 	int rc = ok ? TRXHIP_OK : TRXHIP_EIO;
 	const int16_t *d_bursts = sl.d_iq;
 	if (rc == TRXHIP_OK && np > 1) {                              /* Transceiver.cpp:723-741: the path with the highest energy */
@@ -163,16 +186,13 @@ int trxhip_hostpipe_submit(trxhip_hostpipe *p, int slot, size_t n)
 					       c.threshold, c.full_scale, p->dev_soft_stride, c.flags, st);
 	if (rc == TRXHIP_OK && np > 1)                                /* :741, :751: rssi from the path average */
 		rc = trxhip_apply_diversity_power(p->ctx, sl.d_results, sl.d_params, sl.d_avg, n, c.full_scale, st);
-	if (rc == TRXHIP_OK && c.pkt_stride)
-		rc = trxhip_pack_trxd_wire_batch(p->ctx, sl.d_results, sl.d_params, sl.d_soft, p->dev_soft_stride, sl.d_meta, sl.d_pkt,
-						 c.pkt_stride, sl.d_pkt_len, n, c.rssi_offset, st);
+	if (rc == TRXHIP_OK && c.pkt_stride)                          /* datagrams and lengths: straight into the pinned buffers */
+		rc = trxhip_pack_trxd_wire_batch(p->ctx, sl.d_results, sl.d_params, sl.d_soft, p->dev_soft_stride, sl.d_meta, sl.dv_pkt,
+						 c.pkt_stride, sl.dv_pkt_len, n, c.rssi_offset, st);
+	/* one download: [results][the n soft rows] */
 	ok = rc == TRXHIP_OK &&
-	     hipMemcpyAsync(sl.h.results, sl.d_results, n * sizeof(trxhip_burst_result), hipMemcpyDeviceToHost, st) == hipSuccess;
-	if (ok && c.soft_stride)
-		ok = hipMemcpyAsync(sl.h.soft, sl.d_soft, n * c.soft_stride * sizeof(float), hipMemcpyDeviceToHost, st) == hipSuccess;
-	if (ok && c.pkt_stride)
-		ok = hipMemcpyAsync(sl.h.pkt, sl.d_pkt, n * (size_t)c.pkt_stride, hipMemcpyDeviceToHost, st) == hipSuccess &&
-		     hipMemcpyAsync(sl.h.pkt_len, sl.d_pkt_len, n * sizeof(uint16_t), hipMemcpyDeviceToHost, st) == hipSuccess;
+	     hipMemcpyAsync(sl.h_out, sl.d_out, c.soft_stride ? p->out_soft_off + n * c.soft_stride * sizeof(float)
+							       : n * sizeof(trxhip_burst_result), hipMemcpyDeviceToHost, st) == hipSuccess;
 	if (ok)
 		ok = hipEventRecord(sl.done, st) == hipSuccess;
 	sl.busy = true;                                            /* even on failure: wait() drains what was enqueued */
