@@ -583,7 +583,8 @@ __device__ __forceinline__ uint32_t trxd_byte(int p, int hdr_len, int nbits, boo
 __global__ void __launch_bounds__(256)
 pack_trxd_wire_kernel(const trxhip_burst_result *__restrict__ res, const trxhip_burst_params *__restrict__ prm,
 		      const float *__restrict__ soft, int soft_stride, const trxhip_trxd_meta *__restrict__ meta,
-		      uint8_t *__restrict__ pkt, int pkt_stride, uint16_t *__restrict__ pkt_len, size_t n_bursts, float rssi_offset)
+		      uint8_t *__restrict__ pkt, int pkt_stride, uint16_t *__restrict__ pkt_len, size_t n_bursts, float rssi_offset,
+		      trxhip_burst_result *__restrict__ res_copy)
 {
 	const int wpb = pkt_stride >> 2;                                     // dwords per burst
 	const size_t total = n_bursts * (size_t)wpb;
@@ -629,8 +630,11 @@ pack_trxd_wire_kernel(const trxhip_burst_result *__restrict__ res, const trxhip_
 				word |= trxd_byte(p, hdr_len, nbits, v1, hdr, s) << (8 * k);
 		}
 		out[o] = word;
-		if (wd == 0)
+		if (wd == 0) {
 			pkt_len[b] = (uint16_t)len;
+			if (res_copy)                                                // (host pipe: the record goes out with the datagram)
+				res_copy[b] = r;
+		}
 	}
 }
 
@@ -649,7 +653,8 @@ __device__ __forceinline__ uint32_t trxd_q255(float x)
 __global__ void __launch_bounds__(256)
 pack_trxd_wire16_kernel(const trxhip_burst_result *__restrict__ res, const trxhip_burst_params *__restrict__ prm,
 			const float *__restrict__ soft, int soft_stride, const trxhip_trxd_meta *__restrict__ meta,
-			uint8_t *__restrict__ pkt, int pkt_stride, uint16_t *__restrict__ pkt_len, unsigned n_bursts, float rssi_offset)
+			uint8_t *__restrict__ pkt, int pkt_stride, uint16_t *__restrict__ pkt_len, unsigned n_bursts, float rssi_offset,
+			trxhip_burst_result *__restrict__ res_copy)
 {
 	const unsigned cpb = (unsigned)pkt_stride >> 4;                      // 16-byte chunks per burst
 	const unsigned total = n_bursts * cpb;                               // (the launcher keeps this below 2^32)
@@ -688,6 +693,8 @@ pack_trxd_wire16_kernel(const trxhip_burst_result *__restrict__ res, const trxhi
 			for (int k = 0; k < TRXHIP_TRXD_V1_HDR; k++) hdr[k] = 0;
 			if (p0 == 0) {                                               // the header lives in the first chunk (hdr_len <= 11)
 				const trxhip_burst_result r = res[b];
+				if (res_copy)                                                // (host pipe: the record goes out with the datagram)
+					res_copy[b] = r;
 				hdr[0] = (uint8_t)(((v1 ? 1u : 0u) << 4) | (m.tn & 7u));     // trxd_fill_common(): version:4 | reserved:1 | tn:3
 				hdr[1] = (uint8_t)(m.fn >> 24); hdr[2] = (uint8_t)(m.fn >> 16); hdr[3] = (uint8_t)(m.fn >> 8); hdr[4] = (uint8_t)m.fn;
 				const double rssi = (double)r.rssi + (double)rssi_offset;    // bi->rssi (Transceiver.cpp:751)
@@ -708,14 +715,18 @@ pack_trxd_wire16_kernel(const trxhip_burst_result *__restrict__ res, const trxhi
 			}
 		}
 		out[o] = make_uint4(w[0], w[1], w[2], w[3]);
-		if (p0 == 0)
+		if (p0 == 0) {
 			pkt_len[b] = (uint16_t)len;
+			if (res_copy && !(p0 < len))                                 // (nothing to send: the header branch did not run)
+				res_copy[b] = res[b];
+		}
 	}
 }
 
 extern "C" int trx_launch_pack_trxd_wire(const trxhip_burst_result *d_results, const trxhip_burst_params *d_params,
 					 const float *d_soft, int soft_stride, const trxhip_trxd_meta *d_meta, uint8_t *d_pkt,
-					 int pkt_stride, uint16_t *d_pkt_len, size_t n_bursts, float rssi_offset, hipStream_t stream)
+					 int pkt_stride, uint16_t *d_pkt_len, size_t n_bursts, float rssi_offset, hipStream_t stream,
+					 trxhip_burst_result *d_results_copy)
 {
 	if (n_bursts == 0)
 		return 0;
@@ -723,13 +734,13 @@ extern "C" int trx_launch_pack_trxd_wire(const trxhip_burst_result *d_results, c
 		size_t blocks16 = (n_bursts * (size_t)(pkt_stride >> 4) + 255) / 256;
 		if (blocks16 > 256 * 16) blocks16 = 256 * 16;
 		hipLaunchKernelGGL(pack_trxd_wire16_kernel, dim3((unsigned)blocks16), dim3(256), 0, stream, d_results, d_params, d_soft,
-				   soft_stride, d_meta, d_pkt, pkt_stride, d_pkt_len, (unsigned)n_bursts, rssi_offset);
+				   soft_stride, d_meta, d_pkt, pkt_stride, d_pkt_len, (unsigned)n_bursts, rssi_offset, d_results_copy);
 		return hipGetLastError() == hipSuccess ? 0 : TRXHIP_EIO;
 	}
 	size_t blocks = (n_bursts * (size_t)(pkt_stride >> 2) + 255) / 256;
 	if (blocks > 256 * 8) blocks = 256 * 8;
 	hipLaunchKernelGGL(pack_trxd_wire_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d_results, d_params, d_soft,
-			   soft_stride, d_meta, d_pkt, pkt_stride, d_pkt_len, n_bursts, rssi_offset);
+			   soft_stride, d_meta, d_pkt, pkt_stride, d_pkt_len, n_bursts, rssi_offset, d_results_copy);
 	return hipGetLastError() == hipSuccess ? 0 : TRXHIP_EIO;
 }
 

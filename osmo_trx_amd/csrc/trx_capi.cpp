@@ -19,9 +19,6 @@ extern "C" int trx_launch_pull(unsigned *d_pool_ctr, const void *d_iq, int cf32,
 extern "C" int trx_unit_masks_match(const trx_tables *t);       /* trx_kernel4.hip: compiled-in sign masks vs the tables */
 extern "C" int trx_launch_pack_trxd(const trxhip_burst_result *d_results, const float *d_soft, int soft_stride,
 				    uint8_t *d_pkt, size_t n_bursts, float rssi_offset, hipStream_t stream);
-extern "C" int trx_launch_pack_trxd_wire(const trxhip_burst_result *d_results, const trxhip_burst_params *d_params,
-					 const float *d_soft, int soft_stride, const trxhip_trxd_meta *d_meta, uint8_t *d_pkt,
-					 int pkt_stride, uint16_t *d_pkt_len, size_t n_bursts, float rssi_offset, hipStream_t stream);
 extern "C" int trx_launch_convolve(const float *d_x, int x_len, const float *d_h, int h_len, int h_complex,
 				   float *d_y, int y_len, int start, int len, size_t n_vec, hipStream_t stream);
 extern "C" int trx_launch_convert_short_float(float *d_out, const int16_t *d_in, size_t len, hipStream_t stream);
@@ -300,7 +297,7 @@ int trxhip_pack_trxd_wire_batch(trxhip_ctx *ctx, const trxhip_burst_result *d_re
 	if (with_device(ctx))
 		return TRXHIP_EIO;
 	return trx_launch_pack_trxd_wire(d_results, d_params, d_soft_sliced, soft_stride, d_meta, d_pkt, pkt_stride, d_pkt_len,
-					 n_bursts, rssi_offset, static_cast<hipStream_t>(stream));
+					 n_bursts, rssi_offset, static_cast<hipStream_t>(stream), nullptr);
 }
 
 static int conv_common(trxhip_ctx *ctx, const float *d_x, int x_len, const float *d_h, int h_len, int h_complex,

@@ -18,6 +18,13 @@ struct trxhip_ctx {
 };
 #define TRX_POOL_SLOTS 64
 
+/* the TRXD wire packer's launcher (trx_aux_kernels.hip); d_results_copy (may be NULL): every result record is also written
+ * there -- the host pipe points it at pinned memory and saves the download */
+extern "C" int trx_launch_pack_trxd_wire(const trxhip_burst_result *d_results, const trxhip_burst_params *d_params,
+					 const float *d_soft, int soft_stride, const trxhip_trxd_meta *d_meta, uint8_t *d_pkt,
+					 int pkt_stride, uint16_t *d_pkt_len, size_t n_bursts, float rssi_offset, hipStream_t stream,
+					 trxhip_burst_result *d_results_copy);
+
 static inline int with_device(const trxhip_ctx *ctx)
 {
 	return hipSetDevice(ctx->device) == hipSuccess ? 0 : TRXHIP_EIO;

@@ -14,6 +14,7 @@
 // stage under the reference's 32-deep FIFO rule is bound by exactly this latency.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -32,6 +33,7 @@ struct trxhip_hostpipe {
 		size_t n;
 		trxhip_hostpipe_slot h;        /* pinned host (views into h_in / h_out; pkt, pkt_len separate) */
 		char *h_in, *d_in;             /* one block each: params, meta, bursts */
+		char *dv_in;                   /* device-side address of the pinned input block (small batches are read in place) */
 		char *h_out, *d_out;           /* one block each: results, soft rows */
 		int16_t *d_iq;
 		int16_t *d_iq_sel;             /* n_paths > 1: the chosen path of every burst */
@@ -42,11 +44,15 @@ struct trxhip_hostpipe {
 		float *d_soft;
 		uint8_t *dv_pkt;               /* device-side addresses of the pinned h.pkt / h.pkt_len */
 		uint16_t *dv_pkt_len;
+		trxhip_burst_result *dv_results; /* ... of h.results (TRXD-only pipes: the packer delivers the records too) */
 	} slot[16];
 };
 
+static bool dev_soft_ok(const trxhip_hostpipe *p);
 static bool pin(void **p, size_t bytes) { return hipHostMalloc(p, bytes ? bytes : 16, hipHostMallocDefault) == hipSuccess; }
 static bool dev(void **p, size_t bytes) { return hipMalloc(p, bytes ? bytes : 16) == hipSuccess; }
+
+static bool dev_soft_ok(const trxhip_hostpipe *p) { return p->dev_soft_stride >= 148 && p->cfg.pkt_stride >= 160 && !(p->cfg.pkt_stride & 3); }
 
 extern "C" {
 
@@ -94,6 +100,7 @@ int trxhip_hostpipe_create(trxhip_ctx *ctx, const trxhip_hostpipe_cfg *c, trxhip
 		ok = hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) == hipSuccess &&
 		     hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) == hipSuccess &&
 		     pin((void **)&sl.h_in, in_bytes) && dev((void **)&sl.d_in, in_bytes) &&
+		     hipHostGetDevicePointer((void **)&sl.dv_in, sl.h_in, 0) == hipSuccess &&
 		     pin((void **)&sl.h_out, out_bytes_h) && dev((void **)&sl.d_out, out_bytes_d) &&
 		     (np == 1 || (dev((void **)&sl.d_iq_sel, nb * c->burst_len * 4) && dev((void **)&sl.d_avg, nb * sizeof(float))));
 		if (!ok)
@@ -111,7 +118,8 @@ int trxhip_hostpipe_create(trxhip_ctx *ctx, const trxhip_hostpipe_cfg *c, trxhip
 		if (c->pkt_stride)
 			ok = pin((void **)&sl.h.pkt, nb * c->pkt_stride) && pin((void **)&sl.h.pkt_len, nb * sizeof(uint16_t)) &&
 			     hipHostGetDevicePointer((void **)&sl.dv_pkt, sl.h.pkt, 0) == hipSuccess &&
-			     hipHostGetDevicePointer((void **)&sl.dv_pkt_len, sl.h.pkt_len, 0) == hipSuccess;
+			     hipHostGetDevicePointer((void **)&sl.dv_pkt_len, sl.h.pkt_len, 0) == hipSuccess &&
+			     hipHostGetDevicePointer((void **)&sl.dv_results, sl.h.results, 0) == hipSuccess;
 	}
 	if (!ok) {
 		trxhip_hostpipe_destroy(p);
@@ -173,26 +181,39 @@ int trxhip_hostpipe_submit(trxhip_hostpipe *p, int slot, size_t n)
 		return TRXHIP_EIO;
 	hipStream_t st = sl.stream;
 	const size_t np = c.n_paths > 1 ? (size_t)c.n_paths : 1;
-	/* one upload: [params][meta][the n bursts] */
-	bool ok = hipMemcpyAsync(sl.d_in, sl.h_in, p->in_iq_off + n * np * c.burst_len * 4, hipMemcpyHostToDevice, st) == hipSuccess;
+	/* one upload: [params][meta][the n bursts] -- or none: a small batch is read by the kernels where it lies (pinned memory
+	 * is device-visible; the detector fetches every sample once, one burst ahead, so the link's latency is covered the way
+	 * HBM's is and the copy engine's start-up cost -- more than such a transfer itself -- is not paid) */
+	static const size_t zc_max = getenv("TRXHIP_HOSTPIPE_ZC") ? (size_t)atol(getenv("TRXHIP_HOSTPIPE_ZC")) : 1024;   /* bursts x paths */
+	const bool in_place = n * np <= zc_max;
+	const char *const in = in_place ? sl.dv_in : sl.d_in;
+	bool ok = in_place || hipMemcpyAsync(sl.d_in, sl.h_in, p->in_iq_off + n * np * c.burst_len * 4, hipMemcpyHostToDevice, st) == hipSuccess;
 	int rc = ok ? TRXHIP_OK : TRXHIP_EIO;
-	const int16_t *d_bursts = sl.d_iq;
+	const int16_t *d_bursts = reinterpret_cast<const int16_t *>(in + p->in_iq_off);
+	const trxhip_burst_params *const d_params = reinterpret_cast<const trxhip_burst_params *>(in);
+	const trxhip_trxd_meta *const d_meta = reinterpret_cast<const trxhip_trxd_meta *>(in + p->in_meta_off);
 	if (rc == TRXHIP_OK && np > 1) {                              /* Transceiver.cpp:723-741: the path with the highest energy */
-		rc = trxhip_select_diversity_batch(p->ctx, sl.d_iq, n, (int)np, c.burst_len, c.sps, sl.d_iq_sel, sl.d_avg, nullptr, st);
+		rc = trxhip_select_diversity_batch(p->ctx, d_bursts, n, (int)np, c.burst_len, c.sps, sl.d_iq_sel, sl.d_avg, nullptr, st);
 		d_bursts = sl.d_iq_sel;
 	}
 	if (rc == TRXHIP_OK)
-		rc = trxhip_detect_demod_batch(p->ctx, d_bursts, sl.d_params, sl.d_results, sl.d_soft, n, c.burst_len, c.sps,
+		rc = trxhip_detect_demod_batch(p->ctx, d_bursts, d_params, sl.d_results, sl.d_soft, n, c.burst_len, c.sps,
 					       c.threshold, c.full_scale, p->dev_soft_stride, c.flags, st);
 	if (rc == TRXHIP_OK && np > 1)                                /* :741, :751: rssi from the path average */
-		rc = trxhip_apply_diversity_power(p->ctx, sl.d_results, sl.d_params, sl.d_avg, n, c.full_scale, st);
-	if (rc == TRXHIP_OK && c.pkt_stride)                          /* datagrams and lengths: straight into the pinned buffers */
-		rc = trxhip_pack_trxd_wire_batch(p->ctx, sl.d_results, sl.d_params, sl.d_soft, p->dev_soft_stride, sl.d_meta, sl.dv_pkt,
-						 c.pkt_stride, sl.dv_pkt_len, n, c.rssi_offset, st);
-	/* one download: [results][the n soft rows] */
+		rc = trxhip_apply_diversity_power(p->ctx, sl.d_results, d_params, sl.d_avg, n, c.full_scale, st);
+	const bool records_by_packer = c.pkt_stride && !c.soft_stride;
+	if (rc == TRXHIP_OK && c.pkt_stride) {                        /* datagrams and lengths: straight into the pinned buffers */
+		if (dev_soft_ok(p))
+			rc = trx_launch_pack_trxd_wire(sl.d_results, d_params, sl.d_soft, p->dev_soft_stride, d_meta, sl.dv_pkt, c.pkt_stride,
+						       sl.dv_pkt_len, n, c.rssi_offset, st, records_by_packer ? sl.dv_results : nullptr);
+		else
+			rc = TRXHIP_EINVAL;
+	}
+	/* one download: [results][the n soft rows] (none when the packer has delivered the records) */
 	ok = rc == TRXHIP_OK &&
-	     hipMemcpyAsync(sl.h_out, sl.d_out, c.soft_stride ? p->out_soft_off + n * c.soft_stride * sizeof(float)
-							       : n * sizeof(trxhip_burst_result), hipMemcpyDeviceToHost, st) == hipSuccess;
+	     (records_by_packer ||
+	      hipMemcpyAsync(sl.h_out, sl.d_out, c.soft_stride ? p->out_soft_off + n * c.soft_stride * sizeof(float)
+							        : n * sizeof(trxhip_burst_result), hipMemcpyDeviceToHost, st) == hipSuccess);
 	if (ok)
 		ok = hipEventRecord(sl.done, st) == hipSuccess;
 	sl.busy = true;                                            /* even on failure: wait() drains what was enqueued */
