@@ -249,10 +249,10 @@ def config3_leg(trx, synth, shard, dev, rank, world, out, roof):
         wall_e, ms_e = timed_passes(front_and_detect, shard, dev, world, passes=3)
         found = int((trx.results_to_numpy(res_c)["rc"] > 0).sum())
         n_out = nb * 192 // 48 * 65
-        fe_bytes = nb * (768 * 4 + 2 * 4 * 192 * 8) + 4 * n_out * 8          # wideband in, channelizer out + in again, resampled out
+        fe_bytes = nb * 768 * 4 + 4 * n_out * 8     # wideband in, resampled out (the channel-rate streams stay on the chip since round 3)
         out["configs[3]"] = {
-            "workload": f"4-ARFCN Channelizer(4,192,16) + Resampler(65,48) over {nb} blocks of 768 wideband int16 samples per GPU "
-                        f"(streaming, carried history), then detect+demod of the {3 * n_slots} timeslots of the 3 carriers",
+            "workload": f"4-ARFCN Channelizer(4,192,16) + Resampler(65,48) in one pass (frontend_fused_kernel) over {nb} blocks of 768 "
+                        f"wideband int16 samples per GPU (streaming, carried history), then detect+demod of the {3 * n_slots} timeslots of the 3 carriers",
             "front_end_mblocks_per_s_all_gpus": round(5 * nb * world / wall_f / 1e6, 2), "front_end_ms": round(ms_f, 4),
             "front_end_roofline": roof(fe_bytes, ms_f),
             "with_per_channel_detect_mblocks_per_s_all_gpus": round(3 * nb * world / wall_e / 1e6, 2),

@@ -515,6 +515,233 @@ extern "C" int trx_launch_resample(const float *d_in, float *d_out, size_t n_in,
 }
 
 // ------------------------------------------------------------------------------------------------
+// Channelizer(4, ., 16)::rotate and Resampler(p, q, 16)::rotate of the four channels in ONE pass (round 3): the channel-rate
+// streams never touch HBM.  The two kernels above move  16 B in + 32 B out  and  32 B in + 32 p/q B out  per wideband
+// time step; fused it is 16 B in + 32 p/q B out -- 59 B instead of 123 B for 65/48.
+// A workgroup owns a run of tiles of tm resampler periods = q*tm channel-rate time steps (960 for 65/48).  Per tile:
+//   1. the wideband steps [T0 - 30, T0 + q*tm) are staged as fp32 in the channelizer's 4-phase layout (prefetched into
+//      registers while the previous tile is computed; the 30 steps of overlap with the previous tile come from L2);
+//   2. every thread computes 4 consecutive channel-rate times of all 4 channels -- the same 16-tap sums and the same
+//      4-point DFT as channelize_kernel -- for the times [T0 - 15, T0 + q*tm): the resampler's 15 samples of history are
+//      recomputed, not carried (the stream's very first tile takes them from the carried history instead);
+//   3. behind a barrier the channel samples go to LDS OVER the staged wideband samples (34 KB per workgroup, four
+//      workgroups per CU as before);
+//   4. every thread resamples the outputs t, t + S, ... (S = p*m: same filter path, taps in registers) of all four
+//      channels, exactly as resample_kernel does, and the residues S - 256 .. S - 1 are swept afterwards.
+// Arithmetic and operand order are those of the two kernels: the results are bit-identical to running them in sequence
+// (tests/test_gpu_aux_kernels.py).  The last tile's workgroup leaves the final 15 channel samples in hist_out.
+// ------------------------------------------------------------------------------------------------
+#define FE_CS 1056                      // entries per channel in the aliased LDS array (>= q*tm + 15, <= 4 * CH_PHA)
+
+// Workgroup barrier for LDS hand-offs only: waits for this wave's LDS operations, not for its global loads and stores.
+// __syncthreads() also drains vmcnt -- here that would wait, at every phase change, for the previous tile's output stores
+// to be acknowledged by HBM and for the next tile's prefetch loads to land, which is most of what the two-kernel form spends.
+__device__ __forceinline__ void fe_lds_barrier()
+{
+	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+__global__ void __launch_bounds__(CH_TPB) __attribute__((amdgpu_waves_per_eu(4, 4)))
+frontend_fused_kernel(const uint4 *__restrict__ in4, size_t n_total, c32 *__restrict__ out, size_t n_out, size_t out_stride,
+		      int p, int q, int tm, int m, size_t n_tiles, const float *__restrict__ parts,
+		      const trx_tables *__restrict__ tab, const uint4 *__restrict__ wide_hist,
+		      const c32 *__restrict__ chan_hist_in, c32 *__restrict__ chan_hist_out)
+{
+	__shared__ __attribute__((aligned(16))) c32 xs[CH_M][4][CH_PHA];     // wideband staging, then cs[CH_M][FE_CS]
+	__shared__ __attribute__((aligned(16))) float taps[CH_M][CH_H];
+	extern __shared__ __attribute__((aligned(16))) char fe_smem[];        // resampler taps [16][p + 1] (residue sweep)
+	float *rtaps = reinterpret_cast<float *>(fe_smem);
+	c32 *const cs = &xs[0][0][0];
+	static_assert(CH_M * FE_CS <= CH_M * 4 * CH_PHA, "the channel samples alias the wideband staging");
+	const int t = threadIdx.x;
+	const int pst = p + 1;
+	if (t < CH_M * CH_H)
+		taps[t / CH_H][t % CH_H] = tab->chan_taps[t / CH_H][t % CH_H];
+	for (int i = t; i < p * 16; i += CH_TPB)
+		rtaps[(i % 16) * pst + (i / 16)] = parts[i];
+	const int tile_in = q * tm, tile_out = p * tm;
+	const int n_stage = tile_in + 30;                                    // wideband steps staged per tile (<= 4 * CH_TPB)
+	const int n_cs = tile_in + 15;                                       // channel-rate times computed per tile
+	// Resampling as in resample_kernel: thread t owns the outputs t, t + S, ... (S = p*m: the same filter path at every step,
+	// taps in registers).  (A variant with output PAIRS per thread -- 17 LDS reads for two outputs instead of 32, the second
+	// output's taps shifted inside 17 entries -- read a third less from LDS and was slower: smaller tiles, more of the
+	// per-tile latency chain below.  The kernel is bound by that chain, not by LDS or arithmetic; profiles/r03_ab_runs.txt.)
+	const int S = p * m, iters = tm / m;
+	const bool owner = t < S;
+	const unsigned qt = (unsigned)q * (unsigned)t;
+	const int n_t = (int)(qt / (unsigned)p), path_t = (int)(qt % (unsigned)p);
+	ch_v2f h2[8];                                                        // this thread's 16 resampler taps, in pairs
+#pragma unroll
+	for (int k = 0; k < 8; k++)
+		h2[k] = owner ? (ch_v2f){ parts[path_t * 16 + 2 * k], parts[path_t * 16 + 2 * k + 1] } : (ch_v2f){ 0.0f, 0.0f };
+	const int nstep = q * m;
+
+	const size_t per_wg = (n_tiles + gridDim.x - 1) / gridDim.x;
+	const size_t tile_lo = (size_t)blockIdx.x * per_wg;
+	const size_t tile_hi = (tile_lo + per_wg < n_tiles) ? tile_lo + per_wg : n_tiles;
+	uint4 pre[4];
+	auto prefetch = [&](size_t tile) {
+		const long long t0 = (long long)tile * tile_in - 30;               // first staged wideband step
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			const int j = i * CH_TPB + t;
+			const long long ts = t0 + j;
+			uint4 v = make_uint4(0u, 0u, 0u, 0u);
+			if (j < n_stage) {
+				if (ts >= 0) { if ((size_t)ts < n_total) v = in4[ts]; }
+				else if (ts >= -(CH_H - 1) && wide_hist) v = wide_hist[(CH_H - 1) + ts];   // carried history: steps -15 .. -1
+			}
+			pre[i] = v;
+		}
+	};
+	if (tile_lo < tile_hi)
+		prefetch(tile_lo);
+	for (size_t tile = tile_lo; tile < tile_hi; tile++) {
+		fe_lds_barrier();                                                   // (the previous tile's channel samples are done with)
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			const int j = i * CH_TPB + t;
+			if (j < n_stage) {
+				const uint32_t w[4] = { pre[i].x, pre[i].y, pre[i].z, pre[i].w };
+#pragma unroll
+				for (int n = 0; n < CH_M; n++)                                 // path M-1-n <- wideband sample n of the time step
+					xs[CH_M - 1 - n][j & 3][j >> 2] = make_float2((float)(int16_t)(w[n] & 0xffffu), (float)(int16_t)(w[n] >> 16));
+			}
+		}
+		fe_lds_barrier();
+
+		// ---- channelizer: channel-rate times u = 4t .. 4t+3 of the tile (time T0 - 15 + u); tap k of output u is staged step u + k
+		c32 o[CH_M][CH_J];
+		const bool active = CH_J * t < n_cs;
+		if (active) {
+			c32 yp[CH_J][CH_M];
+#pragma unroll
+			for (int pp = 0; pp < CH_M; pp++) {
+				ch_v2f x[CH_J + CH_H - 1];
+#pragma unroll
+				for (int v = 0; v < CH_J + CH_H - 1; v++)
+					x[v] = ch_lds(&xs[pp][v & 3][t + (v >> 2)]);
+				const float2 *g2 = reinterpret_cast<const float2 *>(&taps[pp][0]);
+				ch_v2f acc[CH_J];
+#pragma unroll
+				for (int j = 0; j < CH_J; j++)
+					acc[j] = (ch_v2f){ 0.0f, 0.0f };
+#pragma unroll
+				for (int k = 0; k < CH_H; k++) {
+					const float2 gq = g2[k >> 1];
+					const ch_v2f gp = (ch_v2f){ gq.x, gq.y };
+#pragma unroll
+					for (int j = 0; j < CH_J; j++)
+						acc[j] = acc[j] + ((k & 1) ? ch_mul_tap<1>(x[j + k], gp) : ch_mul_tap<0>(x[j + k], gp));
+					if (k & 1)
+						__builtin_amdgcn_sched_barrier(0);
+				}
+#pragma unroll
+				for (int j = 0; j < CH_J; j++) {
+					asm volatile("" : "+v"(acc[j]));
+					yp[j][pp] = make_float2(acc[j].x, acc[j].y);
+				}
+				__builtin_amdgcn_sched_barrier(0);
+			}
+#pragma unroll
+			for (int j = 0; j < CH_J; j++) {                                   // forward 4-point DFT (exact +-1 / +-j twiddles)
+				const c32 t1 = make_float2(yp[j][0].x + yp[j][2].x, yp[j][0].y + yp[j][2].y);
+				const c32 t2 = make_float2(yp[j][0].x - yp[j][2].x, yp[j][0].y - yp[j][2].y);
+				const c32 t3 = make_float2(yp[j][1].x + yp[j][3].x, yp[j][1].y + yp[j][3].y);
+				const c32 t4 = make_float2(yp[j][1].x - yp[j][3].x, yp[j][1].y - yp[j][3].y);
+				o[0][j] = make_float2(t1.x + t3.x, t1.y + t3.y);
+				o[1][j] = make_float2(t2.x + t4.y, t2.y - t4.x);
+				o[2][j] = make_float2(t1.x - t3.x, t1.y - t3.y);
+				o[3][j] = make_float2(t2.x - t4.y, t2.y + t4.x);
+			}
+		}
+		if (tile + 1 < tile_hi)                                            // (here, not before the filters: 16 registers they need)
+			prefetch(tile + 1);
+		fe_lds_barrier();                                                   // every window has been read: the staging area is free
+		if (active) {
+#pragma unroll
+			for (int c = 0; c < CH_M; c++) {
+				float4 *dst = reinterpret_cast<float4 *>(cs + c * FE_CS + CH_J * t);
+				dst[0] = make_float4(o[c][0].x, o[c][0].y, o[c][1].x, o[c][1].y);
+				dst[1] = make_float4(o[c][2].x, o[c][2].y, o[c][3].x, o[c][3].y);
+			}
+		}
+		if (tile == 0) {                                                   // the stream's first tile: times -15 .. -1 are the carried history
+			fe_lds_barrier();
+			if (t < CH_M * 15)
+				cs[(t / 15) * FE_CS + (t % 15)] = chan_hist_in ? chan_hist_in[(t / 15) * 16 + (t % 15)] : make_float2(0.0f, 0.0f);
+		}
+		fe_lds_barrier();
+
+		// ---- resampler: cs[c][j] = channel c at time T0 - 15 + j
+		const size_t o0 = tile * (size_t)tile_out;
+		if (owner) {
+#pragma nounroll
+			for (int c = 0; c < CH_M; c++) {
+				const c32 *xp = cs + c * FE_CS + n_t;
+				c32 *yo = out + c * out_stride + o0 + t;
+				size_t oo = o0 + t;
+				for (int it = 0; it < iters && oo < n_out; it++, oo += S, xp += nstep, yo += S) {
+					ch_v2f acc = { 0.0f, 0.0f };
+#pragma unroll
+					for (int k = 0; k < 16; k++) {
+						const ch_v2f xv = ch_lds(xp + k);
+						acc = acc + ((k & 1) ? ch_mul_tap<1>(xv, h2[k >> 1]) : ch_mul_tap<0>(xv, h2[k >> 1]));   // product, then sum
+					}
+					*yo = make_float2(acc.x, acc.y);
+				}
+			}
+		}
+		const int nres = S - CH_TPB;                                       // residues of every step, all channels
+		for (int idx = t; idx < nres * iters * CH_M; idx += CH_TPB) {
+			const int c = idx / (nres * iters), r = idx % (nres * iters);
+			const int oi = CH_TPB + r % nres + S * (r / nres);
+			if (o0 + oi >= n_out)
+				continue;
+			const unsigned qi = (unsigned)q * (unsigned)oi;
+			const int n = (int)(qi / (unsigned)p), path = (int)(qi % (unsigned)p);
+			const c32 *xp = cs + c * FE_CS + n;
+			float yr = 0.0f, yi = 0.0f;
+#pragma unroll
+			for (int k = 0; k < 16; k++) {
+				const c32 xv = xp[k];
+				const float h = rtaps[k * pst + path];
+				yr += xv.x * h;
+				yi += xv.y * h;
+			}
+			out[c * out_stride + o0 + oi] = make_float2(yr, yi);
+		}
+		if (chan_hist_out && tile + 1 == n_tiles && t < CH_M * 15) {        // the call's last 15 channel samples
+			const long long j = (long long)n_total - (long long)tile * tile_in + (t % 15);   // time n_total - 15 + i -> cs index
+			chan_hist_out[(t / 15) * 16 + (t % 15)] = cs[(t / 15) * FE_CS + j];
+		}
+	}
+}
+
+// fused front end; returns 1 when the geometry does not fit (the caller then runs the two kernels), 0 / TRXHIP_EIO otherwise
+extern "C" int trx_launch_frontend_fused(const int16_t *d_wide, float *d_out, size_t n_total, int p, int q, size_t out_stride,
+					 const float *parts, const trx_tables *d_tab, void *d_wide_hist_io, const void *d_chan_hist_in,
+					 void *d_chan_hist_out, hipStream_t stream)
+{
+	const int m = (CH_TPB + p - 1) / p;                                  // outputs o and o + p*m share a filter path
+	const int tm = (4 * CH_TPB - 30) / q / m * m;                         // periods per tile: staging fits 4 loads per thread
+	const size_t n_out = n_total / q * p;
+	if (tm < m || p * m < CH_TPB || p * m > 2 * CH_TPB || q * tm + 15 > FE_CS || (n_total % (size_t)q) != 0 || n_total < 30 || n_out == 0)
+		return 1;
+	const size_t n_tiles = (n_out + (size_t)p * tm - 1) / ((size_t)p * tm);
+	size_t gx = n_tiles < 1024 ? n_tiles : 1024;                         // 4 workgroups of 34 KB LDS per CU, each a run of tiles
+	const size_t lds = (size_t)16 * (p + 1) * sizeof(float);
+	hipLaunchKernelGGL(frontend_fused_kernel, dim3((unsigned)gx), dim3(CH_TPB), lds, stream, reinterpret_cast<const uint4 *>(d_wide),
+			   n_total, reinterpret_cast<c32 *>(d_out), n_out, out_stride, p, q, tm, m, n_tiles, parts, d_tab,
+			   reinterpret_cast<const uint4 *>(d_wide_hist_io), reinterpret_cast<const c32 *>(d_chan_hist_in),
+			   reinterpret_cast<c32 *>(d_chan_hist_out));
+	if (d_wide_hist_io)
+		hipLaunchKernelGGL(save_wide_hist_kernel, dim3(1), dim3(64), 0, stream, reinterpret_cast<const uint4 *>(d_wide),
+				   n_total, reinterpret_cast<uint4 *>(d_wide_hist_io));
+	return hipGetLastError() == hipSuccess ? 0 : TRXHIP_EIO;
+}
+
+// ------------------------------------------------------------------------------------------------
 // TRXD payload packing (proto_trxd.c:36-66): one 156-byte record per burst, one wave per 4 bursts
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)

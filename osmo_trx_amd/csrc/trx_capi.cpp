@@ -25,6 +25,9 @@ extern "C" int trx_launch_convert_short_float(float *d_out, const int16_t *d_in,
 extern "C" int trx_launch_convert_float_short(int16_t *d_out, const float *d_in, float scale, size_t len, hipStream_t stream);
 extern "C" int trx_launch_dft_strided(const float *d_in, float *d_out, int m, size_t howmany, size_t istride, size_t ostride,
 				      int reverse, hipStream_t stream);
+extern "C" int trx_launch_frontend_fused(const int16_t *d_wide, float *d_out, size_t n_total, int p, int q, size_t out_stride,
+					 const float *parts, const trx_tables *d_tab, void *d_wide_hist_io, const void *d_chan_hist_in,
+					 void *d_chan_hist_out, hipStream_t stream);
 extern "C" int trx_launch_channelize(const int16_t *d_in, float *d_out, size_t n_total, size_t out_stride,
 				     const trx_tables *d_tab, void *d_hist_io, hipStream_t stream);
 extern "C" int trx_launch_resample(const float *d_in, float *d_out, size_t n_in, int p, int q, size_t n_chan,
@@ -488,7 +491,9 @@ struct trxhip_rx_frontend {
 	int block_len, p, q;
 	float *d_parts;          /* [p][16] resampler partitions */
 	void *d_wide_hist;       /* 15 time steps x 4 int16 IQ samples */
-	void *d_chan_hist;       /* [4][16] complex64 */
+	void *d_chan_hist;       /* [2][4][16] complex64: the fused kernel reads one half and leaves the other (its first and its
+	                          * last workgroup run at the same time) */
+	int hist_cur;
 	float *d_chan;           /* [4][cap] channelizer output scratch */
 	size_t cap;
 };
@@ -502,14 +507,14 @@ int trxhip_rx_frontend_create(trxhip_ctx *ctx, int block_len, int p, int q, trxh
 	trxhip_rx_frontend *f = new (std::nothrow) trxhip_rx_frontend();
 	if (!f)
 		return TRXHIP_ENOMEM;
-	f->ctx = ctx; f->block_len = block_len; f->p = p; f->q = q; f->d_chan = nullptr; f->cap = 0;
+	f->ctx = ctx; f->block_len = block_len; f->p = p; f->q = q; f->d_chan = nullptr; f->cap = 0; f->hist_cur = 0;
 	float *taps = static_cast<float *>(malloc((size_t)p * 16 * sizeof(float)));
 	if (!taps) { delete f; return TRXHIP_ENOMEM; }
 	trx_polyphase_taps((unsigned)p, (unsigned)q, 16, 1.0f, taps);
 	bool ok = hipMalloc((void **)&f->d_parts, (size_t)p * 16 * sizeof(float)) == hipSuccess &&
-		  hipMalloc(&f->d_wide_hist, 16 * 16) == hipSuccess && hipMalloc(&f->d_chan_hist, 4 * 16 * 8) == hipSuccess &&
+		  hipMalloc(&f->d_wide_hist, 16 * 16) == hipSuccess && hipMalloc(&f->d_chan_hist, 2 * 4 * 16 * 8) == hipSuccess &&
 		  hipMemcpy(f->d_parts, taps, (size_t)p * 16 * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
-		  hipMemset(f->d_wide_hist, 0, 16 * 16) == hipSuccess && hipMemset(f->d_chan_hist, 0, 4 * 16 * 8) == hipSuccess;
+		  hipMemset(f->d_wide_hist, 0, 16 * 16) == hipSuccess && hipMemset(f->d_chan_hist, 0, 2 * 4 * 16 * 8) == hipSuccess;
 	free(taps);
 	if (!ok) { trxhip_rx_frontend_destroy(f); return TRXHIP_ENOMEM; }
 	*out = f;
@@ -534,7 +539,7 @@ int trxhip_rx_frontend_reset(trxhip_rx_frontend *f, void *stream)
 	if (!f || with_device(f->ctx))
 		return TRXHIP_EINVAL;
 	if (hipMemsetAsync(f->d_wide_hist, 0, 16 * 16, static_cast<hipStream_t>(stream)) != hipSuccess ||
-	    hipMemsetAsync(f->d_chan_hist, 0, 4 * 16 * 8, static_cast<hipStream_t>(stream)) != hipSuccess)
+	    hipMemsetAsync(f->d_chan_hist, 0, 2 * 4 * 16 * 8, static_cast<hipStream_t>(stream)) != hipSuccess)
 		return TRXHIP_EIO;
 	return TRXHIP_OK;
 }
@@ -573,17 +578,28 @@ int trxhip_rx_frontend_pull(trxhip_rx_frontend *f, const int16_t *d_wide, size_t
 	const size_t n_total = n_blocks * (size_t)f->block_len;
 	if (out_stride < n_total / f->q * f->p)
 		return TRXHIP_EINVAL;
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	char *const hist = static_cast<char *>(f->d_chan_hist);
+	void *const hist_in = hist + (size_t)f->hist_cur * 4 * 16 * 8, *const hist_out = hist + (size_t)(f->hist_cur ^ 1) * 4 * 16 * 8;
+	/* one pass, the channel-rate streams stay on the chip (trx_aux_kernels.hip, frontend_fused_kernel) ... */
+	static const bool no_fused = getenv("TRXHIP_NO_FUSED_FRONTEND") != nullptr;
+	int rc = no_fused ? 1 : trx_launch_frontend_fused(d_wide, d_out, n_total, f->p, f->q, out_stride, f->d_parts, f->ctx->d_tables,
+							  f->d_wide_hist, hist_in, hist_out, s);
+	if (rc == 0)
+		f->hist_cur ^= 1;
+	if (rc != 1)
+		return rc;
+	/* ... or, for a geometry that does not fit its tiles, the two kernels with the channel streams in a scratch buffer */
 	if (n_total > f->cap) {
 		if (f->d_chan) (void)hipFree(f->d_chan);
 		f->d_chan = nullptr;
 		if (hipMalloc((void **)&f->d_chan, 4 * n_total * 8) != hipSuccess) { f->cap = 0; return TRXHIP_ENOMEM; }
 		f->cap = n_total;
 	}
-	hipStream_t s = static_cast<hipStream_t>(stream);
-	int rc = trx_launch_channelize(d_wide, f->d_chan, n_total, f->cap, f->ctx->d_tables, f->d_wide_hist, s);
+	rc = trx_launch_channelize(d_wide, f->d_chan, n_total, f->cap, f->ctx->d_tables, f->d_wide_hist, s);
 	if (rc)
 		return rc;
-	return trx_launch_resample(f->d_chan, d_out, n_total, f->p, f->q, 4, f->cap, out_stride, f->d_parts, f->d_chan_hist, s);
+	return trx_launch_resample(f->d_chan, d_out, n_total, f->p, f->q, 4, f->cap, out_stride, f->d_parts, hist_in, s);
 }
 
 }  // extern "C"

@@ -29,3 +29,12 @@ x = ch[:, :n_in].contiguous()
 ms, rs = timeit(lambda: trx.resample(x, 65, 48))
 byt = 4 * n_in * 8 + 4 * (n_in // 48 * 65) * 8
 print(f"resample 65/48: {ms:.3f} ms, {byt / ms / 1e6:.0f} GB/s ({byt / ms / 1e6 / 8000:.1%} of 8 TB/s)")
+
+# the fused front end (trxhip_rx_frontend_pull: channelizer + resampler in one pass)
+from osmo_trx_amd import trxhip
+fe = trxhip.RxFrontEnd(trx)
+ms, out = timeit(lambda: fe.pull(wide, n_blocks))
+n_out = n_blocks * 192 // 48 * 65
+byt = n_blocks * 768 * 4 + 4 * n_out * 8
+print(f"rx_frontend_pull (fused): {ms:.3f} ms = {n_blocks / ms / 1e3:.1f} Mblocks/s, {byt / ms / 1e6:.0f} GB/s ({byt / ms / 1e6 / 8000:.1%} of 8 TB/s)")
+fe.close()
