@@ -836,7 +836,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 				// High-side partial outputs the same way (trx_tables.edge_hi): a burst shifted left by w <= -2 ends at delayed
 				// sample n_hi = L - 1 + w and output i0h + e sees decimator taps t <= tm = n_hi + 15 - 4 (i0h + e) only.  Access
 				// bursts live here (TOA up to 63 symbols); the masked two-stage sum of edge_round() was a third of their time.
-								const bool hi_tab = need_hi && (w <= -2) && (n_lo <= 4 * i0h - 15) && (so || is_edge) && !ABL(6);
+				const bool hi_tab = need_hi && (w <= -2) && (n_lo <= 4 * i0h - 15) && (so || is_edge) && !ABL(6);
 				float ch0 = 0.0f, ch1 = 0.0f, ch2 = 0.0f;
 				const int hi_i = i0h + le;                                  // this row's output
 				const int htm = n_hi + 15 - 4 * hi_i;                       // last decimator tap that sees an existing sample
