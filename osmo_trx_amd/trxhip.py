@@ -388,11 +388,14 @@ class RxFrontEnd:
         ptr = self.trx._dev(wide_prev, self.trx.torch.int16) if n_blocks_prev else None
         _check(self.trx.L.trxhip_rx_frontend_seed(self.h, ptr, n_blocks_prev, self.trx._stream(stream)), "trxhip_rx_frontend_seed")
 
-    def pull(self, wide_iq, n_blocks, stream=None):
-        """wide_iq: int16[n_blocks*block_len*4, 2] -> complex64[4, n_blocks*block_len*p/q]"""
+    def pull(self, wide_iq, n_blocks, stream=None, out=None):
+        """wide_iq: int16[n_blocks*block_len*4, 2] -> complex64[4, n_blocks*block_len*p/q] (written into `out` when given)"""
         torch = self.trx.torch
         n_out = n_blocks * self.block_len // self.q * self.p
-        out = torch.empty((4, n_out), dtype=torch.complex64, device=wide_iq.device)
+        if out is None:
+            out = torch.empty((4, n_out), dtype=torch.complex64, device=wide_iq.device)
+        elif tuple(out.shape) != (4, n_out) or out.dtype != torch.complex64 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous complex64[4, n_out] tensor")
         _check(self.trx.L.trxhip_rx_frontend_pull(self.h, self.trx._dev(wide_iq, torch.int16), n_blocks, self.trx._dev(out),
                                                   n_out, self.trx._stream(stream)), "trxhip_rx_frontend_pull")
         return out
