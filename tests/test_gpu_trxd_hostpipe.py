@@ -139,6 +139,31 @@ def test_hostpipe_equals_device_resident_path(trx, n, max_bursts, depth):
     pipe.close()
 
 
+@pytest.mark.parametrize("max_bursts", [256, 2048])                   # 256: read in place from pinned memory; 2048: uploaded
+@pytest.mark.parametrize("soft_stride,pkt_stride", [(148, 0), (0, 160), (148, 160), (0, 456)])
+def test_hostpipe_output_modes_and_input_paths(trx, max_bursts, soft_stride, pkt_stride):
+    """Every output mode of the host pipe (soft rows by one download / TRXD datagrams and result records written by the packer
+    straight into pinned memory / both) on both input paths (a small batch read where it lies, a large one uploaded) equals
+    the device-resident calls, byte for byte -- including a short last chunk."""
+    from osmo_trx_amd.trxhip import HostPipe
+    n = 2 * max_bursts + 77
+    iq, params, meta = mixed_workload(n)
+    pipe = HostPipe(trx, max_bursts, depth=3, soft_stride=soft_stride, pkt_stride=pkt_stride, rssi_offset=-2.0)
+    out = pipe.run(iq.numpy(), params, meta if pkt_stride else None)
+    d_p = trx.params_tensor(params)
+    dev_stride = soft_stride if soft_stride else (444 if pkt_stride >= 455 else 148)
+    res, soft = trx.detect_demod(iq.to("cuda:0"), d_p, sps=4, soft_stride=dev_stride, slice_bits=True)
+    assert np.array_equal(out["results"].view(np.uint8), res.cpu().numpy().reshape(-1))
+    if soft_stride:
+        assert np.array_equal(out["soft"], soft.cpu().numpy())
+    if pkt_stride:
+        d_meta = torch.from_numpy(meta.view(np.uint8).reshape(-1, 8).copy()).to("cuda:0")
+        pkt, plen = trx.pack_trxd_wire(res, d_p, soft, d_meta, pkt_stride=pkt_stride, rssi_offset=-2.0)
+        assert np.array_equal(out["pkt_len"], plen.cpu().numpy().view(np.uint16))
+        assert np.array_equal(out["pkt"], pkt.cpu().numpy())
+    pipe.close()
+
+
 def test_hostpipe_argument_checks(trx):
     from osmo_trx_amd.trxhip import HostPipe, TrxHipError
     with pytest.raises(TrxHipError):
