@@ -34,8 +34,11 @@
 // ------------------------------------------------------------------------------------------------
 // the hot kernel
 // ------------------------------------------------------------------------------------------------
+// (1 SPS: a burst's LDS slice is 4.4 KB and the kernel fits 128 registers, so 16 waves share a CU as in the 4-SPS kernel;
+//  the generic 4-SPS instantiations keep 12 waves and their 147-168 registers)
+#define TRX_WPB_OF(SPS_) ((SPS_) == 1 ? 16 : TRX_WPB)
 template <int SPS, bool CF32, int NLD>
-__global__ void __launch_bounds__(TRX_WPB * WAVE, 3)
+__global__ void __launch_bounds__(TRX_WPB_OF(SPS) * WAVE, (SPS == 1 ? 4 : 3))
 burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__restrict__ params,
 		  trxhip_burst_result *__restrict__ results, float *__restrict__ soft,
 		  const trx_tables *__restrict__ tab, const float4 *__restrict__ ebp_in,
@@ -423,7 +426,7 @@ extern "C" int trx_launch_pull(unsigned *d_pool_ctr, const void *d_iq, int cf32,
 		return trx_launch_pull4(d_pool_ctr, d_iq, cf32, d_params, d_results, d_soft, d_tab, d_ebp_in, n_bursts, L, thresh, full_scale,
 					soft_stride, slice, n_cu, stream);
 	// as many waves per workgroup as the 160 KB of LDS admit (12 at L = 625), one workgroup per CU
-	int wpb = TRX_WPB;
+	int wpb = TRX_WPB_OF(sps);
 	while (wpb > 1 && trx_pull_lds_bytes(L, wpb) > 160 * 1024)
 		wpb--;
 	const size_t lds = trx_pull_lds_bytes(L, wpb);
