@@ -89,10 +89,12 @@ __device__ __forceinline__ PhBase ph_bases(const c32 *P, int ph0, int m0)
 
 // waves per workgroup (one persistent workgroup per CU): 16 = 4 per SIMD for int16 input, both demodulators (<= 128
 // VGPRs; 36.6 KB of tables + 16 x 7.7 KB slices + the work counter = 159.7 KB of the 160 KB LDS, which is why the per-wave
-// buffers are the NARROW ones); 12 for complex64 input (sigProcLib-signature calls: 20 prefetch registers).  Throughput
+// buffers are the NARROW ones); 12 only for complex64 input with the exact demodulator (20 prefetch registers + its filter
+// window: 149 VGPRs; the fused complex64 instantiation -- sigProcLib-signature calls, the multi-ARFCN front end's channel
+// streams -- fits 128 since round 3 and runs 16 as well).  Throughput
 // is (resident waves) / (a wave's time per burst): 12 -> 16 waves was worth 11 % in round 1, and keeping all 16 busy until
 // the end of the launch (work claiming, below) another 13 % in round 2.
-#define K4_WPB(CF_, EX_) ((CF_) ? 12 : 16)
+#define K4_WPB(CF_, EX_) (((CF_) && (EX_)) ? 12 : 16)
 
 // The fused demodulator's main filter: three ADJACENT outputs per lane over the composite taps u = 8 .. 31 (24 of 35: see the
 // kernel).  pb addresses the lane's first sample (tap u = 8 of its first output), c4 its tap row from u = 8 on -- a per-lane
