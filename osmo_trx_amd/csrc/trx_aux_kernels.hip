@@ -1117,10 +1117,58 @@ extern "C" int trx_launch_vector_slicer(float *d_dst, const float *d_src, size_t
 // delayVector() (sigProcLib.cpp:1046-1098) for a batch of equally long vectors, one delay per vector:
 //   whole = floor(d), frac = d - whole; |frac| > 0.01: fshift[m] = sum_k X(m - 9 + k) * h_f[k], f = floorf(frac * 64),
 //   20 real taps (convolve NO_DELAY, zero-padded :318-323), else fshift = x; out[i] = fshift[i - whole], 0 outside.
-// One workgroup per vector tile; taps are wave-uniform (scalar loads), sums in tap order.
+// One workgroup per vector: the vector is staged once in LDS between two zero pads (round 3: every output used to fetch its
+// 20 samples from global memory -- 20 vector-memory instructions per output, 0.47 ms per 65536 x 625 samples), outputs are
+// then computed from consecutive LDS entries (conflict-free) and stored coalesced; taps are wave-uniform (scalar loads), sums
+// in tap order.  Vectors too long for the LDS take the direct form.
+#define DV_PAD 10                                                       // X(m - 9 + k), k = 0..19: 9 before, 10 behind
 __global__ void __launch_bounds__(256)
 delay_vector_kernel(const c32 *__restrict__ in, c32 *__restrict__ out, const float *__restrict__ delays,
 		    const trx_tables *__restrict__ tab, int len)
+{
+	extern __shared__ __attribute__((aligned(16))) char dv_smem[];
+	c32 *xs = reinterpret_cast<c32 *>(dv_smem);                          // xs[DV_PAD + j] = x[j], zeros either side
+	const size_t v = blockIdx.x;
+	const c32 *x = in + v * (size_t)len;
+	c32 *y = out + v * (size_t)len;
+	const float delay = delays[v];
+	const float fl = floorf(delay);
+	const int whole = (int)fl;
+	const float frac = delay - (float)whole;
+	const bool use_filt = (double)fabsf(frac) > 1e-2;                  // :1056
+	const int fidx = use_filt ? (int)floorf(frac * (float)TRX_DELAY_FILTS) : 0;
+	const float *h = tab->delay_filt[fidx];
+	for (int j = threadIdx.x; j < len + 2 * DV_PAD; j += blockDim.x) {
+		const int jj = j - DV_PAD;
+		xs[j] = (jj >= 0 && jj < len) ? x[jj] : make_float2(0.0f, 0.0f);
+	}
+	__syncthreads();
+	for (int i = threadIdx.x; i < len; i += blockDim.x) {
+		const int m = i - whole;
+		c32 r = make_float2(0.0f, 0.0f);
+		if (m >= 0 && m < len) {
+			if (use_filt) {
+				const c32 *xp = xs + (m - 9 + DV_PAD);
+				float yr = 0.0f, yi = 0.0f;
+#pragma unroll
+				for (int k = 0; k < TRX_DELAY_HLEN; k++) {
+					const c32 xv = xp[k];
+					yr += xv.x * h[k];
+					yi += xv.y * h[k];
+				}
+				r = make_float2(yr, yi);
+			} else {
+				r = xs[m + DV_PAD];
+			}
+		}
+		y[i] = r;
+	}
+}
+
+// the direct form (any length): one thread per output, samples from global memory
+__global__ void __launch_bounds__(256)
+delay_vector_long_kernel(const c32 *__restrict__ in, c32 *__restrict__ out, const float *__restrict__ delays,
+			 const trx_tables *__restrict__ tab, int len)
 {
 	const size_t v = blockIdx.y;
 	const c32 *x = in + v * (size_t)len;
@@ -1159,11 +1207,17 @@ extern "C" int trx_launch_delay_vector(const float *d_in, float *d_out, const fl
 {
 	if (n_vec == 0 || len == 0)
 		return 0;
+	if (len <= 4096 && n_vec <= 0x7fffffffu) {                         // one workgroup per vector, the vector in LDS (<= 32 KB)
+		const size_t lds = (size_t)(len + 2 * DV_PAD) * sizeof(c32);
+		hipLaunchKernelGGL(delay_vector_kernel, dim3((unsigned)n_vec), dim3(256), lds, stream, reinterpret_cast<const c32 *>(d_in),
+				   reinterpret_cast<c32 *>(d_out), d_delays, d_tab, len);
+		return hipGetLastError() == hipSuccess ? 0 : TRXHIP_EIO;
+	}
 	unsigned bx = (unsigned)((len + 255) / 256);
 	if (bx > 64) bx = 64;
 	for (size_t v0 = 0; v0 < n_vec; v0 += 65535) {                     // gridDim.y limit
 		const size_t nv = (n_vec - v0 < 65535) ? n_vec - v0 : 65535;
-		hipLaunchKernelGGL(delay_vector_kernel, dim3(bx, (unsigned)nv), dim3(256), 0, stream,
+		hipLaunchKernelGGL(delay_vector_long_kernel, dim3(bx, (unsigned)nv), dim3(256), 0, stream,
 				   reinterpret_cast<const c32 *>(d_in) + v0 * (size_t)len,
 				   reinterpret_cast<c32 *>(d_out) + v0 * (size_t)len, d_delays + v0, d_tab, len);
 	}

@@ -323,11 +323,12 @@ def test_streaming_front_end_any_chunking(trx, p, q, block_len):
     fe.close()
 
 
-def test_delay_vector_batch_bit_exact(trx):
+@pytest.mark.parametrize("length", [625, 157, 5000])                    # 5000: longer than the LDS-staged form takes
+def test_delay_vector_batch_bit_exact(trx, length):
     """trxhip_delay_vector_batch_cf32 == delayVector() (sigProcLib.cpp:1046-1098) per vector, every filter phase."""
     import torch
     rng = np.random.default_rng(31)
-    n, length = 130, 625
+    n = 130
     x = (rng.standard_normal((n, length)) + 1j * rng.standard_normal((n, length))).astype(np.complex64) * 500
     delays = np.concatenate([np.arange(64) / 64.0 + 0.003, -np.arange(64) / 64.0 - 2.0, [0.0, 630.0]]).astype(np.float32)
     got = trx.delay_vector(torch.from_numpy(x).to("cuda:0"), torch.from_numpy(delays).to("cuda:0")).cpu().numpy()
