@@ -157,15 +157,61 @@ convolve_kernel(const c32 *__restrict__ x, int x_len, const c32 *__restrict__ h,
 	}
 }
 
+// The same sums with the vector's window staged in LDS (round 3): one workgroup per vector loads x[start - (H-1) ..
+// start + len - 1] once, coalesced, instead of H global loads per output; taps are wave-uniform (scalar loads).
+// Used when the window fits 48 KB; the form above otherwise.
+template <bool HCPLX>
+__global__ void __launch_bounds__(256)
+convolve_lds_kernel(const c32 *__restrict__ x, int x_len, const c32 *__restrict__ h, int h_len,
+		    c32 *__restrict__ y, int y_len, int start, int len)
+{
+	extern __shared__ __attribute__((aligned(16))) char cv_smem[];
+	c32 *xs = reinterpret_cast<c32 *>(cv_smem);                          // xs[j] = x[v][start - (H-1) + j]
+	const size_t v = blockIdx.x;
+	const c32 *xv0 = x + v * (size_t)x_len + (start - (h_len - 1));
+	const int span = len + h_len - 1;
+	for (int j = threadIdx.x; j < span; j += blockDim.x)
+		xs[j] = xv0[j];
+	__syncthreads();
+	for (int i = threadIdx.x; i < len; i += blockDim.x) {
+		const c32 *xp = xs + i;
+		float yr = 0.0f, yi = 0.0f;
+		for (int k = 0; k < h_len; k++) {
+			const c32 xv = xp[k];
+			const c32 t = h[k];
+			if (HCPLX) {                                  // mac_cmplx
+				yr += xv.x * t.x - xv.y * t.y;
+				yi += xv.x * t.y + xv.y * t.x;
+			} else {                                      // mac_real: imag of the tap ignored
+				yr += xv.x * t.x;
+				yi += xv.y * t.x;
+			}
+		}
+		y[v * (size_t)y_len + i] = make_float2(yr, yi);
+	}
+}
+
 extern "C" int trx_launch_convolve(const float *d_x, int x_len, const float *d_h, int h_len, int h_complex,
 				   float *d_y, int y_len, int start, int len, size_t n_vec, hipStream_t stream)
 {
 	const size_t total = n_vec * (size_t)len;
 	if (total == 0)
 		return 0;
+	const c32 *x = reinterpret_cast<const c32 *>(d_x);
+	const size_t span_bytes = ((size_t)len + h_len - 1) * sizeof(c32);
+	if (span_bytes <= 48 * 1024 && n_vec <= 0x7fffffffu && len >= 64) {  // one workgroup per vector, its window in LDS
+		const c32 *hh = reinterpret_cast<const c32 *>(d_h);
+		c32 *yy = reinterpret_cast<c32 *>(d_y);
+		if (h_complex)
+			hipLaunchKernelGGL(convolve_lds_kernel<true>, dim3((unsigned)n_vec), dim3(256), span_bytes, stream, x, x_len, hh, h_len, yy,
+					   y_len, start, len);
+		else
+			hipLaunchKernelGGL(convolve_lds_kernel<false>, dim3((unsigned)n_vec), dim3(256), span_bytes, stream, x, x_len, hh, h_len, yy,
+					   y_len, start, len);
+		return hipGetLastError() == hipSuccess ? 0 : TRXHIP_EIO;
+	}
 	size_t blocks = (total + 255) / 256;
 	if (blocks > 256 * 8) blocks = 256 * 8;
-	const c32 *x = reinterpret_cast<const c32 *>(d_x);
 	const c32 *h = reinterpret_cast<const c32 *>(d_h);
 	c32 *y = reinterpret_cast<c32 *>(d_y);
 	if (h_complex)

@@ -52,6 +52,19 @@ def test_convolve_batch_bit_exact_vs_compiled_reference(trx, golden_dir, h_len):
             assert np.array_equal(y[r], O.convolve(xb[r], h, start, ln, kind == "complex"))
 
 
+@pytest.mark.parametrize("x_len,h_len", [(7000, 16), (40, 5), (6200, 40)])
+def test_convolve_long_and_short_vectors_take_the_direct_form(trx, x_len, h_len):
+    """Windows that do not fit the LDS-staged kernel (> 48 KB) or are too short for it: the one-thread-per-output form."""
+    rng = np.random.default_rng(77)
+    xb = (rng.standard_normal((3, x_len)) + 1j * rng.standard_normal((3, x_len))).astype(np.complex64)
+    h = (rng.standard_normal(h_len) + 1j * rng.standard_normal(h_len)).astype(np.complex64)
+    start, ln = h_len - 1, x_len - (h_len - 1)
+    for cplx in (False, True):
+        y = trx.convolve(dev(xb), dev(h), start, ln, cplx).cpu().numpy()
+        for r in range(3):
+            assert np.array_equal(y[r], O.convolve(xb[r], h, start, ln, cplx))
+
+
 def test_convolve_bounds_check(trx):
     from osmo_trx_amd import TrxHipError
     x = torch.zeros((1, 100), dtype=torch.complex64, device="cuda:0")

@@ -100,9 +100,9 @@ nv = 1 << 16
 xv = torch.view_as_complex(torch.randn((nv, 700, 2), device=dev))
 h16 = torch.view_as_complex(torch.randn((16, 2), device=dev))
 ms = timeit(lambda: trx.convolve(xv, h16, 40, 625, False))
-report("convolve_kernel<false>", "convolve_real, 16 taps, 625 outputs", nv, "vectors", nv * (700 * 8 + 625 * 8), ms)
+report("convolve_lds_kernel<false>", "convolve_real, 16 taps, 625 outputs", nv, "vectors", nv * (700 * 8 + 625 * 8), ms)
 ms = timeit(lambda: trx.convolve(xv, h16, 40, 625, True))
-report("convolve_kernel<true>", "convolve_complex, 16 taps, 625 outputs", nv, "vectors", nv * (700 * 8 + 625 * 8), ms)
+report("convolve_lds_kernel<true>", "convolve_complex, 16 taps, 625 outputs", nv, "vectors", nv * (700 * 8 + 625 * 8), ms)
 s16 = torch.randint(-32768, 32767, (1 << 28,), dtype=torch.int16, device=dev)
 ms = timeit(lambda: trx.convert_short_float(s16))
 report("convert_short_float_kernel", "int16 -> fp32", s16.numel(), "values", s16.numel() * 6, ms)

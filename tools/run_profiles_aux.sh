@@ -19,7 +19,7 @@ find $O/prof_aux_stats $O/prof_aux_fetch $O/prof_aux_write -name "*kernel_trace.
 find $O/prof_aux_stats $O/prof_aux_fetch $O/prof_aux_write -name "*agent_info.csv" -delete
 # counter files: keep the library's kernels only (drop torch's fill / copy / rng kernels)
 for f in $(find $O/prof_aux_fetch $O/prof_aux_write -name "*counter_collection.csv"); do
-	(head -1 $f; grep -E "burst_pull|pack_trxd|va_demod|channelize|resample|frontend_fused|convolve_kernel|convert_short|delay_vector|energy_detect|vector_slicer|sch_detect|save_" $f) > $f.tmp && mv $f.tmp $f
+	(head -1 $f; grep -E "burst_pull|pack_trxd|va_demod|channelize|resample|frontend_fused|convolve_kernel|convolve_lds_kernel|convert_short|delay_vector|energy_detect|vector_slicer|sch_detect|save_" $f) > $f.tmp && mv $f.tmp $f
 done
 du -sh $O/prof_aux_*
 cat $O/${TAG}_aux.jsonl
