@@ -786,12 +786,18 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 						if (i < nwrite && !ABL(5)) {
 							const c32 *pd = P + PH_M0 + i - 4;
 							float yr = 0.0f, yi = 0.0f;
+							if (!(slice & TRX_IFLAG_NO_SYM)) {                  // the detector's decimator: same sums, same order, taps in registers
+								const c32 yd = decimate16_sym(pd, gdec);
+								yr = yd.x;
+								yi = yd.y;
+							} else {
 #pragma unroll
-							for (int k = 0; k < 16; k++) {
-								const c32 x = lds_c32(pd + ((k + 1) & 3) * PH_A + ((k + 1) >> 2));
-								const float g = gdec[k];
-								yr += x.x * g;
-								yi += x.y * g;
+								for (int k = 0; k < 16; k++) {
+									const c32 x = lds_c32(pd + ((k + 1) & 3) * PH_A + ((k + 1) >> 2));
+									const float g = gdec[k];
+									yr += x.x * g;
+									yi += x.y * g;
+								}
 							}
 							if (is_edge) {
 								dec[i] = make_float2(yr, yi);
