@@ -478,13 +478,24 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 			asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0xf\n\t"
 				     "v_add_f32_dpp %1, %1, %1 row_shl:4 row_mask:0xf bank_mask:0xf" : "+v"(er), "+v"(ei));
 			wave_sync();                                                // (every lane has read its taps from dec[0..95])
-			if (lane < 50) {
-#pragma unroll
-				for (int j = 0; j < 3; j++)
-					dec[3 * lane + j] = cmul(make_float2(acc[j].x, acc[j].y), scale);
+			// Only ONE component of every symbol is ever used: flush() stores +-re for even, +-im for odd symbols (the (-j)^i
+			// rotation) and reads exactly that float of dec[i].  So the product with 1 / amp is formed for that component alone --
+			// a * p + b * q with (p, q) = (s.x, -s.y) for the real, (s.y, s.x) for the imaginary part: a multiply and an fma
+			// instead of three packed instructions -- and stored as 4 bytes in the slot flush() reads (a ds_write_b32 costs two
+			// thirds of a ds_write_b64).  Symbol 3 lane + j is odd when lane + j is.
+			{
+				const bool odd = (lane & 1) != 0;
+				const float p0 = odd ? scale.y : scale.x, q0 = odd ? scale.x : -scale.y;   // j = 0, 2: parity of the lane
+				const float p1 = odd ? scale.x : scale.y, q1 = odd ? -scale.y : scale.x;   // j = 1: the other one
+				float *const df = reinterpret_cast<float *>(dec + 3 * lane);
+				if (lane < 50) {
+					df[0 + (odd ? 1 : 0)] = fmaf(acc[0].y, q0, acc[0].x * p0);
+					df[2 + (odd ? 0 : 1)] = fmaf(acc[1].y, q1, acc[1].x * p1);
+					df[4 + (odd ? 1 : 0)] = fmaf(acc[2].y, q0, acc[2].x * p0);
+				}
+				if (lane >= 52 && lane < 56)                            // symbols 0 .. 3, after lanes 0, 1 wrote their (partial) versions
+					reinterpret_cast<float *>(dec + (lane - 52))[odd ? 1 : 0] = fmaf(ei, q0, er * p0);
 			}
-			if (lane >= 52 && lane < 56)
-				dec[lane - 52] = cmul(make_float2(er, ei), scale);      // after lanes 0, 1 wrote their (partial) versions
 			wave_sync();
 			pend_mode = 1;
 			pend_so = so;
