@@ -817,6 +817,16 @@ __device__ __forceinline__ int detect_burst_h(const c32 *sig, int sig_len, c32 *
 		best = v0; bidx = l2;
 		if (v1 > v0) { best = v1; bidx = l2 + 1; }
 		if (!(best > 0.0f)) bidx = -1;
+	} else if (PADDED && unit_slot >= 0 && len + TRX_CZ_PAD <= WAVE && start + WAVE <= sig_len + 4) {
+		// one round (normal bursts: len <= 49): lane = lag, and the twelve lanes behind the window write the right zero pad in
+		// the SAME store (an LDS store costs three reads); what they correlated -- real samples further on -- is discarded
+		const trx_v2f acc = corr_unit(unit_slot, sig + (lane + start - (N - 1)));
+		const bool in = lane < len;
+		const c32 y = make_float2(in ? acc.x : 0.0f, in ? acc.y : 0.0f);
+		if (lane < len + TRX_CZ_PAD)
+			cz[lane] = y;
+		const float v = norm2(y);
+		if (v > best) { best = v; bidx = lane; }
 	} else if (PADDED && unit_slot >= 0) {
 		for (int i = lane; i < len; i += WAVE) {
 			const trx_v2f acc = corr_unit(unit_slot, sig + (i + start - (N - 1)));
