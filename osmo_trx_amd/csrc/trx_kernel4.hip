@@ -641,7 +641,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 			}
 		}
 
-#if defined(TRX_SENS_VALU) || defined(TRX_SENS_PLAIN) || defined(TRX_SENS_LDS) || defined(TRX_SENS_SALU)
+#if defined(TRX_SENS_VALU) || defined(TRX_SENS_PLAIN) || defined(TRX_SENS_LDS) || defined(TRX_SENS_SALU) || defined(TRX_SENS_LDSW)
 		// measurement builds only (tools/build_variants.py): N extra instructions of one kind per burst, results unused --
 		// the slope of throughput against N is what one instruction of that kind costs (or its removal buys)
 		{
@@ -658,6 +658,15 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 			{
 				const unsigned la = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)sincv + lane * 8;
 				asm volatile(".rept %c3\n ds_read_b64 %0, %2\n ds_read_b64 %1, %2 offset:512\n .endr\n s_waitcnt lgkmcnt(0)" : "=&v"(sx), "=&v"(sy) : "v"(la), "n"(TRX_SENS_LDS / 2) : "memory");
+			}
+#endif
+#ifdef TRX_SENS_LDSW
+			{
+				// N extra ds_write_b64 into this wave's correlation pad area (cz[64 + ...] is beyond anything a burst reads back;
+				// zeros, so the pads stay zero)
+				const unsigned la = (unsigned)(uintptr_t)(__attribute__((address_space(3))) c32 *)(cz + 64) + (lane & 7) * 8;
+				const v2f zz = { 0.0f, 0.0f };
+				asm volatile(".rept %c2\n ds_write_b64 %0, %1\n .endr" :: "v"(la), "v"(zz), "n"(TRX_SENS_LDSW) : "memory");
 			}
 #endif
 #ifdef TRX_SENS_SALU
