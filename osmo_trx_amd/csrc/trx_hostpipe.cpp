@@ -48,11 +48,8 @@ struct trxhip_hostpipe {
 	} slot[16];
 };
 
-static bool dev_soft_ok(const trxhip_hostpipe *p);
 static bool pin(void **p, size_t bytes) { return hipHostMalloc(p, bytes ? bytes : 16, hipHostMallocDefault) == hipSuccess; }
 static bool dev(void **p, size_t bytes) { return hipMalloc(p, bytes ? bytes : 16) == hipSuccess; }
-
-static bool dev_soft_ok(const trxhip_hostpipe *p) { return p->dev_soft_stride >= 148 && p->cfg.pkt_stride >= 160 && !(p->cfg.pkt_stride & 3); }
 
 extern "C" {
 
@@ -202,13 +199,9 @@ int trxhip_hostpipe_submit(trxhip_hostpipe *p, int slot, size_t n)
 	if (rc == TRXHIP_OK && np > 1)                                /* :741, :751: rssi from the path average */
 		rc = trxhip_apply_diversity_power(p->ctx, sl.d_results, d_params, sl.d_avg, n, c.full_scale, st);
 	const bool records_by_packer = c.pkt_stride && !c.soft_stride;
-	if (rc == TRXHIP_OK && c.pkt_stride) {                        /* datagrams and lengths: straight into the pinned buffers */
-		if (dev_soft_ok(p))
-			rc = trx_launch_pack_trxd_wire(sl.d_results, d_params, sl.d_soft, p->dev_soft_stride, d_meta, sl.dv_pkt, c.pkt_stride,
-						       sl.dv_pkt_len, n, c.rssi_offset, st, records_by_packer ? sl.dv_results : nullptr);
-		else
-			rc = TRXHIP_EINVAL;
-	}
+	if (rc == TRXHIP_OK && c.pkt_stride)                          /* datagrams and lengths: straight into the pinned buffers */
+		rc = trx_launch_pack_trxd_wire(sl.d_results, d_params, sl.d_soft, p->dev_soft_stride, d_meta, sl.dv_pkt, c.pkt_stride,
+					       sl.dv_pkt_len, n, c.rssi_offset, st, records_by_packer ? sl.dv_results : nullptr);   /* (strides checked in create()) */
 	/* one download: [results][the n soft rows] (none when the packer has delivered the records) */
 	ok = rc == TRXHIP_OK &&
 	     (records_by_packer ||
