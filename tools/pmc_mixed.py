@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""One workload per launch for counter passes: WORKLOAD=normal|rach|ext|mixed python tools/pmc_mixed.py (2 warm + 2 timed launches)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from osmo_trx_amd import TrxHip, synth
+n = 1 << 20
+wl = os.environ.get("WORKLOAD", "mixed")
+trx = TrxHip(0)
+if wl == "mixed":
+    iq, p = synth.make_mixed_bursts(n, "cuda:0")
+elif wl in ("rach", "ext"):
+    iq, p, _ = synth.make_access_bursts(n, "cuda:0", ext=(wl == "ext"))
+else:
+    iq, p, _ = synth.make_normal_bursts(n, "cuda:0", 4)
+dp = trx.params_tensor(p)
+res = torch.empty((n, 32), dtype=torch.uint8, device="cuda:0")
+soft = torch.empty((n, 148), dtype=torch.float32, device="cuda:0")
+for _ in range(4):
+    trx.detect_demod(iq, dp, sps=4, soft_stride=148, slice_bits=True, results=res, soft=soft)
+torch.cuda.synchronize()
