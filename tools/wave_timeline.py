@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Start / end wall-clock of every wave of the fused kernel (diagnostic build): is the persistent grid balanced?
-   TRXHIP_LIB=.../libtrxhip_diag.so python tools/wave_timeline.py"""
+   TRXHIP_LIB=.../libtrxhip_diag.so [WORKLOAD=normal|mixed|rach] python tools/wave_timeline.py"""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -9,10 +9,16 @@ n = int(os.environ.get('N_BURSTS', str(1 << 20)))
 trx = TrxHip(0)
 L = trxhip.load_library()
 L.trxhip_diag_read_waves.argtypes = [C.c_void_p, C.c_int]
-iq, params, _ = synth.make_normal_bursts(n, "cuda:0", 4)
+wl = os.environ.get('WORKLOAD', 'normal')
+if wl == 'mixed':
+    iq, params = synth.make_mixed_bursts(n, "cuda:0")
+elif wl == 'rach':
+    iq, params, _ = synth.make_access_bursts(n, "cuda:0")
+else:
+    iq, params, _ = synth.make_normal_bursts(n, "cuda:0", 4)
 dp = trx.params_tensor(params)
 for _ in range(3):
-    trx.detect_demod(iq, dp); torch.cuda.synchronize()
+    trx.detect_demod(iq, dp, soft_stride=148, slice_bits=True); torch.cuda.synchronize()
 W = 4096
 buf = np.zeros((W, 24), dtype=np.uint64)
 L.trxhip_diag_read_waves(buf.ctypes.data, W)
