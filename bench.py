@@ -287,9 +287,16 @@ def strong_leg(trx, synth, shard, dev, rank, world, out):
     # configs[4], strong scaling: ONE fixed global batch of 8M mixed bursts, rank r owns shard_range(8M, r, N)
     if True:
         total = int(os.environ.get("TRXHIP_BENCH_STRONG_TOTAL", 8 << 20))     # (env: tests shrink the fixed batch)
-        lo, hi = shard.shard_range(total, rank, world)
+        # the generator starts a shard on a multiple of 8 * chunk only: round the shard edges to that (any N, also 3, 5, 6, 7),
+        # with a smaller generator chunk when the batch is too small for 65536-burst chunks on every rank
+        chunk = 65536
+        while chunk > 512 and 8 * chunk * world > total:
+            chunk //= 2
+        lo, hi = shard.shard_range_aligned(total, rank, world, 8 * chunk)
         m = hi - lo
-        iq, p = synth.make_mixed_bursts(m, dev, seed=synth.SEED + 2, offset=lo)
+        if m <= 0:
+            raise SystemExit(f"strong leg: {total} bursts do not split over {world} ranks in blocks of {8 * chunk}")
+        iq, p = synth.make_mixed_bursts(m, dev, seed=synth.SEED + 2, chunk=chunk, offset=lo)
         dp = trx.params_tensor(p)
         res_s = torch.empty((m, 32), dtype=torch.uint8, device=dev)
         soft_s = torch.empty((m, 148), dtype=torch.float32, device=dev)
@@ -298,10 +305,53 @@ def strong_leg(trx, synth, shard, dev, rank, world, out):
         det = shard.sum_over_ranks(int((trx.results_to_numpy(res_s)["rc"] > 0).sum()), dev if world > 1 else None)
         out["configs[4]_strong"] = {
             "workload": f"BASELINE.json configs[4]: ONE fixed batch of {total} mixed bursts (7:1 NB:RACH), contiguous shard "
-                        "[N*r/G, N*(r+1)/G) per rank, no data-path collective", "scaling": "strong",
+                        f"[N*r/G, N*(r+1)/G) per rank with the edges rounded down to {8 * chunk} bursts, no data-path collective",
+            "scaling": "strong",
             "global_bursts": total, "bursts_this_rank": m, "mbursts_per_s_all_gpus": round(3 * total / wall / 1e6, 2),
             "ms_per_pass": round(wall / 3 * 1e3, 4), "detected_fraction": round(det / total, 4)}
         del iq, res_s, soft_s
+
+
+def free_port():
+    import socket
+    so = socket.socket()
+    so.bind(("127.0.0.1", 0))
+    port = so.getsockname()[1]
+    so.close()
+    return port
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` with no torchrun environment: start the N ranks ourselves, one child process per GPU
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as torch.distributed.run would set them), and pass rank 0's JSON line
+    through.  The parent never touches the GPU (torch.cuda.device_count() does not initialise it): nothing that has
+    made a HIP call is ever re-executed.  A rank that dies takes the others with it (their exact PIDs)."""
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < n and not os.environ.get("TRXHIP_ONE_DEVICE"):
+        raise SystemExit(f"--gpus {n} but this node shows {have} GPU(s) (TRXHIP_ONE_DEVICE=1 with TRXHIP_DIST_BACKEND=gloo "
+                         "runs every rank on cuda:0: tests only)")
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TRXHIP_BENCH_LAUNCHER="bench.py self-spawn")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            try:
+                r = p.wait(timeout=0.5)
+            except subprocess.TimeoutExpired:
+                continue
+            pending.remove(p)
+            if r != 0 and rc == 0:
+                rc = r
+                for q in pending:                                    # one rank failed: the others would wait in a collective
+                    q.terminate()
+    return rc
 
 
 def main():
@@ -318,7 +368,12 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=0, help="bursts for the CPU baseline (0 = auto)")
     ap.add_argument("--legs", default="all", help="which other_configs legs run: all | none | comma list of c0,c2,c3,strong "
                                                   "(strong = configs[4]'s fixed 8M batch; default only when N > 1)")
+    ap.add_argument("--sustain-seconds", type=float, default=1.0,
+                    help="length of the sustained leg (back-to-back launches behind the timed region; 0 = skip)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:             # plain `python bench.py --gpus N`: launch the ranks here
+        raise SystemExit(spawn_ranks(args.gpus))
 
     import numpy as np
     import torch
@@ -369,6 +424,30 @@ def main():
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev))
     kernel_ms = shard.max_over_ranks(kernel_ms, dev if world > 1 else None)
 
+    # sustained leg (not `value`): >= --sustain-seconds of back-to-back launches of the same step, queued without a host
+    # synchronisation in between, so that the 20-step timed region can be read against a second of continuous load
+    sustained = None
+    if args.sustain_seconds > 0:
+        k_sus = max(args.steps, int(args.sustain_seconds * 1.05 / max(kernel_ms * 1e-3, 1e-6)) + 1)
+        shard.barrier()
+        torch.cuda.synchronize()
+        t0s = time.perf_counter()
+        for _ in range(k_sus):
+            step()
+        torch.cuda.synchronize()
+        t_sus = time.perf_counter() - t0s
+        shard.barrier()
+        t_sus = shard.max_over_ranks(t_sus, dev if world > 1 else None)
+        sustained = {"seconds": round(t_sus, 3), "launches": k_sus, "mbursts_per_s_all_gpus": round(n * world * k_sus / t_sus / 1e6, 3),
+                     "ms_per_step": round(t_sus / k_sus * 1e3, 4),
+                     "note": "back-to-back launches behind the timed region, no host synchronisation in between; never `value`"}
+
+    # who ran: every rank's device, gathered over the same backend the tables were broadcast on
+    props = torch.cuda.get_device_properties(local_rank)
+    me = f"rank {rank}: cuda:{local_rank} {props.name} {getattr(props, 'gcnArchName', '')} pci {getattr(props, 'pci_bus_id', '?')}"
+    devices = shard.gather_strings(me, dev if world > 1 else None)
+    backend = shard.backend_name()
+
     r = trx.results_to_numpy(results)
     detected = int((r["rc"] > 0).sum())
     ns = args.cpu_sample or min(n, max(8192, 4096 * usable_cores()))
@@ -390,7 +469,7 @@ def main():
         total_bursts = n * world * args.steps
         value = total_bursts / elapsed / 1e6
         achieved = BYTES_PER_BURST * n / (kernel_ms * 1e-3) / 1e9
-        traffic = traffic_source = None
+        traffic = traffic_source = compute = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
@@ -398,12 +477,18 @@ def main():
                 traffic = j["hbm_bytes_per_burst"] * n
                 traffic_source = ("recorded PMC profile, not this run: profiles/pmc_traffic.json (" + str(j.get("tag", "?")) +
                                   ": FETCH_SIZE x2 + WRITE_SIZE per burst, separate --pmc passes) x bursts_per_launch")
+                if "compute" in j:
+                    # what actually bounds the kernel: the vector ALU's issue rate (SQ counters of the same recorded profile)
+                    compute = dict(j["compute"], bound="valu-issue",
+                                   source="recorded SQ counter passes, not this run: profiles/" + str(j.get("tag", "?")) + "_sq_counters.json")
             except Exception:
-                traffic = traffic_source = None
+                traffic = traffic_source = compute = None
         out = {
             "metric": "Mbursts/s detect+demod (156.25 sym, 4 SPS)",
             "value": round(value, 4), "unit": "Mbursts/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "world": world, "backend": backend or "none (single process)",
+            "launcher": os.environ.get("TRXHIP_BENCH_LAUNCHER") or ("torch.distributed.run / external" if world > 1 else "single process"),
+            "devices": devices, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -416,7 +501,10 @@ def main():
                 "parallelism": f"batch-sharded x{world} (no data-path collective; tables RCCL-broadcast once)",
                 "detected_fraction": round(detected / n, 4),
                 "demodulator": "fused delay-o-decimate composite filter, 24 of 35 taps (default); rc, TOA, amp bit-exact; "
-                               f"soft bits <= {FUSED_SOFT_ATOL:g} absolute (full scale 1)",
+                               f"|soft - ref| <= {FUSED_SOFT_ATOL:g} * max(1, rms / (4 |amp|)), absolute on full scale 1 "
+                               f"(include/trxhip.h: plain {FUSED_SOFT_ATOL:g} on every real detection, amplitude-scaled on noise "
+                               "slots detected far below their samples' level)",
+                "sustained": sustained,
                 "exact_demod_mbursts_per_gpu": round(n / exact_ms / 1e3, 2) if side else None,
                 "mixed_7to1_nb_rach": ({"workload": "BASELINE.json configs[4] per-GPU share: 7:1 NB:RACH, RACH max_toa 63",
                                         "mbursts_per_s_all_gpus": round(5 * n * world / mixed_s / 1e6, 3),
@@ -425,8 +513,11 @@ def main():
                 "other_configs": legs or None,
             },
             "roofline": {
+                # `bound` names the roofline the fraction is priced against (the measurement contract: HBM bytes); what limits
+                # the kernel in practice is in `compute` -- the vector ALU's issue rate, not HBM
                 "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,
+                "compute": compute,
                 "kernel": "burst_pull4_kernel<false, false, true>", "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_bytes_per_burst": BYTES_PER_BURST, "bursts_per_launch": n,
             },

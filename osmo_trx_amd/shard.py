@@ -41,6 +41,33 @@ def shard_range(n_total, rank, world):
     return lo, hi
 
 
+def shard_range_aligned(n_total, rank, world, align):
+    """shard_range() with every inner boundary rounded down to a multiple of `align` (the last shard ends at n_total):
+    for generators and layouts that can only start on a block boundary (synth.make_mixed_bursts: 8 * chunk).  Any world size
+    works -- N = 3, 5, 6, 7 included; shards differ by at most `align` bursts."""
+    def edge(r):
+        return n_total if r >= world else ((n_total * r) // world) // align * align
+    return edge(rank), edge(rank + 1)
+
+
+def backend_name():
+    return dist.get_backend() if dist.is_initialized() else None
+
+
+def gather_strings(text, device=None, width=96):
+    """Every rank's `text` (ASCII, cut to `width` bytes) on every rank, in rank order: one all_gather of fixed-size byte
+    tensors -- works on RCCL (device tensors) and gloo alike."""
+    rank, _, world = env_world()
+    if world == 1 or not dist.is_initialized():
+        return [text]
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    raw = text.encode("ascii", "replace")[:width].ljust(width, b"\0")
+    mine = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+    parts = [torch.zeros(width, dtype=torch.uint8, device=dev) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    return [bytes(t.cpu().numpy().tobytes()).rstrip(b"\0").decode("ascii", "replace") for t in parts]
+
+
 def broadcast_tables(device=None):
     """Rank 0 generates the table blob on the host; everyone receives it (RCCL/gloo broadcast) and checks
     the FNV-1a checksum.  Returns the blob as bytes."""

@@ -21,8 +21,10 @@ ck = trxhip.tables_checksum(blob)
 lo, hi = shard.shard_range(1000003, rank, world)
 tot = shard.sum_over_ranks(hi - lo)
 mx = shard.max_over_ranks(float(rank + 1))
+names = shard.gather_strings(f"rank {rank}: cpu worker")          # bench.py's device list (same call on RCCL)
 shard.barrier()
-print(json.dumps({"rank": rank, "ck": ck, "lo": lo, "hi": hi, "tot": tot, "mx": mx, "n": len(blob)}))
+print(json.dumps({"rank": rank, "ck": ck, "lo": lo, "hi": hi, "tot": tot, "mx": mx, "n": len(blob), "names": names,
+                  "backend": shard.backend_name()}))
 dist.destroy_process_group()
 '''
 
@@ -60,6 +62,8 @@ def test_two_rank_table_broadcast_and_sharding(tmp_path):
     assert outs[0]["lo"] == 0 and outs[0]["hi"] == outs[1]["lo"] and outs[1]["hi"] == 1000003
     assert outs[0]["tot"] == outs[1]["tot"] == 1000003
     assert outs[0]["mx"] == outs[1]["mx"] == 2.0
+    assert outs[0]["names"] == outs[1]["names"] == ["rank 0: cpu worker", "rank 1: cpu worker"]
+    assert outs[0]["backend"] == "gloo"
 
 
 def test_shard_ranges_partition_exactly():
@@ -71,3 +75,31 @@ def test_shard_ranges_partition_exactly():
             assert all(r[k][1] == r[k + 1][0] for k in range(world - 1))
             sizes = [b - a for a, b in r]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_aligned_shard_ranges_for_every_world_size():
+    """bench.py's strong-scaling leg: shard edges on multiples of the generator's block (8 * chunk) for ANY N -- round 3's
+    plain shard_range() crashed the leg for N = 3, 5, 6, 7 (offsets that are no multiple of 524288)."""
+    from osmo_trx_amd import shard
+    for n, align in ((8 << 20, 8 * 65536), (1 << 20, 8 * 4096), (1000003, 4096)):
+        for world in range(1, 17):
+            r = [shard.shard_range_aligned(n, k, world, align) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(r[k][1] == r[k + 1][0] for k in range(world - 1))
+            assert all(a % align == 0 for a, _ in r)
+            assert all(b > a for a, b in r) or n < world * align
+            sizes = [b - a for a, b in r]
+            assert max(sizes) - min(sizes) <= align + (n % align)
+
+
+def test_bench_self_spawn_refuses_more_ranks_than_gpus():
+    """plain `python bench.py --gpus 2` launches its own ranks; on a box without that many GPUs it says so (before any
+    child starts) instead of running as world 1 and printing n_gpus 1 (round 3)."""
+    import pytest
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("a multi-GPU node: the launch would succeed (tests/test_gpu_sharded.py covers it)")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "TRXHIP_ONE_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode != 0 and "--gpus 2 but this node shows" in r.stderr and '"metric"' not in r.stdout

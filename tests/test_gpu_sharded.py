@@ -95,13 +95,33 @@ def test_bench_py_two_ranks_code_path(tmp_path):
     env = dict(os.environ, TRXHIP_DIST_BACKEND="gloo", TRXHIP_ONE_DEVICE="1", TRXHIP_BENCH_STRONG_TOTAL=str(1 << 20))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--bursts", str(1 << 16), "--no-host-fed", "--legs", "strong"]
-    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT)
+           "--bursts", str(1 << 16), "--no-host-fed", "--legs", "strong", "--sustain-seconds", "0.2"]
+    check_two_rank_line(subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT),
+                        "torch.distributed.run / external")
+
+
+def test_plain_bench_py_gpus_2_spawns_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no torchrun environment starts the two ranks itself (bench.spawn_ranks) and prints
+    ONE line with n_gpus 2, the world, the backend and every rank's device."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(TRXHIP_DIST_BACKEND="gloo", TRXHIP_ONE_DEVICE="1", TRXHIP_BENCH_STRONG_TOTAL=str(1 << 20))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--bursts", str(1 << 16), "--no-host-fed", "--legs", "strong", "--sustain-seconds", "0.2"]
+    check_two_rank_line(subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT),
+                        "bench.py self-spawn")
+
+
+def check_two_rank_line(r, launcher):
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(line) == 1, r.stdout[-2000:]                      # rank 0 alone prints
     j = json.loads(line[0])
     assert j["n_gpus"] == 2 and j["steps"] == 3 and j["scaling"] == "weak"
+    assert j["world"] == 2 and j["backend"] == "gloo" and j["launcher"] == launcher
+    assert len(j["devices"]) == 2 and j["devices"][0].startswith("rank 0: cuda:0") and j["devices"][1].startswith("rank 1: cuda:0")
+    assert j["config"]["sustained"]["seconds"] >= 0.2 and j["config"]["sustained"]["mbursts_per_s_all_gpus"] > 0
     assert j["config"]["global_bursts"] == 2 << 16 and 0.9 < j["config"]["detected_fraction"] < 1.0
     assert j["value"] > 0 and j["roofline"]["kernel_ms"] > 0 and "cpu_baseline" not in j
     s = j["config"]["other_configs"]["configs[4]_strong"]
