@@ -1597,3 +1597,81 @@ int orc_demod_any_burst_va(const orc_cf *burst, int n, int type, int tsc, int ma
 	free(x);
 	return start;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Transceiver::pullRadioVector() around its DSP calls, Transceiver.cpp:665-815
+ * ---------------------------------------------------------------------------------------- */
+void orc_rx_state_init(orc_rx_state *st)
+{
+	memset(st, 0, sizeof(*st));                      /* Transceiver.cpp:64-68; std::vector<float>(20): zeros */
+}
+
+/* avgVector::insert, radioVector.cpp:97-108 */
+static void rx_noise_insert(orc_rx_state *st, float val)
+{
+	if (st->itr >= ORC_NOISE_CNT)
+		st->itr = 0;
+	st->noises[st->itr++] = val;
+}
+
+/* avgVector::avg, radioVector.cpp:84-95 */
+static float rx_noise_avg(const orc_rx_state *st)
+{
+	float val = 0.0;
+	for (size_t i = 0; i < ORC_NOISE_CNT; i++)
+		val += st->noises[i];
+	return val / (float)ORC_NOISE_CNT;
+}
+
+int orc_pull_radio_vector(orc_rx_state *st, int type, uint32_t fn, uint8_t tn, float pow_avg, int rc, const orc_ebp *ebp,
+			  const float *soft, int nsoft, double full_scale, double rssi_offset, orc_ul_burst_ind *bi)
+{
+	float avg;
+	/* :693-704 */
+	bi->nbits = 0;
+	bi->fn = fn;
+	bi->tn = tn;
+	bi->rssi = 0.0;
+	bi->toa = 0.0;
+	bi->noise = 0.0;
+	bi->idle = 0;
+	bi->modulation = 0;
+	bi->tss = 0;
+	bi->tsc = 0;
+	bi->ci = 0.0;
+	if (type == ORC_OFF)                             /* :713-717 */
+		return -2;                               /* -ENOENT */
+	if (st->muted)                                   /* :719-721 */
+		goto ret_idle;
+	avg = sqrtf(pow_avg);                            /* :741 (float sqrt of a float: the C++ overload) */
+	if (type == ORC_IDLE) {                          /* :743-748 */
+		rx_noise_insert(st, avg);
+		st->noise_lev = rx_noise_avg(st);
+	}
+	bi->rssi = 20.0 * log10(full_scale / avg) + rssi_offset;              /* :751 */
+	bi->noise = 20.0 * log10(full_scale / st->noise_lev) + rssi_offset;   /* :752 */
+	if (type == ORC_IDLE)                            /* :754-755 */
+		goto ret_idle;
+	if (rc <= 0) {                                   /* :769-781 */
+		if (rc == -ORC_SIGERR_CLIP)
+			st->rx_clipping++;
+		else if (rc != ORC_SIGERR_NONE)
+			st->rx_no_burst_detected++;
+		goto ret_idle;
+	}
+	bi->toa = ebp->toa;                              /* :789-791 */
+	bi->tsc = ebp->tsc;
+	bi->ci = ebp->ci;
+	if (nsoft == 444) {                              /* :794-800 */
+		bi->modulation = 1;
+		bi->nbits = 444;
+	} else {
+		bi->modulation = 0;
+		bi->nbits = 148;                         /* gSlotLen */
+	}
+	orc_vector_slicer(bi->rx_burst, soft, bi->nbits);                     /* :803 */
+	return 0;
+ret_idle:
+	bi->idle = 1;                                    /* :808 */
+	return 0;
+}

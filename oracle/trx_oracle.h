@@ -157,6 +157,35 @@ void    orc_trxd_soft_u8(uint8_t *dst, const float *rx_burst, unsigned nbits);
 int     orc_trxd_pack(uint8_t *buf, unsigned version, uint32_t fn, uint8_t tn, double rssi, double toa, int idle,
 		      int modulation_8psk, uint8_t tss, uint8_t tsc, float ci, const float *rx_burst, unsigned nbits);
 
+/* ---- Transceiver::pullRadioVector() around the DSP core, Transceiver.cpp:665-815: struct bi initialisation, OFF / muted /
+ * IDLE early-outs, the 20-entry noise ring (avgVector, radioVector.cpp:79-108), rssi / noise in dBFS, rate counters ---- */
+#define ORC_NOISE_CNT 20                                  /* Transceiver.cpp:55 */
+typedef struct {
+	float    noises[ORC_NOISE_CNT];                   /* avgVector mNoises(NOISE_CNT): value-initialised */
+	size_t   itr;
+	float    noise_lev;                               /* mNoiseLev(0.0), Transceiver.cpp:66 */
+	int      muted;                                   /* mMuted */
+	unsigned rx_empty_burst, rx_clipping, rx_no_burst_detected;   /* struct trx_counters, osmo_signal.h:68-70 */
+} orc_rx_state;
+/* struct trx_ul_burst_ind, proto_trxd.h:24-37 (plain ints for the bool / enum) */
+typedef struct {
+	float    rx_burst[444];
+	unsigned nbits;
+	uint32_t fn;
+	uint8_t  tn;
+	double   rssi, toa, noise;
+	int      idle;
+	int      modulation;                              /* 0 MODULATION_GMSK, 1 MODULATION_8PSK */
+	uint8_t  tss, tsc;
+	float    ci;
+} orc_ul_burst_ind;
+void orc_rx_state_init(orc_rx_state *st);
+/* One call of pullRadioVector() given what its DSP calls returned for the slot: `type` = expectedCorrType(), `pow_avg` =
+ * sum of the paths' energyDetect() / chans (the argument of :741's sqrt), rc / ebp = detectAnyBurst()'s, `soft` =
+ * demodAnyBurst()'s SoftVector (-1..+1, nsoft = 156 GMSK or 444 8-PSK; unused unless rc > 0).  Returns 0, or -2 (-ENOENT). */
+int  orc_pull_radio_vector(orc_rx_state *st, int type, uint32_t fn, uint8_t tn, float pow_avg, int rc, const orc_ebp *ebp,
+			   const float *soft, int nsoft, double full_scale, double rssi_offset, orc_ul_burst_ind *bi);
+
 /* ---- Channelizer (Channelizer.cpp / ChannelizerBase.cpp), M-path polyphase + M-point DFT ---- */
 typedef struct orc_channelizer orc_channelizer;
 orc_channelizer *orc_channelizer_new(int m, int block_len, int h_len);

@@ -79,7 +79,7 @@ def ref_include_dirs():
     return None
 
 
-SHIM_SOURCES = ["sigProcLib.cpp", "MultiArfcnRx.cpp", "BurstGatherer.cpp"]
+SHIM_SOURCES = ["sigProcLib.cpp", "MultiArfcnRx.cpp", "BurstGatherer.cpp", "trxPullRadioVector.cpp"]
 
 
 def _build_shim(out, inc_dirs, force):

@@ -21,7 +21,15 @@
 //     closed, submitted and completed in the order they were opened, and a channel's bursts come back in push order.
 //   * stop() joins the submitter, lets the completion thread drain what was submitted, and discards bursts that were
 //     gathered but not submitted (their pull() returns -EIO, as after any stop); start() after stop() begins from empty
-//     FIFOs.  stop() may race with push()/pull(); the destructor may not.
+//     FIFOs.  stop() may race with push()/pull() and with another stop() (life_mu); so may start(): every push / pull counts
+//     itself in `users` on entry, start() raises `reconfig`, waits for the count to reach zero and only then frees the
+//     previous run's pinned slots and rings (entrants that see `reconfig` leave at once: push -> refused, pull -> -EIO).
+//     The destructor may not race with anything.
+//
+// Multi-device dispatch (BurstGathererConfig::devices[], or TRXHIP_DEVICES=...): staging batch b belongs to device entry
+// b % n and is that entry's host-pipe slot b / n; batches are opened in the rotating order 0, 1, 2, ... so consecutive
+// batches go to consecutive GPUs, and the completion thread waits for them in submission order -- which GPU ran a batch
+// never shows in the order a channel sees.  Every entry has its own trxhip_ctx (same tables), pinned slots and streams.
 #include <atomic>
 #include <cerrno>
 #include <chrono>
@@ -130,7 +138,37 @@ struct Batch {
 
 struct BurstGatherer::Impl {
 	BurstGathererConfig cfg;
-	trxhip_hostpipe *pipe = nullptr;
+	/* one entry per device of the list (one entry, the sigProcLibSetup() context, without a list) */
+	struct Dev {
+		trxhip_ctx *ctx = nullptr;
+		bool own_ctx = false;                   /* created by this gatherer (trxsigproc_create_context): destroyed with it */
+		trxhip_hostpipe *pipe = nullptr;
+		std::atomic<uint64_t> n_batches{0};
+	};
+	std::vector<Dev> dev;
+	std::mutex life_mu;                         /* start() / stop() against each other */
+	std::atomic<int> users{0};                  /* threads inside pushSlot() / pull() */
+	std::atomic<bool> reconfig{false};          /* start() is replacing pipes, batches and rings: entrants leave at once */
+	struct User {                               /* entry ticket of pushSlot() / pull() */
+		Impl &m;
+		bool ok;
+		explicit User(Impl &mm) : m(mm)
+		{
+			m.users.fetch_add(1, std::memory_order_seq_cst);
+			ok = !m.reconfig.load(std::memory_order_seq_cst);
+		}
+		~User() { m.users.fetch_sub(1, std::memory_order_seq_cst); }
+	};
+	trxhip_hostpipe *pipe_of(int b) const { return dev[(size_t)b % dev.size()].pipe; }
+	int slot_of(int b) const { return b / (int)dev.size(); }
+	void release_devices()
+	{
+		for (Dev &d : dev) {
+			if (d.pipe) trxhip_hostpipe_destroy(d.pipe);
+			if (d.own_ctx && d.ctx) trxsigproc_destroy_context(d.ctx);
+		}
+		dev.clear();
+	}
 	size_t payload = 0, entry_bytes = 0, stride = 0;
 	std::vector<Batch> batch;
 	std::vector<Chan> chan;
@@ -187,7 +225,8 @@ struct BurstGatherer::Impl {
 				for (uint32_t i = 0; i < b.count; i++)                       /* a producer may still be inside its memcpy */
 					while (b.slot[i].ready.load(std::memory_order_acquire) != b.epoch)
 						std::this_thread::yield();
-				(void)trxhip_hostpipe_submit(pipe, s, b.count);               /* a failure surfaces in wait() */
+				(void)trxhip_hostpipe_submit(pipe_of(s), slot_of(s), b.count);   /* a failure surfaces in wait() */
+				dev[(size_t)s % dev.size()].n_batches++;
 				lk.lock();
 				n_batches++;
 				flight_q.push_back(s);
@@ -225,7 +264,7 @@ struct BurstGatherer::Impl {
 			flight_q.pop_front();
 			Batch &b = batch[s];
 			lk.unlock();
-			const bool ok = trxhip_hostpipe_wait(pipe, s) == TRXHIP_OK;
+			const bool ok = trxhip_hostpipe_wait(pipe_of(s), slot_of(s)) == TRXHIP_OK;
 			/* counting sort of the batch by channel (stable: arrival order within a channel is kept), then one lock and
 			 * one wake-up per channel */
 			const size_t nch = chan.size();
@@ -293,14 +332,34 @@ BurstGatherer::BurstGatherer(const BurstGathererConfig &cfg) : impl_(new Impl())
 BurstGatherer::~BurstGatherer()
 {
 	stop();
-	if (impl_->pipe)
-		trxhip_hostpipe_destroy(impl_->pipe);
+	impl_->release_devices();
 	delete impl_;
+}
+
+/* the device list: cfg.devices[], else TRXHIP_DEVICES=0,1,..., else empty (= the sigProcLibSetup() context alone) */
+static std::vector<int> device_list(const BurstGathererConfig &cfg)
+{
+	std::vector<int> v;
+	if (cfg.n_devices > 0) {
+		for (int k = 0; k < cfg.n_devices && k < TRX_GATHERER_MAX_DEVICES; k++)
+			v.push_back(cfg.devices[k]);
+	} else if (const char *e = getenv("TRXHIP_DEVICES")) {
+		while (*e && v.size() < TRX_GATHERER_MAX_DEVICES) {
+			char *end = nullptr;
+			const long d = strtol(e, &end, 10);
+			if (end == e)
+				break;
+			v.push_back((int)d);
+			e = (*end == ',') ? end + 1 : end;
+		}
+	}
+	return v;
 }
 
 bool BurstGatherer::start()
 {
 	Impl &m = *impl_;
+	std::lock_guard<std::mutex> life(m.life_mu);
 	if (m.running || !trxsigproc_context() || m.cfg.chans == 0 || m.cfg.chans > 65535)
 		return false;
 	trxhip_hostpipe_cfg c;
@@ -309,41 +368,64 @@ bool BurstGatherer::start()
 	c.depth = m.cfg.depth;
 	c.burst_len = (int32_t)m.cfg.burst_len;
 	c.sps = m.cfg.sps;
+	size_t stride, payload;
 	if (m.cfg.trxd_version < 0) {
 		c.soft_stride = m.cfg.egprs ? EDGE_BURST_NBITS : NORMAL_BURST_NBITS;
-		m.stride = c.soft_stride;
-		m.payload = m.stride * sizeof(float);
+		stride = c.soft_stride;
+		payload = stride * sizeof(float);
 	} else {
 		if (m.cfg.trxd_version > 1)
 			return false;
 		c.pkt_stride = m.cfg.egprs ? 456 : 160;
-		m.stride = c.pkt_stride;
-		m.payload = m.stride;
+		stride = c.pkt_stride;
+		payload = stride;
 	}
-	m.entry_bytes = (sizeof(Entry) + m.payload + 15) & ~(size_t)15;
-	c.flags = TRXHIP_FLAG_SLICE;
+	c.flags = TRXHIP_FLAG_SLICE | (m.cfg.exact_demod ? TRXHIP_FLAG_EXACT_DEMOD : 0);
 	c.threshold = BURST_THRESH;
 	c.full_scale = (float)m.cfg.rxFullScale;
 	c.rssi_offset = (float)m.cfg.rssi_offset;
-	if (m.cfg.n_paths < 0 || m.cfg.n_paths > 8)
+	if (m.cfg.n_paths < 0 || m.cfg.n_paths > 8 || m.cfg.n_devices < 0 || m.cfg.n_devices > TRX_GATHERER_MAX_DEVICES)
 		return false;
 	c.n_paths = m.cfg.n_paths > 1 ? m.cfg.n_paths : 0;
-	if (m.pipe) {                                                  /* restart: the previous run's staging slots, streams, events */
-		trxhip_hostpipe_destroy(m.pipe);
-		m.pipe = nullptr;
+
+	/* From here on the previous run's pinned slots, batches and rings are replaced: no push() / pull() may be inside.  They
+	 * count themselves in `users`; with `reconfig` raised new entrants leave at once, the ones already inside finish (a
+	 * stopped gatherer blocks nobody: pull() on an empty FIFO returns -EIO, pushSlot() returns 0). */
+	m.reconfig.store(true, std::memory_order_seq_cst);
+	while (m.users.load(std::memory_order_seq_cst) != 0)
+		std::this_thread::yield();
+	struct Lower { std::atomic<bool> &f; ~Lower() { f.store(false, std::memory_order_seq_cst); } } lower{m.reconfig};
+
+	m.release_devices();                                           /* restart: the previous run's contexts, staging slots, streams */
+	const std::vector<int> list = device_list(m.cfg);
+	m.dev = std::vector<Impl::Dev>(list.empty() ? 1 : list.size());
+	for (size_t k = 0; k < m.dev.size(); k++) {
+		Impl::Dev &d = m.dev[k];
+		if (list.empty()) {
+			d.ctx = trxsigproc_context();
+		} else {
+			d.ctx = trxsigproc_create_context(list[k]);
+			d.own_ctx = true;
+		}
+		if (!d.ctx || trxhip_hostpipe_create(d.ctx, &c, &d.pipe) != TRXHIP_OK) {
+			m.release_devices();
+			return false;
+		}
 	}
-	if (trxhip_hostpipe_create(trxsigproc_context(), &c, &m.pipe) != TRXHIP_OK)
-		return false;
+	m.stride = stride;
+	m.payload = payload;
+	m.entry_bytes = (sizeof(Entry) + m.payload + 15) & ~(size_t)15;
+	const int n_batch = m.cfg.depth * (int)m.dev.size();
 	std::lock_guard<std::mutex> g(m.mu);
-	m.batch = std::vector<Batch>(m.cfg.depth);
+	m.batch = std::vector<Batch>(n_batch);
 	m.free_q.clear(); m.closed_q.clear(); m.flight_q.clear();
-	for (int s = 0; s < m.cfg.depth; s++) {
-		trxhip_hostpipe_slot_buffers(m.pipe, s, &m.batch[s].h);
+	for (int s = 0; s < n_batch; s++) {
+		trxhip_hostpipe_slot_buffers(m.pipe_of(s), m.slot_of(s), &m.batch[s].h);
 		m.batch[s].slot = std::vector<Slot>(m.cfg.max_batch);
 		for (size_t k = 0; k < m.cfg.max_batch; k++)
 			m.batch[s].slot[k].ready.store(0, std::memory_order_relaxed);
 		if (s)
-			m.free_q.push_back(s);
+			m.free_q.push_back(s);                                 /* opened in the order 0, 1, 2, ...: round-robin over the devices */
 	}
 	if (m.chan.size() != m.cfg.chans) {
 		m.chan = std::vector<Chan>(m.cfg.chans);
@@ -369,6 +451,7 @@ bool BurstGatherer::start()
 void BurstGatherer::stop()
 {
 	Impl &m = *impl_;
+	std::lock_guard<std::mutex> life(m.life_mu);                   /* two stop() calls: the second finds it stopped */
 	if (!m.running)
 		return;
 	{
@@ -409,8 +492,12 @@ bool BurstGatherer::push(size_t c, const BurstRequest &rq)
 size_t BurstGatherer::pushSlot(const size_t *chans, const BurstRequest *rqs, size_t n, bool *accepted)
 {
 	Impl &m = *impl_;
-	if (!chans || !rqs || m.stopping || !m.running)
+	Impl::User user(m);
+	if (!user.ok || !chans || !rqs || m.stopping || !m.running) {
+		if (accepted)
+			for (size_t k = 0; k < n; k++) accepted[k] = false;
 		return 0;
+	}
 	/* the FIFO rule first, per channel (radioInterface.cpp:277-280: FIFO full, burst deleted) */
 	enum { STACK = 64 };
 	uint16_t ok_idx_stack[STACK];
@@ -515,13 +602,15 @@ size_t BurstGatherer::pushSlot(const size_t *chans, const BurstRequest *rqs, siz
 int BurstGatherer::pull(size_t c, BurstIndication *bi, uint8_t *pkt, size_t *pkt_len)
 {
 	Impl &m = *impl_;
-	if (c >= m.chan.size() || !bi)
+	Impl::User user(m);
+	if (!user.ok || c >= m.chan.size() || !bi)
 		return -EIO;
 	Chan &ch = m.chan[c];
 	if (ch.tail.load(std::memory_order_acquire) == ch.head) {         /* empty: block, as the reference's FIFO read does (:683) */
 		std::unique_lock<std::mutex> lk(ch.mu);
 		ch.waiting.store(1, std::memory_order_seq_cst);
-		ch.cv.wait(lk, [&] { return ch.tail.load(std::memory_order_seq_cst) != ch.head || m.stopping || !m.running; });
+		ch.cv.wait(lk, [&] { return ch.tail.load(std::memory_order_seq_cst) != ch.head || m.stopping || !m.running ||
+					    m.reconfig.load(std::memory_order_seq_cst); });
 		ch.waiting.store(0, std::memory_order_relaxed);
 		if (ch.tail.load(std::memory_order_acquire) == ch.head)
 			return -EIO;
@@ -551,6 +640,7 @@ bool BurstGatherer::setTrxdVersion(size_t c, int version)
 	Impl &m = *impl_;
 	if (m.cfg.trxd_version < 0 || version < 0 || version > 1)
 		return false;                                                  /* float mode is gatherer-wide */
+	std::lock_guard<std::mutex> life(m.life_mu);                       /* (creates the channel table before the first start()) */
 	if (m.chan.size() != m.cfg.chans) {                                /* before the first start(): create the channels now */
 		m.chan = std::vector<Chan>(m.cfg.chans);
 		for (size_t k = 0; k < m.cfg.chans; k++)
@@ -565,5 +655,8 @@ bool BurstGatherer::setTrxdVersion(size_t c, int version)
 uint64_t BurstGatherer::rejected() const { return impl_->n_rejected.load(); }
 uint64_t BurstGatherer::batches() const { return impl_->n_batches.load(); }
 uint64_t BurstGatherer::dropped() const { return impl_->n_dropped.load(); }
+const BurstGathererConfig &BurstGatherer::config() const { return impl_->cfg; }
+size_t BurstGatherer::devices() const { return impl_->dev.size(); }
+uint64_t BurstGatherer::batchesOn(size_t entry) const { return entry < impl_->dev.size() ? impl_->dev[entry].n_batches.load() : 0; }
 
 TRX_SHIM_NS_END

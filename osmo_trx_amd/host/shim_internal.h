@@ -6,6 +6,10 @@
 
 /* the context sigProcLibSetup() created (sigProcLib.cpp) */
 extern "C" trxhip_ctx *trxsigproc_context(void);
+/* a further context on `device` with the SAME tables (generated once per process, uploaded with
+ * trxhip_create_from_tables): the multi-device gatherer owns one per devices[] entry and destroys it itself */
+extern "C" trxhip_ctx *trxsigproc_create_context(int device);
+extern "C" void trxsigproc_destroy_context(trxhip_ctx *ctx);
 
 TRX_SHIM_NS_BEGIN
 /* result record + soft row of the C ABI -> the fields pullRadioVector() fills in struct trx_ul_burst_ind

@@ -104,6 +104,31 @@ size_t soft_cap(int sps, size_t burst_size) { size_t n = soft_len(sps, burst_siz
 /* the context for the other host classes of the shim (MultiArfcnRx, BurstGatherer) */
 extern "C" trxhip_ctx *trxsigproc_context(void) { return g_ctx; }
 
+/* Further contexts for the multi-device gatherer: the table blob is generated ONCE per process on the host (sigProcLibSetup()'s
+ * work, sigProcLib.cpp:2139-2172) and every device gets a plain upload of it -- what SURVEY section 5 allows inside one process
+ * where bench.py's one-process-per-GPU form uses the RCCL broadcast. */
+extern "C" trxhip_ctx *trxsigproc_create_context(int device)
+{
+	static std::mutex mu;
+	static std::vector<char> blob;
+	std::lock_guard<std::mutex> lk(mu);
+	if (blob.empty()) {
+		blob.resize(trxhip_tables_size());
+		if (trxhip_tables_generate_host(blob.data(), blob.size()) != TRXHIP_OK) {
+			blob.clear();
+			return nullptr;
+		}
+	}
+	trxhip_ctx *ctx = nullptr;
+	const int rc = trxhip_create_from_tables(&ctx, device, blob.data(), blob.size());
+	if (rc != TRXHIP_OK) {
+		fprintf(stderr, "trxsigproc: device %d: %s\n", device, trxhip_strerror(rc));
+		return nullptr;
+	}
+	return ctx;
+}
+extern "C" void trxsigproc_destroy_context(trxhip_ctx *ctx) { trxhip_destroy(ctx); }
+
 /* Which headers this library was compiled against, and the object layout it therefore assumes: a caller (or
  * tests/test_shim_abi.py) compares these with its own sizeof/offsetof before handing objects across. */
 extern "C" const char *trxsigproc_abi(void) { return TRX_SHIM_ABI; }
@@ -367,6 +392,7 @@ void trxsigproc_fill_indication(BurstIndication &bi, const BurstRequest &rq, con
 	bi.ci = 0.0f;
 	bi.rc = r.rc;
 	bi.energy = r.energy;
+	bi.type = (uint8_t)rq.type;
 	if (rq.type != OFF)
 		bi.rssi = (double)r.rssi + rssi_offset;                /* Transceiver.cpp:751 */
 	if (bi.idle)

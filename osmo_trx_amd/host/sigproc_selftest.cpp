@@ -7,6 +7,7 @@
 //   sigproc_selftest va <cfile> <tsc> <out.f32>
 //   sigproc_selftest sch <cfile> <0 full | 1 narrow | 2 buffer> <out.txt>
 //   sigproc_selftest batch <iq.s16> <params.bin> <n> <sps> <burst_len> <out_results.bin> <out_soft.bin>
+//   sigproc_selftest pullrv <iq.s16> <params.bin> <n> <chans> <muted_chan | -1> <exact 0|1> <out.bin>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -18,6 +19,7 @@
 #include <thread>
 
 #include "trxBatch.h"
+#include "trxPullRadioVector.h"
 #include "MultiArfcnRx.h"
 
 // "signalvector is owning despite claiming not to" (Transceiver.cpp:648-654): a vector built over memory it must not
@@ -57,6 +59,31 @@ static int abi_report()
 				 offsetof(struct estim_burst_params, ci), sizeof(Vector<float>) };
 	int bad = 0;
 	printf("abi %s\n", trxsigproc_abi());
+	{
+		/* struct trx_ul_burst_ind as this executable's compiler lays it out vs the library's (trxPullRadioVector.h) */
+		size_t lb[14];
+		trxsigproc_abi_layout_bi(lb);
+		const size_t mb[14] = { sizeof(struct trx_ul_burst_ind), offsetof(struct trx_ul_burst_ind, rx_burst),
+					offsetof(struct trx_ul_burst_ind, nbits), offsetof(struct trx_ul_burst_ind, fn),
+					offsetof(struct trx_ul_burst_ind, tn), offsetof(struct trx_ul_burst_ind, rssi),
+					offsetof(struct trx_ul_burst_ind, toa), offsetof(struct trx_ul_burst_ind, noise),
+					offsetof(struct trx_ul_burst_ind, idle), offsetof(struct trx_ul_burst_ind, modulation),
+					offsetof(struct trx_ul_burst_ind, tss), offsetof(struct trx_ul_burst_ind, tsc),
+					offsetof(struct trx_ul_burst_ind, ci), sizeof(enum Modulation) };
+		static const char *const bn[14] = { "sizeof_trx_ul_burst_ind", "offsetof_bi_rx_burst", "offsetof_bi_nbits", "offsetof_bi_fn",
+						    "offsetof_bi_tn", "offsetof_bi_rssi", "offsetof_bi_toa", "offsetof_bi_noise",
+						    "offsetof_bi_idle", "offsetof_bi_modulation", "offsetof_bi_tss", "offsetof_bi_tsc",
+						    "offsetof_bi_ci", "sizeof_enum_Modulation" };
+		for (int k = 0; k < 14; k++) {
+			printf("%s %zu %zu\n", bn[k], mb[k], lb[k]);
+			bad |= mb[k] != lb[k];
+		}
+#ifdef TRX_HAVE_REFERENCE_PROTO_TRXD
+		printf("trx_ul_burst_ind reference\n");
+#else
+		printf("trx_ul_burst_ind declared\n");
+#endif
+	}
 	static const char *const name[8] = { "sizeof_signalVector", "sizeof_SoftVector", "sizeof_complex", "sizeof_ebp",
 					     "offsetof_ebp_toa", "offsetof_ebp_tsc", "offsetof_ebp_ci", "sizeof_Vector_float" };
 	for (int k = 0; k < 8; k++) {
@@ -319,8 +346,69 @@ int main(int argc, char **argv)
 		printf("gather bursts %zu seconds %.6f mbursts_per_s %.3f batches %llu push_retries %llu producers %zu consumers %zu fifo_depth %zu\n",
 		       n * repeat, dt, n * repeat / dt * 1e-6, (unsigned long long)g.batches(), (unsigned long long)retries.load(), producers,
 		       chans, fifo_depth);
+		printf("devices %zu batches_per_device", g.devices());      /* TRXHIP_DEVICES=0,0: two contexts on one GPU */
+		for (size_t k = 0; k < g.devices(); k++) printf(" %llu", (unsigned long long)g.batchesOn(k));
+		printf("\n");
 		g.stop();
 		FILE *o = fopen(argv[9], "wb");
+		fwrite(rec.data(), sizeof(Rec), n, o);
+		fclose(o);
+		sigProcLibDestroy();
+		return 0;
+	}
+
+	// pullrv: Transceiver::pullRadioVector(chan, bi) over the gatherer (trxPullRadioVector.h).  Burst i belongs to channel
+	// i % chans (fn = i / chans, tn = i & 7); one thread pushes the slots in order, one consumer per channel pulls with its
+	// own RxChanState (channel `muted` has mMuted set).  out.bin: per burst, in input order,
+	// {int32 code; uint32 nbits, fn, tn, idle, modulation, tss, tsc; float ci; double rssi, toa, noise; float rx_burst[444];
+	//  uint32 rx_clipping, rx_no_burst_detected}  (the channel's counters after this burst)
+	if (!strcmp(argv[1], "pullrv") && argc == 9) {
+		std::vector<char> iq = slurp(argv[2]), pr = slurp(argv[3]);
+		const size_t n = atol(argv[4]), chans = atol(argv[5]);
+		const long muted = atol(argv[6]);
+		BurstGathererConfig cfg;
+		memset(&cfg, 0, sizeof(cfg));
+		cfg.chans = chans; cfg.max_batch = 256; cfg.timeout_us = 200; cfg.fifo_depth = 32; cfg.sps = 4; cfg.burst_len = 625;
+		cfg.rxFullScale = 32767.0; cfg.rssi_offset = -3.5; cfg.egprs = false; cfg.trxd_version = -1; cfg.depth = 4;
+		cfg.exact_demod = atoi(argv[7]) != 0;
+		BurstGatherer g(cfg);
+		if (!g.start()) { fprintf(stderr, "BurstGatherer::start failed\n"); return 5; }
+#pragma pack(push, 1)
+		struct Rec { int32_t code; uint32_t nbits, fn, tn, idle, modulation, tss, tsc; float ci; double rssi, toa, noise; float rx[444];
+			     uint32_t rx_clipping, rx_no_burst_detected; };
+#pragma pack(pop)
+		std::vector<Rec> rec(n);
+		memset(rec.data(), 0, n * sizeof(Rec));
+		const int16_t *s16 = reinterpret_cast<const int16_t *>(iq.data());
+		std::vector<std::thread> th;
+		th.emplace_back([&] {
+			for (size_t i = 0; i < n; i++) {
+				const unsigned char *p = reinterpret_cast<const unsigned char *>(pr.data()) + 8 * i;
+				BurstRequest rq;
+				memset(&rq, 0, sizeof(rq));
+				rq.iq = s16 + i * 625 * 2; rq.type = (CorrType)p[0]; rq.tsc = p[1]; rq.max_toa = p[2] | (p[3] << 8);
+				rq.fn = (uint32_t)(i / chans); rq.tn = (uint8_t)(i & 7);
+				while (!g.push(i % chans, rq)) std::this_thread::yield();
+			}
+		});
+		for (size_t c = 0; c < chans; c++)
+			th.emplace_back([&, c] {
+				RxChanState st;
+				st.mMuted = (long)c == muted;
+				struct trx_ul_burst_ind bi;
+				for (size_t i = c; i < n; i += chans) {
+					memset(&bi, 0xa5, sizeof(bi));                     /* every field the reference initialises must be written */
+					Rec &r = rec[i];
+					r.code = trxPullRadioVector(g, st, c, &bi);
+					r.nbits = bi.nbits; r.fn = bi.fn; r.tn = bi.tn; r.idle = bi.idle; r.modulation = (uint32_t)bi.modulation;
+					r.tss = bi.tss; r.tsc = bi.tsc; r.ci = bi.ci; r.rssi = bi.rssi; r.toa = bi.toa; r.noise = bi.noise;
+					if (r.code == 0 && !bi.idle) memcpy(r.rx, bi.rx_burst, bi.nbits * sizeof(float));
+					r.rx_clipping = st.ctrs.rx_clipping; r.rx_no_burst_detected = st.ctrs.rx_no_burst_detected;
+				}
+			});
+		for (auto &t : th) t.join();
+		g.stop();
+		FILE *o = fopen(argv[8], "wb");
 		fwrite(rec.data(), sizeof(Rec), n, o);
 		fclose(o);
 		sigProcLibDestroy();

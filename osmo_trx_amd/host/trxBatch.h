@@ -48,6 +48,7 @@ struct BurstIndication {          /* struct trx_ul_burst_ind (proto_trxd.h:24-37
 	float ci;
 	int rc;                /* detectAnyBurst() result, for the rate counters (Transceiver.cpp:769-781) */
 	float energy;          /* energyDetect(): avg = sqrt(energy) feeds the caller's noise average (:741-748) */
+	uint8_t type;          /* expectedCorrType() of the slot as it was pushed (IDLE slots update the noise ring, :743-748) */
 };
 /** Process n bursts in one GPU launch.  egprs: some slots may carry 8-PSK (cfg->egprs): soft output is 444 wide.
  *  Host buffers go through the pinned, stream-pipelined path of the C ABI (trxhip_hostpipe_*): no per-call
@@ -76,6 +77,7 @@ int trxdPackBurstInd(uint8_t *buf, const BurstIndication *bi, unsigned version);
  * each burst straight into the pinned staging buffer of the batch being filled, launches the batch when it holds
  * `max_batch` bursts or its first burst has waited `timeout_us`, and hands the results back per channel in
  * arrival order. */
+#define TRX_GATHERER_MAX_DEVICES 16
 struct BurstGathererConfig {
 	size_t chans;             /* number of ARFCN channels (FIFOs) */
 	size_t max_batch;         /* launch when this many bursts are gathered (all channels together) */
@@ -91,6 +93,18 @@ struct BurstGathererConfig {
 	int depth;                /* staging batches in flight (>= 2) */
 	int n_paths;              /* diversity paths per burst, radioVector::chans() (0 / 1: none): the path with the highest energy is
 	                           * demodulated, rssi and energy come from the path average (Transceiver.cpp:723-751) */
+	/* Multi-GPU dispatch (north star: "shard the batch across the 8 GPUs ... host code stays C++").  n_devices = 0: the one
+	 * device of sigProcLibSetup() (TRXHIP_DEVICE) -- unless the environment names a list, TRXHIP_DEVICES=0,1,2,3,4,5,6,7.
+	 * n_devices >= 1: every entry of devices[] gets its own trxhip_ctx (tables generated once on the host, uploaded per device
+	 * with trxhip_create_from_tables: SURVEY section 5 -- no collective needed inside one process), its own host pipe with
+	 * `depth` pinned staging batches and its own streams; gathered batches go to the entries round-robin and are delivered
+	 * in submission order, so a channel's bursts still come back in push order.  An entry may repeat a device (two
+	 * contexts on one GPU: what the single-GPU test runs).  The reference's counterpart is one RxUpper thread per ARFCN
+	 * (Transceiver.cpp:1330-1351): here the ARFCNs' bursts share batches and the batches share the GPUs. */
+	int n_devices;
+	int devices[TRX_GATHERER_MAX_DEVICES];
+	bool exact_demod;         /* TRXHIP_FLAG_EXACT_DEMOD: the reference's two FIR stages, soft bits bit-identical to generic C
+	                           * (default false: the fused demodulator, include/trxhip.h) */
 };
 class BurstGatherer {
 public:
@@ -118,6 +132,9 @@ public:
 	uint64_t batches() const;
 	uint64_t dropped() const;
 	uint64_t rejected() const;
+	const BurstGathererConfig &config() const;       /* as normalised by the constructor */
+	size_t devices() const;                          /* device entries in use (1 without a list) */
+	uint64_t batchesOn(size_t entry) const;          /* batches submitted to devices[entry] */
 private:
 	struct Impl;
 	Impl *impl_;

@@ -2,7 +2,11 @@
 // One producer thread and one consumer thread per channel on an oversubscribed machine; checks the class's contract
 // (radioInterface.cpp:272-291, Transceiver.cpp:1229-1253): every accepted burst is delivered exactly once, to its own
 // channel, in push order; dropped bursts (FIFO full) are never delivered.
-//   gatherer_stress <channels> <pushes_per_channel> <max_batch> <timeout_us> <trxd_version> [restart]
+//   gatherer_stress <channels> <pushes_per_channel> <max_batch> <timeout_us> <trxd_version> [restart] [n_devices] [churn]
+// n_devices > 0: the multi-device dispatcher on that many fake devices (every one must see its share of the batches, the
+// per-channel order must not show which device ran a batch).  churn = 1: a third pass in which stop() / start() are called
+// WHILE producers and consumers are inside push() / pull() (round 3's advisor finding: start() freed the pinned slots and
+// rings under them) -- nothing may crash or trip the sanitizer; deliveries between two restarts stay ordered.
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -16,6 +20,58 @@ using namespace trxhip_sa;
 #endif
 
 extern "C" int stub_live_pipes(void);
+extern "C" int stub_live_contexts(void);
+extern "C" long stub_submits_on(int device);
+
+/* stop() / start() under fire: producers and consumers keep calling while the gatherer is cycled */
+static void churn(BurstGatherer &g, size_t nch, std::atomic<long> &errors)
+{
+	std::atomic<bool> quit{false};
+	std::atomic<uint64_t> pushed{0}, pulled{0};
+	std::vector<std::thread> th;
+	for (size_t c = 0; c < nch; c++) {
+		th.emplace_back([&, c] {
+			std::vector<int16_t> iq(625 * 2, 0);
+			uint32_t fn = 0;
+			while (!quit.load()) {
+				fn++;
+				iq[0] = (int16_t)(fn & 0x7fff); iq[1] = (int16_t)(fn >> 15); iq[2] = (int16_t)c;
+				BurstRequest rq;
+				memset(&rq, 0, sizeof(rq));
+				rq.iq = iq.data(); rq.type = TSC; rq.tsc = fn & 7; rq.max_toa = 3; rq.fn = fn; rq.tn = fn & 7;
+				if (g.push(c, rq)) pushed++; else std::this_thread::yield();
+			}
+		});
+		th.emplace_back([&, c] {
+			BurstIndication bi;
+			uint32_t last_fn = 0;
+			while (!quit.load()) {
+				memset(&bi, 0, sizeof(bi));
+				const int rc = g.pull(c, &bi);
+				if (rc == -5) { last_fn = 0; std::this_thread::yield(); continue; }   /* stopped: a restart begins from empty FIFOs */
+				pulled++;
+				if ((size_t)bi.energy != c) { errors++; fprintf(stderr, "churn chan %zu: foreign burst (chan %g)\n", c, bi.energy); }
+				if (bi.fn <= last_fn) {
+					/* a restart between two pulls resets the FIFO: fn may go back only across a -EIO ... or when the consumer did
+					 * not see the stop at all (it was not pulling): accept a drop back, never a repeat of the same fn */
+					if (bi.fn == last_fn) { errors++; fprintf(stderr, "churn chan %zu: fn %u twice\n", c, bi.fn); }
+				}
+				last_fn = bi.fn;
+			}
+		});
+	}
+	for (int k = 0; k < 40; k++) {
+		std::this_thread::sleep_for(std::chrono::milliseconds(5));
+		g.stop();
+		if (k & 1) g.stop();                                           /* a second stop() finds it stopped */
+		if (!g.start()) { errors++; fprintf(stderr, "churn: restart %d failed\n", k); break; }
+	}
+	quit.store(true);
+	g.stop();                                                          /* wakes blocked consumers; producers see `stopping` */
+	for (auto &t : th) t.join();
+	printf("churn pushed %llu pulled %llu\n", (unsigned long long)pushed.load(), (unsigned long long)pulled.load());
+	if (pulled.load() == 0 || pulled.load() > pushed.load()) { errors++; fprintf(stderr, "churn accounting\n"); }
+}
 static const uint32_t END_FN = 0xfffff0;       /* below 2^24: exact in the stub's float echo */
 
 static int run_once(BurstGatherer &g, size_t nch, uint32_t per_chan, int version, std::atomic<long> &errors)
@@ -98,6 +154,10 @@ int main(int argc, char **argv)
 	cfg.fifo_depth = 32; cfg.sps = 4; cfg.burst_len = 625; cfg.rxFullScale = 32767.0; cfg.rssi_offset = 0.0;
 	cfg.egprs = false; cfg.trxd_version = argc > 5 ? atoi(argv[5]) : -1; cfg.depth = 4;
 	const bool restart = argc > 6 && atoi(argv[6]);
+	const int n_dev = argc > 7 ? atoi(argv[7]) : 0;
+	const bool do_churn = argc > 8 && atoi(argv[8]);
+	cfg.n_devices = n_dev;
+	for (int k = 0; k < n_dev; k++) cfg.devices[k] = k;
 	std::atomic<long> errors{0};
 	{
 		BurstGatherer g(cfg);
@@ -106,6 +166,18 @@ int main(int argc, char **argv)
 				if (!g.setTrxdVersion(c, (int)(c & 1))) errors++;      /* per-channel header version (mVersionTRXD[chan]) */
 		if (!g.start()) { fprintf(stderr, "start failed\n"); return 2; }
 		run_once(g, nch, per_chan, cfg.trxd_version, errors);
+		if (n_dev > 0) {
+			/* every fake device got its share: consecutive batches go to consecutive devices */
+			if (g.devices() != (size_t)n_dev || stub_live_contexts() != n_dev || stub_live_pipes() != n_dev) { errors++; fprintf(stderr, "device entries\n"); }
+			long lo = 1L << 60, hi = 0, sum = 0;
+			for (int k = 0; k < n_dev; k++) {
+				const long v = stub_submits_on(k);
+				if ((uint64_t)v != g.batchesOn(k)) { errors++; fprintf(stderr, "device %d: stub saw %ld, gatherer %llu\n", k, v, (unsigned long long)g.batchesOn(k)); }
+				lo = v < lo ? v : lo; hi = v > hi ? v : hi; sum += v;
+			}
+			printf("devices %d batches_per_device %ld..%ld\n", n_dev, lo, hi);
+			if ((uint64_t)sum != g.batches() || hi - lo > 1) { errors++; fprintf(stderr, "round-robin: %ld..%ld of %llu\n", lo, hi, (unsigned long long)g.batches()); }
+		}
 		/* an EDGE slot on a gatherer without egprs rows is refused, not written past the 148-float payload */
 		{
 			std::vector<int16_t> iq(625 * 2, 0);
@@ -125,12 +197,17 @@ int main(int argc, char **argv)
 			for (int k = 0; k < 6; k++) { const int rc = g.pull(0, &bi); if (rc == -5) { n_eio++; break; } n_ok++; }
 			if (n_eio != 1) { errors++; fprintf(stderr, "pull after stop: %d delivered, no -EIO\n", n_ok); }
 			if (!g.start()) { errors++; fprintf(stderr, "restart failed\n"); }
-			if (stub_live_pipes() != 1) { errors++; fprintf(stderr, "%d hostpipes alive after restart\n", stub_live_pipes()); }
+			if (stub_live_pipes() != (n_dev > 0 ? n_dev : 1)) { errors++; fprintf(stderr, "%d hostpipes alive after restart\n", stub_live_pipes()); }
 			run_once(g, nch, per_chan / 4 + 1, cfg.trxd_version, errors);
+		}
+		if (do_churn) {
+			g.stop();
+			if (!g.start()) { errors++; fprintf(stderr, "start before churn failed\n"); }
+			churn(g, nch, errors);
 		}
 		g.stop();
 	}
-	if (stub_live_pipes() != 0) { errors++; fprintf(stderr, "%d hostpipes leaked\n", stub_live_pipes()); }
+	if (stub_live_pipes() != 0 || stub_live_contexts() != 0) { errors++; fprintf(stderr, "%d hostpipes / %d contexts leaked\n", stub_live_pipes(), stub_live_contexts()); }
 	/* EDGE rows with egprs = false used to overflow the ring entry: egprs gatherer, float mode, 444-bit rows delivered */
 	{
 		cfg.egprs = true; cfg.trxd_version = -1; cfg.chans = 1;

@@ -14,6 +14,7 @@
 #include "shim_internal.h"
 
 struct trxhip_hostpipe {
+	trxhip_ctx *ctx;
 	trxhip_hostpipe_cfg cfg;
 	std::vector<trxhip_hostpipe_slot> slot;
 	std::vector<std::atomic<int64_t>> done_ns;
@@ -29,10 +30,30 @@ static int64_t now_ns()
 }
 
 extern "C" trxhip_ctx *trxsigproc_context(void) { return reinterpret_cast<trxhip_ctx *>(0x1000); }
+/* fake devices of the multi-device gatherer: a context is an address that encodes its device; the stub counts the live ones
+ * and the submits each device saw */
+static std::atomic<int> g_live_ctx{0};
+static std::atomic<long> g_submits_on[64];
+extern "C" int stub_live_contexts(void) { return g_live_ctx.load(); }
+extern "C" long stub_submits_on(int device) { return g_submits_on[device & 63].load(); }
+extern "C" trxhip_ctx *trxsigproc_create_context(int device)
+{
+	if (device < 0 || device >= 64)
+		return nullptr;
+	g_live_ctx++;
+	return reinterpret_cast<trxhip_ctx *>((uintptr_t)0x100000 + (uintptr_t)device * 16);
+}
+extern "C" void trxsigproc_destroy_context(trxhip_ctx *ctx) { if (ctx) g_live_ctx--; }
+static int device_of(const trxhip_ctx *ctx)
+{
+	const uintptr_t a = reinterpret_cast<uintptr_t>(ctx);
+	return a >= 0x100000 ? (int)((a - 0x100000) / 16) : 63;        /* 63: the sigProcLibSetup() context */
+}
 
-extern "C" int trxhip_hostpipe_create(trxhip_ctx *, const trxhip_hostpipe_cfg *cfg, trxhip_hostpipe **out)
+extern "C" int trxhip_hostpipe_create(trxhip_ctx *ctx, const trxhip_hostpipe_cfg *cfg, trxhip_hostpipe **out)
 {
 	trxhip_hostpipe *p = new trxhip_hostpipe();
+	p->ctx = ctx;
 	p->cfg = *cfg;
 	p->slot.resize(cfg->depth);
 	p->done_ns = std::vector<std::atomic<int64_t>>(cfg->depth);
@@ -73,6 +94,7 @@ extern "C" int trxhip_hostpipe_submit(trxhip_hostpipe *p, int slot, size_t n)
 {
 	static thread_local std::mt19937 rng(12345);
 	trxhip_hostpipe_slot &h = p->slot[slot];
+	g_submits_on[device_of(p->ctx) & 63]++;
 	for (size_t i = 0; i < n; i++) {
 		const int16_t *iq = h.iq + i * p->cfg.burst_len * 2;
 		trxhip_burst_result &r = h.results[i];
@@ -115,6 +137,7 @@ void trxsigproc_fill_indication(BurstIndication &bi, const BurstRequest &rq, con
 {
 	bi.fn = rq.fn; bi.tn = rq.tn; bi.rc = r.rc; bi.idle = r.idle != 0; bi.toa = r.toa; bi.tsc = r.tsc; bi.ci = r.ci;
 	bi.energy = r.amp_re;                                          /* the stub's channel stamp */
+	bi.type = (uint8_t)rq.type;
 	bi.rssi = r.rssi + rssi_offset;
 	bi.nbits = bi.idle ? 0 : 4u * r.nbits_div4;
 	bi.modulation = bi.nbits == EDGE_BURST_NBITS ? 1 : 0;

@@ -243,6 +243,52 @@ def convolve(x, h, start, length, complex_taps):
     return y
 
 
+class RxState(C.Structure):
+    _fields_ = [("noises", C.c_float * 20), ("itr", C.c_size_t), ("noise_lev", C.c_float), ("muted", C.c_int),
+                ("rx_empty_burst", C.c_uint), ("rx_clipping", C.c_uint), ("rx_no_burst_detected", C.c_uint)]
+
+
+class UlBurstInd(C.Structure):
+    _fields_ = [("rx_burst", C.c_float * 444), ("nbits", C.c_uint), ("fn", C.c_uint32), ("tn", C.c_uint8), ("rssi", C.c_double),
+                ("toa", C.c_double), ("noise", C.c_double), ("idle", C.c_int), ("modulation", C.c_int), ("tss", C.c_uint8),
+                ("tsc", C.c_uint8), ("ci", C.c_float)]
+
+
+def pull_radio_vector_chain(iq, params, chans, muted=-1, full_scale=32767.0, rssi_offset=0.0):
+    """Transceiver::pullRadioVector() for a schedule of slots (burst i on channel i % chans, fn = i // chans, tn = i & 7): the
+    oracle's DSP per burst (energyDetect -> detectAnyBurst -> demodAnyBurst) inside the restated wrapper with one
+    orc_rx_state per channel.  Returns a list of (code, UlBurstInd, rx_clipping, rx_no_burst_detected) in input order."""
+    L = lib()
+    L.orc_pull_radio_vector.restype = C.c_int
+    L.orc_pull_radio_vector.argtypes = [C.POINTER(RxState), C.c_int, C.c_uint32, C.c_uint8, C.c_float, C.c_int, C.POINTER(Ebp),
+                                        C.c_void_p, C.c_int, C.c_double, C.c_double, C.POINTER(UlBurstInd)]
+    L.orc_rx_state_init.argtypes = [C.POINTER(RxState)]
+    states = [RxState() for _ in range(chans)]
+    for c, st in enumerate(states):
+        L.orc_rx_state_init(C.byref(st))
+        st.muted = int(c == muted)
+    n = len(params)
+    out = []
+    soft = np.zeros(444, dtype=np.float32)
+    for i in range(n):
+        x = np.ascontiguousarray(iq[i].astype(np.float32))             # convert_short_float: no scaling
+        typ, tsc, max_toa = int(params["type"][i]), int(params["tsc"][i]), int(params["max_toa"][i])
+        ebp = Ebp()
+        rc, nsoft, pw = 0, 0, 0.0
+        if typ != OFF:
+            pw = float(L.orc_energy_detect(x.ctypes.data, 625, 80))
+            if typ != IDLE:
+                rc = L.orc_detect_any_burst(x.ctypes.data, 625, tsc, 4.0, 4, typ, max_toa, C.byref(ebp))
+                if rc > 0:
+                    nsoft = L.orc_demod_any_burst(x.ctypes.data, 625, rc, 4, C.byref(ebp), soft.ctypes.data)
+        bi = UlBurstInd()
+        st = states[i % chans]
+        code = L.orc_pull_radio_vector(C.byref(st), typ, i // chans, i & 7, pw, rc, C.byref(ebp), soft.ctypes.data, nsoft,
+                                       full_scale, rssi_offset, C.byref(bi))
+        out.append((code, bi, st.rx_clipping, st.rx_no_burst_detected))
+    return out
+
+
 def trxd_pack_batch(res, params, soft, meta, rssi_offset=0.0, pkt_stride=160):
     """pullRadioVector()'s bi -> trxd_send_burst_ind_v0/v1 bytes for a batch (Transceiver.cpp:694-814, proto_trxd.c:68-117).
     res RESULT_DTYPE[n], params PARAMS_DTYPE[n], soft float32[n, stride] (sliced), meta {fn, tn, version, tss}[n].

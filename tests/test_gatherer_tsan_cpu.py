@@ -55,10 +55,25 @@ def test_gatherer_order_and_exactly_once_under_tsan(tmp_path):
     assert r.returncode == 0 and "errors 0" in r.stdout, r.stdout[-4000:]
 
 
+@pytest.mark.timeout(900)
+def test_multi_device_dispatch_and_restart_under_fire_tsan(tmp_path):
+    """The C++ multi-device dispatcher (BurstGathererConfig::devices[]): two and five fake devices under ThreadSanitizer --
+    per-channel order and exactly-once delivery as on one device, batches dealt round-robin (every device within one batch of
+    the others), contexts and pipes released; then stop() / start() called 40 times WHILE 8 producers and 8 consumers are
+    inside push() / pull() (the advisor's use-after-free window of round 3)."""
+    exe = build(tmp_path, "gstress_tsan_md", ["-fsanitize=thread"])
+    for args in ((16, 16384, 64, 50, -1, 1, 2, 0), (8, 8192, 32, 30, 1, 0, 5, 1)):
+        r = run(exe, *args)
+        assert "ThreadSanitizer" not in r.stdout, r.stdout[-4000:]
+        assert r.returncode == 0 and "errors 0" in r.stdout, r.stdout[-4000:]
+        assert f"devices {args[6]} batches_per_device" in r.stdout
+    assert "churn pushed" in r.stdout
+
+
 @pytest.mark.timeout(600)
 def test_gatherer_under_asan(tmp_path):
     exe = build(tmp_path, "gstress_asan", ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"])
-    for args in ((8, 20000, 64, 50, -1, 1), (8, 20000, 128, 100, 0, 1)):
+    for args in ((8, 20000, 64, 50, -1, 1), (8, 20000, 128, 100, 0, 1), (8, 8000, 64, 50, -1, 1, 3, 1)):
         r = run(exe, *args)
         assert "AddressSanitizer" not in r.stdout and "runtime error" not in r.stdout, r.stdout[-4000:]
         assert r.returncode == 0 and "errors 0" in r.stdout, r.stdout[-4000:]

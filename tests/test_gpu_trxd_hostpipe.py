@@ -233,6 +233,101 @@ def test_burst_gatherer_per_channel_semantics(trx, tmp_path, version):
                 assert np.array_equal(g["body"], o_pkt)
 
 
+def test_multi_device_gatherer_two_contexts_equal_one(trx, tmp_path):
+    """The C++ multi-device dispatcher on the hardware a 1-GPU box has: TRXHIP_DEVICES=0,0 (and 0,0,0) gives the gatherer two
+    (three) contexts, host pipes and stream sets on device 0, batches dealt round-robin.  Every delivered record -- return code,
+    rc, TOA, C/I, rssi, fn / tn, and the datagram or soft row -- equals the single-context run bit for bit, and every entry ran
+    its share of the batches."""
+    from osmo_trx_amd import build as trx_build
+    trx_build.build_all()
+    n, chans = 8192, 16
+    iq, params, meta = mixed_workload(n)
+    (tmp_path / "iq.s16").write_bytes(iq.numpy().tobytes())
+    (tmp_path / "p.bin").write_bytes(params.tobytes())
+    env0 = {k: v for k, v in os.environ.items() if k != "TRXHIP_DEVICES"}
+    for exe in exes():
+        for version in (-1, 1):
+            ref = None
+            for devs in (None, "0,0", "0,0,0"):
+                out = tmp_path / "g.bin"
+                env = dict(env0) if devs is None else dict(env0, TRXHIP_DEVICES=devs)
+                txt = subprocess.run([exe, "gather", str(tmp_path / "iq.s16"), str(tmp_path / "p.bin"), str(n), str(chans),
+                                      "128", "200", str(version), str(out)], stdout=subprocess.PIPE, text=True, check=True, env=env).stdout
+                line = [l for l in txt.splitlines() if l.startswith("devices ")][0].split()
+                want = 1 if devs is None else devs.count(",") + 1
+                assert int(line[1]) == want, txt
+                per_dev = [int(x) for x in line[3:]]
+                assert len(per_dev) == want and min(per_dev) > 0 and max(per_dev) - min(per_dev) <= 1, txt
+                got = out.read_bytes()
+                if ref is None:
+                    ref = got
+                assert got == ref, (exe, version, devs)
+
+
+def test_pull_radio_vector_adapter_against_the_oracle_chain(trx, tmp_path):
+    """trxPullRadioVector(): Transceiver::pullRadioVector(chan, struct trx_ul_burst_ind *bi) over the gatherer, on a schedule of
+    TSC / RACH / IDLE / OFF slots on four channels (one of them muted), against the oracle's restatement of the same function
+    around the oracle's DSP: return codes, every field of bi -- noise from the 20-entry ring of IDLE slots, modulation, idle,
+    nbits -- the soft bits (exact demodulator: identical) and the two rate counters."""
+    from osmo_trx_amd import build as trx_build, synth
+    trx_build.build_all()
+    n, chans, muted = 1536, 4, 2
+    iq, params = synth.make_mixed_bursts(n, "cpu", seed=77, chunk=128)
+    params = params.copy()
+    params["type"][3::5] = O.IDLE                              # plenty of IDLE slots: the noise ring wraps (20 entries)
+    params["type"][11::64] = O.OFF
+    iq = iq.numpy().copy()
+    iq[8::96] = np.clip(iq[8::96].astype(np.int32) * 40, -32768, 32767).astype(np.int16)     # clipped slots -> rx_clipping
+    (tmp_path / "iq.s16").write_bytes(iq.tobytes())
+    (tmp_path / "p.bin").write_bytes(params.tobytes())
+    rec_dt = np.dtype([("code", "<i4"), ("nbits", "<u4"), ("fn", "<u4"), ("tn", "<u4"), ("idle", "<u4"), ("modulation", "<u4"),
+                       ("tss", "<u4"), ("tsc", "<u4"), ("ci", "<f4"), ("rssi", "<f8"), ("toa", "<f8"), ("noise", "<f8"),
+                       ("rx", "<f4", 444), ("rx_clipping", "<u4"), ("rx_no_burst_detected", "<u4")])
+    want = O.pull_radio_vector_chain(iq, params, chans, muted=muted, rssi_offset=-3.5)
+    n_clip = max(w[2] for w in want)
+    assert n_clip > 0 and sum(1 for w in want if w[0] == -2) == (params["type"] == O.OFF).sum()
+    for exe in exes():
+        for exact in (1, 0):
+            out = tmp_path / "rv.bin"
+            subprocess.run([exe, "pullrv", str(tmp_path / "iq.s16"), str(tmp_path / "p.bin"), str(n), str(chans), str(muted),
+                            str(exact), str(out)], check=True)
+            g = np.fromfile(out, dtype=rec_dt)
+            assert len(g) == n
+            n_det = 0
+            for i, (code, bi, clipc, nodet) in enumerate(want):
+                r = g[i]
+                assert r["code"] == code, i
+                assert r["fn"] == bi.fn == i // chans and r["tn"] == bi.tn == (i & 7), i
+                assert r["tss"] == 0
+                if code != 0:
+                    assert r["nbits"] == 0 and r["rssi"] == 0.0 and r["noise"] == 0.0 and r["idle"] == 0   # OFF: bi initialised only
+                    continue
+                assert r["idle"] == bi.idle and r["nbits"] == bi.nbits and r["modulation"] == bi.modulation, i
+                assert r["rx_clipping"] == clipc and r["rx_no_burst_detected"] == nodet, i
+                if i % chans == muted:
+                    assert r["idle"] == 1 and r["rssi"] == 0.0 and r["noise"] == 0.0
+                    continue
+                # energyDetect is a tree sum on the GPU (3e-6 relative): 20 log10 of its square root moves by < 2e-5 dB
+                assert abs(r["rssi"] - bi.rssi) < 2e-5, (i, r["rssi"], bi.rssi)
+                if np.isinf(bi.noise):
+                    assert np.isinf(r["noise"]) and r["noise"] > 0                                     # no IDLE slot yet: mNoiseLev = 0
+                else:
+                    assert abs(r["noise"] - bi.noise) < 2e-5, (i, r["noise"], bi.noise)
+                if not bi.idle:
+                    n_det += 1
+                    assert r["toa"] == bi.toa and r["tsc"] == bi.tsc, i
+                    assert abs(r["ci"] - bi.ci) <= 2e-5
+                    ref_row = np.frombuffer(bi.rx_burst, dtype=np.float32)[:148]
+                    if exact:
+                        assert np.array_equal(r["rx"][:148], ref_row), i
+                    else:
+                        assert np.abs(r["rx"][:148] - ref_row).max() <= 1e-5, i
+                else:
+                    assert r["toa"] == 0.0 and r["tsc"] == 0 and r["ci"] == 0.0
+            assert n_det > 0.5 * n
+            assert np.isfinite(g["noise"][(g["code"] == 0) & (np.arange(n) % chans != muted)][-chans:]).all()
+
+
 def test_host_trxd_packer_equals_oracle(trx, tmp_path):
     """trxdPackBurstInd() (the per-indication host packer of the shim) against the oracle's restatement."""
     rng = np.random.default_rng(5)

@@ -49,6 +49,13 @@ def check_layout(kv):
     # no GPU / no setup: the reference's error conventions, objects untouched
     assert kv["detect_without_setup"] == "-4"        # -SIGERR_INTERNAL
     assert kv["demod_without_setup"] == "null"
+    # struct trx_ul_burst_ind (proto_trxd.h:24-37), the output type of pullRadioVector(): 444 floats, then nbits / fn / tn,
+    # three doubles (rssi, toa, noise), bool idle, enum Modulation, tss, tsc, float ci -- same on both sides of the library
+    for k, want in (("sizeof_trx_ul_burst_ind", 1832), ("offsetof_bi_rx_burst", 0), ("offsetof_bi_nbits", 1776), ("offsetof_bi_fn", 1780),
+                    ("offsetof_bi_tn", 1784), ("offsetof_bi_rssi", 1792), ("offsetof_bi_toa", 1800), ("offsetof_bi_noise", 1808),
+                    ("offsetof_bi_idle", 1816), ("offsetof_bi_modulation", 1820), ("offsetof_bi_tss", 1824), ("offsetof_bi_tsc", 1825),
+                    ("offsetof_bi_ci", 1828), ("sizeof_enum_Modulation", 4)):
+        assert kv[k] == f"{want} {want}", (k, kv[k])
 
 
 def test_standalone_build_layout():
@@ -145,3 +152,48 @@ def test_reference_vector_test_against_standalone_header(tmp_path):
                            "-o", exe, src])
     out = subprocess.run([exe], stdout=subprocess.PIPE, text=True, check=True).stdout
     assert out == open(os.path.join(ROOT, "tests", "golden", "VectorTest.ok")).read()
+
+
+def struct_fields(text, name):
+    """[(type, member)] of `struct name { ... }` in a C header: declarations in order, comments stripped."""
+    import re
+    body = re.search(r"struct\s+" + name + r"\s*\{(.*?)\};", text, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    body = re.sub(r"//[^\n]*", "", body)
+    out = []
+    for decl in body.split(";"):
+        decl = " ".join(decl.split())
+        if decl:
+            t, m = decl.rsplit(" ", 1)
+            out.append((t, m))
+    return out
+
+
+def test_trx_ul_burst_ind_declaration_matches_the_reference_header():
+    """The adapter's fallback declaration of struct trx_ul_burst_ind / enum Modulation (host/trxPullRadioVector.h, used where
+    libosmocore's <osmocom/core/endian.h> -- which the reference's proto_trxd.h includes -- is not installed) against the
+    reference header where it lies: same members, same types, same order, same enumerators."""
+    hdr = os.path.join(REF, "Transceiver52M", "proto_trxd.h")
+    if not os.path.exists(hdr):
+        pytest.skip("needs /root/reference (container only)")
+    import re
+    ref = open(hdr).read()
+    mine = open(os.path.join(ROOT, "osmo_trx_amd", "host", "trxPullRadioVector.h")).read()
+    assert struct_fields(mine, "trx_ul_burst_ind") == struct_fields(ref, "trx_ul_burst_ind")
+    assert len(struct_fields(ref, "trx_ul_burst_ind")) == 12
+
+    def enumerators(text):
+        body = re.search(r"enum\s+Modulation\s*\{(.*?)\};", text, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        return [e.strip() for e in body.split(",") if e.strip()]
+    assert enumerators(mine) == enumerators(ref) == ["MODULATION_GMSK", "MODULATION_8PSK"]
+    assert re.search(r"#define\s+MAX_RX_BURST_BUF_SIZE\s+444", ref) and re.search(r"#define\s+MAX_RX_BURST_BUF_SIZE\s+444", mine)
+
+
+def test_pull_radio_vector_adapter_is_exported_with_the_reference_type():
+    """libtrxsigproc.so exports trxPullRadioVector(BurstGatherer&, RxChanState&, unsigned long, trx_ul_burst_ind*) with the
+    GLOBAL struct trx_ul_burst_ind (what a reference-compiled Transceiver.o passes)."""
+    if not os.path.exists(SHIM):
+        pytest.skip("libtrxsigproc.so not built")
+    defined = set(nm(SHIM, "-D", "--defined-only"))
+    assert "trxPullRadioVector(BurstGatherer&, RxChanState&, unsigned long, trx_ul_burst_ind*)" in defined
