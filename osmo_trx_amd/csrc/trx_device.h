@@ -100,6 +100,24 @@ static __device__ unsigned long long g_trx_diag[TRX_DIAG_WAVES * 24];   // per w
 #define DIAG_FLUSH()
 #endif
 
+// Measurement build only (-DTRX_WHATIF_PAIR, tools/build_variants.py): an UPPER BOUND on what packing two bursts into one
+// wave for correlation / arg-max / the two gates / computeCI could buy.  Every other normal burst of a
+// wave skips exactly those phases and reuses the previous burst's peak index -- as if the neighbour's pass had produced both
+// results at no extra cost -- while decimation, both bisection rounds and the demodulator (phases whose lanes are full, or
+// whose 34 + 34 samples do not fit 64 lanes) run as always.  Results are wrong by construction: timing and counters only.
+#ifdef TRX_WHATIF_PAIR
+struct WhatIf { int bidx; int skip; };
+#define WI_ARG , WhatIf &wi
+#define WI_PASS , wi
+#define WI_LOCAL WhatIf wi = { 0, 0 }
+#define WI_SKIP (wi.skip != 0)
+#else
+#define WI_ARG
+#define WI_PASS
+#define WI_LOCAL
+#define WI_SKIP false
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // wave-level helpers
 // ------------------------------------------------------------------------------------------------
@@ -642,9 +660,9 @@ struct NoToaHook { __device__ __forceinline__ void operator()(int) const {} };
 template <typename Hook>
 __device__ __forceinline__ int detect_tail_h(const c32 *sig, int sig_len, c32 *cz, const float *hdr, int N, float thresh,
 					      int start, int len, int bidx, const float *sincv, const PeakConst &pc, int lane,
-					      float *toa_out, c32 *amp_out, float *ci_out, Hook on_toa, const float4 *wa4, int slice DIAG_ARG)
+					      float *toa_out, c32 *amp_out, float *ci_out, Hook on_toa, const float4 *wa4, int slice DIAG_ARG WI_ARG)
 {
-	if ((bidx < 3) || (bidx > len - 3))               // :1683
+	if (!WI_SKIP && ((bidx < 3) || (bidx > len - 3)))   // :1683
 		return 0;
 	wave_sync();
 	const c32 amp0 = cz[bidx];
@@ -653,7 +671,7 @@ __device__ __forceinline__ int detect_tail_h(const c32 *sig, int sig_len, c32 *c
 	DIAG_MARK(4);
 	// ---- computePeakRatio (:1541-1571): terms in the reference's order; out-of-range terms read the
 	// zero pads (adding +0 is exact), their count is arithmetic
-	{
+	if (!WI_SKIP) {
 		// lane k (mod 8) squares the k-th term of the reference's loop (peak-2, peak+2, peak-3, ... peak+5; out-of-range
 		// ones read the zero pads), a serial DPP scan adds them left to right: lane 7 holds the reference's avg
 		float acc = norm2(cz[bidx + pc.ratio_off]);
@@ -713,7 +731,7 @@ __device__ __forceinline__ int detect_tail_h(const c32 *sig, int sig_len, c32 *c
 		// roundf(toa): toa is k/512 -> round half away from zero on integers
 		const int rt = (toa512 >= 0) ? ((toa512 + 256) >> 9) : -((-toa512 + 256) >> 9);
 		const int ps = start + 1 - N + rt;
-		if (ps >= 0 && ps + N <= sig_len && !ABL(7)) {
+		if (ps >= 0 && ps + N <= sig_len && !ABL(7) && !WI_SKIP) {
 			// S = sum_i |sig[ps+i]|^2 in index order: lane i squares one sample, the sum walks the lanes
 			const float pw = norm2(sig[ps + (lane < N ? lane : 0)]);
 			// serial scan along the lanes: after step s lane k holds pw[k-s] + ... + pw[k] added left to right, so
@@ -754,8 +772,9 @@ __device__ __forceinline__ int detect_tail(const c32 *sig, int sig_len, c32 *cz,
 					    int start, int len, int bidx, const float *sincv, const PeakConst &pc, int lane,
 					    float *toa_out, c32 *amp_out, float *ci_out, int slice DIAG_ARG)
 {
+	WI_LOCAL;
 	return detect_tail_h(sig, sig_len, cz, hdr, N, thresh, start, len, bidx, sincv, pc, lane, toa_out, amp_out, ci_out,
-			     NoToaHook(), nullptr, slice DIAG_PASS);
+			     NoToaHook(), nullptr, slice DIAG_PASS WI_PASS);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -772,8 +791,13 @@ __device__ __forceinline__ int detect_tail(const c32 *sig, int sig_len, c32 *cz,
 template <bool PADDED, bool NARROW, typename Hook>
 __device__ __forceinline__ int detect_burst_h(const c32 *sig, int sig_len, c32 *cz, const c32 *taps, const float *hdr,
 					       int N, float thresh, int start, int len, const float *sincv, const PeakConst &pc, int lane,
-					       float *toa_out, c32 *amp_out, float *ci_out, Hook on_toa, const float4 *wa4, int slice, int unit_slot DIAG_ARG)
+					       float *toa_out, c32 *amp_out, float *ci_out, Hook on_toa, const float4 *wa4, int slice, int unit_slot DIAG_ARG WI_ARG)
 {
+#ifdef TRX_WHATIF_PAIR
+	if (wi.skip)                                     // the neighbour's pass "already" correlated and gated this burst
+		return detect_tail_h(sig, sig_len, cz, hdr, N, thresh, start, len, wi.bidx, sincv, pc, lane, toa_out, amp_out, ci_out,
+				     on_toa, wa4, slice DIAG_PASS WI_PASS);
+#endif
 	const bool wide = NARROW && (len > TRX_CORR_NARROW || start + len > TRX_DEC_NARROW);
 	// corr[i] with range-checked reads, taps in order (cold: wide windows only)
 	auto corr_at = [&](int i) {
@@ -896,8 +920,11 @@ __device__ __forceinline__ int detect_burst_h(const c32 *sig, int sig_len, c32 *
 		}
 		czp = win - (bidx - TRX_CZ_PAD);
 	}
+#ifdef TRX_WHATIF_PAIR
+	wi.bidx = (bidx < 3) ? 3 : (bidx > len - 3 ? len - 3 : bidx);
+#endif
 	const int r = detect_tail_h(sig, sig_len, czp, hdr, N, thresh, start, len, bidx, sincv, pc, lane, toa_out, amp_out, ci_out,
-				    on_toa, wa4, slice DIAG_PASS);
+				    on_toa, wa4, slice DIAG_PASS WI_PASS);
 	if (wide) {
 		wave_sync();
 		if (lane < TRX_CZ_PAD)
@@ -911,8 +938,9 @@ __device__ __forceinline__ int detect_burst(const c32 *sig, int sig_len, c32 *cz
 					     int N, float thresh, int start, int len, const float *sincv, const PeakConst &pc, int lane,
 					     float *toa_out, c32 *amp_out, float *ci_out, int slice, int unit_slot DIAG_ARG)
 {
+	WI_LOCAL;
 	return detect_burst_h<PADDED, NARROW>(sig, sig_len, cz, taps, hdr, N, thresh, start, len, sincv, pc, lane, toa_out, amp_out,
-					      ci_out, NoToaHook(), nullptr, slice, unit_slot DIAG_PASS);
+					      ci_out, NoToaHook(), nullptr, slice, unit_slot DIAG_PASS WI_PASS);
 }
 
 

@@ -398,6 +398,10 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 	};
 
 	DIAG_DECL;
+#ifdef TRX_WHATIF_PAIR
+	WhatIf wi = { 8, 1 };                                          /* (the first normal burst of a wave runs in full) */
+	WhatIf wi_full = { 0, 0 };
+#endif
 	unsigned j_next = 0, b_next = K4_NO_BURST;
 	for (unsigned b = b_first; b != K4_NO_BURST; b = b_next) {
 		// Re-materialise the lane id per burst (2 VALU ops): otherwise every lane-derived address, tree-node
@@ -594,8 +598,11 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 					// all multiples of 1/512) and, in the usual geometry, the fetch of its low-edge tap rows (fast_fetch)
 					const float *const hdr = lhdr + 8 * tsc;
 					auto on_toa = [&](int toa512) { fast_fetch(toa512 - (int)(hdr[5] * 512.0f) - 10 * 512); };
+#ifdef TRX_WHATIF_PAIR
+					wi.skip ^= 1;
+#endif
 					const int hit = detect_burst_h<true, true>(dec, 156, cz, lseq + LSEQ_TSC(tsc), hdr, 16, thresh, 71, len, sincv,
-										   pkc, lane, &toa, &amp, &ci, on_toa, wa4, slice, unit_bad ? -1 : tsc DIAG_PASS);
+										   pkc, lane, &toa, &amp, &ci, on_toa, wa4, slice, unit_bad ? -1 : tsc DIAG_PASS WI_PASS);
 					wave_sync();
 					rc = hit ? TRXHIP_TSC : (clip ? -TRXHIP_SIGERR_CLIP : 0);                 // :1764, :1953-1954
 					toa -= 10.0f;                                                              // :1768
@@ -618,14 +625,22 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 					wave_sync();
 					DIAG_MARK(2);
 					int hit = detect_burst_h<true, true>(dec, 156, cz, lseq + LSEQ_RACH(0), lhdr + 8 * 8, 40, thresh, 39, len, sincv,
-									     pkc, lane, &toa, &amp, &ci, NoToaHook(), wa4, slice, unit_bad ? -1 : 8 DIAG_PASS);
+									     pkc, lane, &toa, &amp, &ci, NoToaHook(), wa4, slice, unit_bad ? -1 : 8 DIAG_PASS
+#ifdef TRX_WHATIF_PAIR
+									     , wi_full
+#endif
+									     );
 					wave_sync();
 					out_tsc = 0;                                                               // ebp->tsc = i (:1797)
 					if (!hit && type == TRXHIP_EXT_RACH) {
 						// extended access bursts: TS1, then TS2 over the same window, first hit wins (:1791-1800)
 						for (int c = 1; c < 3 && !hit; c++) {
 							hit = detect_burst_h<true, true>(dec, 156, cz, lseq + LSEQ_RACH(c), lhdr + 8 * (8 + c), 40, thresh, 39, len,
-											 sincv, pkc, lane, &toa, &amp, &ci, NoToaHook(), wa4, slice, unit_bad ? -1 : 8 + c DIAG_PASS);
+											 sincv, pkc, lane, &toa, &amp, &ci, NoToaHook(), wa4, slice, unit_bad ? -1 : 8 + c DIAG_PASS
+#ifdef TRX_WHATIF_PAIR
+											 , wi_full
+#endif
+											 );
 							wave_sync();
 							out_tsc = c;
 						}

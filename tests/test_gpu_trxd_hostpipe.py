@@ -277,7 +277,10 @@ def test_pull_radio_vector_adapter_against_the_oracle_chain(trx, tmp_path):
     params["type"][3::5] = O.IDLE                              # plenty of IDLE slots: the noise ring wraps (20 entries)
     params["type"][11::64] = O.OFF
     iq = iq.numpy().copy()
-    iq[8::96] = np.clip(iq[8::96].astype(np.int32) * 40, -32768, 32767).astype(np.int16)     # clipped slots -> rx_clipping
+    rng = np.random.default_rng(3)
+    k = len(iq[8::96])
+    iq[8::96] = rng.integers(-32768, 32767, (k, 625, 2), dtype=np.int16)      # saturated noise: nothing found, clipped -> rx_clipping
+    params["type"][8::96] = O.TSC
     (tmp_path / "iq.s16").write_bytes(iq.tobytes())
     (tmp_path / "p.bin").write_bytes(params.tobytes())
     rec_dt = np.dtype([("code", "<i4"), ("nbits", "<u4"), ("fn", "<u4"), ("tn", "<u4"), ("idle", "<u4"), ("modulation", "<u4"),
@@ -326,6 +329,65 @@ def test_pull_radio_vector_adapter_against_the_oracle_chain(trx, tmp_path):
                     assert r["toa"] == 0.0 and r["tsc"] == 0 and r["ci"] == 0.0
             assert n_det > 0.5 * n
             assert np.isfinite(g["noise"][(g["code"] == 0) & (np.arange(n) % chans != muted)][-chans:]).all()
+
+
+def wire_byte_mismatch(trx, iq, params, oracle_soft=None):
+    """TRXD v1 datagrams packed from the FUSED demodulator's soft bits against the same packed from the reference's soft bits
+    (EXACT mode on the GPU, which the parity tests pin bit for bit to the oracle -- or the oracle's own soft bits when given).
+    Returns (differing soft bytes, soft bytes compared, differing header bytes, max |byte difference|, max relative error of a
+    raw soft value over |soft| >= 0.05 and over |soft| >= 0.25)."""
+    from osmo_trx_amd import trxhip
+    n = len(params)
+    d_iq = iq.to("cuda:0")
+    d_p = trx.params_tensor(params)
+    meta = np.zeros(n, dtype=trxhip.TRXD_META_DTYPE)
+    meta["fn"] = np.arange(n) // 8
+    meta["tn"] = np.arange(n) & 7
+    meta["version"] = 1
+    d_meta = torch.from_numpy(meta.view(np.uint8).reshape(-1, 8).copy()).to("cuda:0")
+    res_e, soft_e = trx.detect_demod(d_iq, d_p, sps=4, soft_stride=148, slice_bits=True, exact=True)
+    if oracle_soft is not None:
+        soft_e = torch.from_numpy(oracle_soft).to("cuda:0")
+    pkt_e, len_e = trx.pack_trxd_wire(res_e, d_p, soft_e, d_meta, pkt_stride=160)
+    res_f, soft_f = trx.detect_demod(d_iq, d_p, sps=4, soft_stride=148, slice_bits=True, exact=False)
+    pkt_f, len_f = trx.pack_trxd_wire(res_f, d_p, soft_f, d_meta, pkt_stride=160)
+    torch.cuda.synchronize()
+    assert torch.equal(res_e, res_f) and torch.equal(len_e, len_f)          # detection and every header field: identical
+    det = (len_e.view(torch.int16) == 11 + 148)
+    a, b = pkt_e[det][:, 11:159].to(torch.int16), pkt_f[det][:, 11:159].to(torch.int16)
+    diff = (a - b).abs()
+    hdr = int((pkt_e[:, :11] != pkt_f[:, :11]).sum())
+    # relative error of the raw (-1..+1) soft value 2 s - 1 where it is not small
+    raw_e, raw_f = 2.0 * soft_e[det] - 1.0, 2.0 * soft_f[det] - 1.0
+    rel = []
+    for floor in (0.05, 0.25):
+        big = raw_e.abs() >= floor
+        rel.append(float(((raw_f - raw_e).abs() / raw_e.abs())[big].max()) if bool(big.any()) else 0.0)
+    return int((diff != 0).sum()), int(diff.numel()), hdr, int(diff.max()), tuple(rel)
+
+
+def test_fused_demodulator_wire_bytes(trx):
+    """How often a TRXD soft BYTE of the default (fused) demodulator differs from the reference's:
+    1M normal bursts (BASELINE configs[1]) and 256k access bursts, v1 datagrams.  A soft byte is round(255 s): it can move by
+    one count where 255 s lies within 255 * 1e-5 of a rounding boundary.  Bars: <= 1e-3 of the soft bytes, never more than one
+    count, no header byte; north star's "<= 1e-4 relative" on every soft value of a quarter of full scale or more (the error is
+    absolute, <= 1e-5 of full scale: relative to a value of 0.05 it may reach 2e-4).  The first 16384 bursts are also compared with
+    the oracle's own soft bits instead of the GPU's exact mode."""
+    from osmo_trx_amd import synth
+    out = {}
+    for name, (iq, params, _) in (("normal", synth.make_normal_bursts(1 << 20, "cuda:0", 4, seed=0xB17E)),
+                                  ("access", synth.make_access_bursts(1 << 18, "cuda:0", seed=0xB17F))):
+        nd, nt, hdr, mx, rel = wire_byte_mismatch(trx, iq, params)
+        out[name] = (nd, nt, rel)
+        assert nt > 0.9 * 148 * len(params) * 0.9
+        assert hdr == 0 and mx <= 1, (name, hdr, mx)
+        assert nd / nt <= 1e-3, (name, nd, nt)
+        assert rel[1] <= 1e-4 and rel[0] <= 5e-4, (name, rel)
+        m = 16384
+        o_res, o_soft = O.pull_batch(iq[:m].cpu().numpy(), 4, params[:m])
+        nd2, nt2, hdr2, mx2, _ = wire_byte_mismatch(trx, iq[:m], params[:m], oracle_soft=o_soft)
+        assert hdr2 == 0 and mx2 <= 1 and nd2 / nt2 <= 1e-3, (name, nd2, nt2)
+    print("fused-vs-reference TRXD soft bytes:", {k: f"{v[0]} of {v[1]} ({v[0] / v[1]:.2e}), max rel {v[2][0]:.1e} (|soft| >= 0.05) / {v[2][1]:.1e} (>= 0.25)" for k, v in out.items()})
 
 
 def test_host_trxd_packer_equals_oracle(trx, tmp_path):

@@ -31,6 +31,14 @@ for name, (iq, params) in (("normal, max_toa 3", synth.make_normal_bursts(n_nb, 
     print(f"{name:22s} {len(params):8d} bursts, {int((o_res['rc'] > 0).sum()):8d} detected: bit-exact (exact) / fused max {worst:.2e}, "
           f"{n_over} of {err.size} values above {FUSED_SOFT_ATOL:g} (noise slots detected at C/I < -12 dB)  [{time.time() - t0:.0f} s]", flush=True)
 
+# TRXD wire bytes of the default (fused) demodulator against the reference's (tests/test_gpu_trxd_hostpipe.py)
+from test_gpu_trxd_hostpipe import wire_byte_mismatch
+for name, (iq, params, _) in (("normal, 1M", synth.make_normal_bursts(1 << 20, "cuda:0", 4, seed=0xB17E)),
+                              ("access, 256k", synth.make_access_bursts(1 << 18, "cuda:0", seed=0xB17F))):
+    nd, nt, hdr, mx, rel = wire_byte_mismatch(trx, iq, params)
+    print(f"TRXD v1, fused vs exact demodulator, {name:13s}: {nd} of {nt} soft bytes differ ({nd / nt:.2e}), by at most {mx} count; "
+          f"{hdr} header bytes differ; max relative error of a soft value with |soft| >= 0.05: {rel[0]:.2e}, >= 0.25: {rel[1]:.2e}", flush=True)
+
 # EDGE 8-PSK (444 soft bits) and the generic kernel (1 SPS, 156/157-sample bursts)
 iq, params, _ = synth.make_edge_bursts(1 << 16, "cpu", seed=0xCA15)
 o_res, o_soft = O.pull_batch(iq.numpy(), 4, params, soft_stride=444, slice_bits=False)
