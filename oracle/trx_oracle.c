@@ -92,14 +92,63 @@ void orc_convert_float_short(short *out, const float *in, float scale, int len)
 }
 
 /*
+ * Optional arch seam (tests and bench.py's second CPU baseline only).  orc_set_arch() routes every FIR of the call graph --
+ * table generation included -- through externally supplied kernels with the reference's signatures
+ * (arch/common/convolve.h:6-14: convolve_real / convolve_complex): tests plug the reference's OWN objects, compiled
+ * unmodified into oracle/_ref/libref_generic.so / libref_sse.so (oracle/Makefile), in here.  With the generic build every
+ * result must equal the restated loops below bit for bit (tests/test_oracle.py): that pins the loops, the zero padding and
+ * the call arguments of every site against the reference's kernels inside the full detect / demod call graph.  With the SSE
+ * build the oracle becomes the reference's SSE path (north star: "match the reference CPU/SSE path").
+ * NULL, NULL restores the restated loops.  Tables are rebuilt by the next call (they are convolution outputs themselves).
+ */
+static orc_conv_fn A_real, A_cmplx;
+
+void orc_set_arch(orc_conv_fn conv_real, orc_conv_fn conv_complex)
+{
+	A_real = conv_real;
+	A_cmplx = conv_complex;
+	T_ready = 0;
+}
+
+/* what the reference's convolve() does in front of the kernel call (sigProcLib.cpp:309-358): a copy of x with `head` zero
+ * samples in front and `tail` behind when the span reaches outside the vector, taps in a 16-byte aligned buffer
+ * (convolve_h_alloc); the kernel is then called with start moved by `head`.  `aligned` = h->isAligned() of that call site:
+ * false selects base_convolve_* in the reference (:374-383), i.e. the generic loops, whatever kernels are plugged. */
+static int conv_arch(const orc_cf *x, int n, const float *h2, int H, int h_real, orc_cf *y, int start, int len)
+{
+	int head = (start < H - 1) ? (H - 1 - start) : 0;
+	int tail = (start + len > n) ? (start + len - n) : 0;
+	size_t tot = (size_t)head + (size_t)n + (size_t)tail;
+	float *xp = NULL, *hp = NULL, *yp = NULL;
+	int rc = -1;
+	if (posix_memalign((void **)&xp, 16, (tot + 4) * 2 * sizeof(float)) ||
+	    posix_memalign((void **)&hp, 16, ((size_t)H + 4) * 2 * sizeof(float)) ||
+	    posix_memalign((void **)&yp, 16, ((size_t)len + 4) * 2 * sizeof(float)))
+		goto out;
+	memset(xp, 0, (tot + 4) * 2 * sizeof(float));
+	memcpy(xp + 2 * (size_t)head, x, (size_t)n * sizeof(orc_cf));
+	memcpy(hp, h2, (size_t)H * 2 * sizeof(float));
+	rc = (h_real ? A_real : A_cmplx)(xp, (int)tot, hp, H, yp, len, start + head, len);
+	memcpy(y, yp, (size_t)len * sizeof(orc_cf));
+out:
+	free(xp); free(hp); free(yp);
+	return rc;
+}
+
+/*
  * sigProcLib.cpp:297-398 convolve() reduced to what every span type computes:
  *   y[i] = sum_k X(i + start - (H-1) + k) * h[k],  X = x inside [0,n) and 0 outside
  * (START_ONLY reads zeroed head-room, NO_DELAY/CUSTOM zero-pad a copy :352-353).
  * h_real: taps are real (mac_real), else complex (mac_cmplx).  Sequential k order.
+ * aligned: h->isAligned() at this call site (only matters when arch kernels are plugged, see above).
  */
 static void conv_span(const orc_cf *x, int n, const orc_cf *h, int H, int h_real,
-		      orc_cf *y, int start, int len)
+		      orc_cf *y, int start, int len, int aligned)
 {
+	if (aligned && (h_real ? A_real : A_cmplx) && len > 0) {
+		conv_arch(x, n, (const float *)h, H, h_real, y, start, len);
+		return;
+	}
 	for (int i = 0; i < len; i++) {
 		float yr = 0.0f, yi = 0.0f;
 		for (int k = 0; k < H; k++) {
@@ -118,8 +167,14 @@ static void conv_span(const orc_cf *x, int n, const orc_cf *h, int H, int h_real
 }
 
 static void conv_span_rtaps(const orc_cf *x, int n, const float *h, int H,
-			    orc_cf *y, int start, int len)
+			    orc_cf *y, int start, int len, int aligned)
 {
+	if (aligned && A_real && len > 0 && H <= 64) {
+		float h2[2 * 64];
+		for (int k = 0; k < H; k++) { h2[2 * k] = h[k]; h2[2 * k + 1] = 0.0f; }   /* real taps live in complex storage */
+		conv_arch(x, n, h2, H, 1, y, start, len);
+		return;
+	}
 	for (int i = 0; i < len; i++) {
 		float yr = 0.0f, yi = 0.0f;
 		for (int k = 0; k < H; k++) {
@@ -258,7 +313,7 @@ static int rotate_burst(const uint8_t *bits, int nbits, int guard, int sps, orc_
 		rot[i * sps] = cf((float)(2.0 * (bits[i] & 0x01) - 1.0), 0.0f);
 	gmsk_rotate(rot, burst_len, sps, 0);         /* `rotated` is not flagged real */
 	orc_cf one = cf(1.0f, 0.0f);
-	conv_span(rot, burst_len, &one, 1, 1, out, 0, burst_len);  /* START_ONLY, h = empty pulse */
+	conv_span(rot, burst_len, &one, 1, 1, out, 0, burst_len, 0);  /* START_ONLY, h = empty pulse (not aligned) */
 	free(rot);
 	return burst_len;
 }
@@ -273,7 +328,7 @@ static int modulate_burst_basic(const uint8_t *bits, int nbits, int guard, int s
 	for (int i = 0; i < nbits; i++)
 		b[i * sps] = cf((float)(2.0 * (bits[i] & 0x01) - 1.0), 0.0f);
 	gmsk_rotate(b, burst_len, sps, 1);
-	conv_span_rtaps(b, burst_len, pulse, plen, out, 0, burst_len);   /* START_ONLY */
+	conv_span_rtaps(b, burst_len, pulse, plen, out, 0, burst_len, 1);   /* START_ONLY; c0 is aligned (:497) */
 	free(b);
 	return burst_len;
 }
@@ -309,8 +364,8 @@ static int modulate_burst_laurent(const uint8_t *bits, int nbits, orc_cf *out)
 	phase = (float)(2.0 * ((bits[nbits - 1] & 0x01) ^ (bits[nbits - 2] & 0x01)) - 1.0);  /* :654-656 */
 	c1[q] = cmul(c0[q], cf(0.0f, phase));
 
-	conv_span_rtaps(c0, burst_len, T.pulse4_c0, 16, out, 0, burst_len);   /* :659 */
-	conv_span_rtaps(c1, burst_len, T.pulse4_c1, 8, c1s, 0, burst_len);    /* :660 */
+	conv_span_rtaps(c0, burst_len, T.pulse4_c0, 16, out, 0, burst_len, 1);   /* :659 */
+	conv_span_rtaps(c1, burst_len, T.pulse4_c1, 8, c1s, 0, burst_len, 1);    /* :660; c1 aligned (:443) */
 	for (int i = 0; i < burst_len; i++) {                                  /* :663-666 */
 		out[i].re += c1s[i].re;
 		out[i].im += c1s[i].im;
@@ -370,7 +425,7 @@ int orc_modulate_edge_burst(const uint8_t *bits, int nbits, orc_cf *out)
 		orc_cf rot = cf(cosf(phase), sinf(phase));
 		b[sps + i * sps] = cmul(sym[i], rot);
 	}
-	conv_span_rtaps(b, nsamps, T.pulse4_c0, 16, out, 0, nsamps);
+	conv_span_rtaps(b, nsamps, T.pulse4_c0, 16, out, 0, nsamps, 1);
 	free(b);
 	return nsamps;
 }
@@ -456,7 +511,7 @@ static void finish_corr_seq(orc_corr_seq *cs, const orc_cf *shaped, int shaped_l
 {
 	orc_cf ac[160];
 	float toa;
-	conv_span(shaped, shaped_len, cs->seq, cs->n, 0, ac, cs->n / 2, shaped_len);
+	conv_span(shaped, shaped_len, cs->seq, cs->n, 0, ac, cs->n / 2, shaped_len, 1);
 	cs->gain = peak_detect(ac, shaped_len, &toa, NULL);
 	cs->toa = (float)(toa - toa_off);
 }
@@ -607,11 +662,16 @@ const float *orc_resampler_partition(const orc_resampler *r, int path)
 /* Resampler.cpp:131-150: out[i] = sum_k in[n - (L-1) + k] * part[path][k], n=(q*i)/p, path=(q*i)%p */
 int orc_resampler_rotate(const orc_resampler *r, const orc_cf *in, int in_len, orc_cf *out, int out_len)
 {
-	(void)in_len;
 	for (int i = 0; i < out_len; i++) {
 		int n = (r->q * i) / r->p;
 		int path = (r->q * i) % r->p;
 		const float *h = &r->part[(size_t)path * r->filt_len];
+		if (A_real && r->filt_len <= 64) {
+			/* one convolve_real() call per output, len 1, start n (Resampler.cpp:143-147); the vector handed over
+			 * starts filt_len samples early (the caller's history), as the reference's head-room does */
+			conv_span_rtaps(in - r->filt_len, in_len + r->filt_len, h, r->filt_len, &out[i], n + r->filt_len, 1, 1);
+			continue;
+		}
 		float yr = 0.0f, yi = 0.0f;
 		for (int k = 0; k < r->filt_len; k++) {
 			const orc_cf xv = in[n - (r->filt_len - 1) + k];
@@ -688,6 +748,15 @@ void orc_vector_slicer(float *dest, const float *src, size_t len)
  * in = 16 zeros + burst[0..in_len); out[i] = sum_k in[4i - 15 + k] * g[k] */
 static void downsample_burst(const orc_cf *burst, int in_len, orc_cf *out, int out_len)
 {
+	if (A_real) {
+		/* signalVector in(in_len, dnsampler->len()): 16 zero samples of head-room, then Resampler::rotate() (:1590-1598) */
+		orc_cf *buf = calloc((size_t)in_len + 16, sizeof(orc_cf));
+		memcpy(buf + 16, burst, (size_t)in_len * sizeof(orc_cf));
+		for (int i = 0; i < out_len; i++)
+			conv_span_rtaps(buf, in_len + 16, T.dec_taps, 16, &out[i], 4 * i + 16, 1, 1);
+		free(buf);
+		return;
+	}
 	for (int i = 0; i < out_len; i++) {
 		float yr = 0.0f, yi = 0.0f;
 		for (int k = 0; k < 16; k++) {
@@ -755,7 +824,7 @@ static int detect_burst_1sps(const orc_cf *corr_in, int corr_in_len, orc_cf *cor
 	orc_cf xcorr;
 
 	/* Correlate :1674 (CUSTOM span) */
-	conv_span(corr_in, corr_in_len, sync->seq, sync->n, 0, corr, start, len);
+	conv_span(corr_in, corr_in_len, sync->seq, sync->n, 0, corr, start, len, 1);
 
 	ebp->amp = fast_peak_detect(corr, len, &ebp->toa);
 
@@ -981,7 +1050,7 @@ void orc_delay_vector(const orc_cf *in, int n, float delay, orc_cf *out)
 	if ((double)fabsf(frac) > 1e-2) {
 		int index = (int)floorf(frac * (float)ORC_DELAYFILTS);
 		/* convolve(in, h, NULL, NO_DELAY): start = h_len/2 = 10 */
-		conv_span_rtaps(in, n, T.delay_filt[index], ORC_DELAY_HLEN, shift, ORC_DELAY_HLEN / 2, n);
+		conv_span_rtaps(in, n, T.delay_filt[index], ORC_DELAY_HLEN, shift, ORC_DELAY_HLEN / 2, n, 1);   /* aligned (:1021) */
 	} else {
 		memcpy(shift, in, (size_t)n * sizeof(orc_cf));
 	}
@@ -1064,7 +1133,7 @@ static int demod_edge_burst(const orc_cf *burst, int n, int sps, orc_ebp *ebp, f
 	if (olen < 0) { free(dec); return -1; }
 
 	/* eq = convolve(dec, c0_inv, NULL, NO_DELAY): 5 real taps, start = 2 */
-	conv_span_rtaps(dec, olen, T.c0_inv, 5, eq, 2, olen);
+	conv_span_rtaps(dec, olen, T.c0_inv, 5, eq, 2, olen, 0);   /* c0_inv->setAligned(false) (:412): base_convolve_real */
 	for (int i = 0; i < olen; i++) {
 		float phase = (float)((double)((float)(i % 16) * 3.0f) * M_PI / 8.0f);
 		orc_cf r = cf(cosf(phase), -sinf(phase));

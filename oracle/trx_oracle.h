@@ -78,6 +78,11 @@ typedef struct {
 int orc_setup(void);
 const orc_tables *orc_get_tables(void);
 
+/* ---- optional arch seam: every FIR of the call graph through the caller's kernels (the reference's own objects in
+ * oracle/_ref/libref_generic.so / libref_sse.so); NULL, NULL = the restated generic-C loops.  Tests and bench.py only. ---- */
+typedef int (*orc_conv_fn)(const float *x, int x_len, const float *h, int h_len, float *y, int y_len, int start, int len);
+void orc_set_arch(orc_conv_fn conv_real, orc_conv_fn conv_complex);
+
 /* ---- arch kernels (generic C), arch/common/convolve_base.c, convert_base.c ---- */
 int  orc_convolve_real(const float *x, int x_len, const float *h, int h_len,
 		       float *y, int y_len, int start, int len);

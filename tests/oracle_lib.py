@@ -129,6 +129,33 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+REF_DIR = os.path.join(ORACLE_DIR, "_ref")
+_ref_libs = {}
+
+
+def ref_arch_available(kind):
+    return os.path.exists(os.path.join(REF_DIR, f"libref_{kind}.so"))
+
+
+def use_ref_arch(kind):
+    """Route every FIR of the oracle's call graph -- table generation included -- through the reference's OWN arch kernels,
+    compiled unmodified into oracle/_ref/libref_<kind>.so (kind = "generic" | "sse"; oracle/Makefile), or back through the
+    restated loops (kind = None).  See orc_set_arch() in oracle/trx_oracle.c."""
+    L = lib()
+    L.orc_set_arch.argtypes = [C.c_void_p, C.c_void_p]
+    if kind is None:
+        L.orc_set_arch(None, None)
+    else:
+        if kind not in _ref_libs:
+            R = C.CDLL(os.path.join(REF_DIR, f"libref_{kind}.so"))
+            R.convolve_init()                                     # arch/x86/convolve.c:66-90: SSE3 function table when built with it
+            R.convert_init()
+            _ref_libs[kind] = R
+        R = _ref_libs[kind]
+        L.orc_set_arch(C.cast(R.convolve_real, C.c_void_p), C.cast(R.convolve_complex, C.c_void_p))
+    L.orc_setup()
+
+
 def tables():
     """Oracle tables as a dict of numpy arrays (complex tables as complex64)."""
     t = lib().orc_get_tables().contents

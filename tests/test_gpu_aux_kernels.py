@@ -132,6 +132,36 @@ def test_resampler_65_48_and_decimator(trx, golden_dir):
     assert np.array_equal(got[0].view(np.float32), v["dec4_generic"])
 
 
+def test_standalone_entry_points_against_reference_stage_vectors(trx, golden_dir):
+    """The HIP stand-alone entry points of the three FIR stages of detectAnyBurst / demodAnyBurst -- trxhip_resample_batch (1, 4)
+    = downsampleBurst, trxhip_convolve_complex_batch = detectBurst's correlation at N = 16 / 40 / 64, and
+    trxhip_delay_vector_batch_cf32 = delayVector's 20-tap filter -- against tests/golden/ref_stage_vectors.npz: the outputs of
+    the reference's unmodified arch objects for the captured burst and 64 seeded bursts (tests/golden/make_stage_vectors.py).
+    Bit for bit."""
+    v = np.load(os.path.join(golden_dir, "ref_stage_vectors.npz"))
+    cap = np.fromfile(os.path.join(golden_dir, "nb_chunk_tsc7.cfile"), dtype=np.complex64)[:625]
+    xs = np.stack([cap] + [b.astype(np.float32).view(np.complex64).reshape(625) for b in v["iq"]])
+    T = O.tables()
+    # decimator: the C-ABI stream starts from zero history, exactly downsampleBurst's 16 zeros of head-room
+    dec = trx.resample(dev(np.ascontiguousarray(xs[:, :624])), 1, 4)
+    assert np.array_equal(dec.cpu().numpy().view(np.float32).reshape(65, -1), v["dec"])
+    dec_ref = dev(np.ascontiguousarray(v["dec"].view(np.complex64)))
+    nb = np.flatnonzero(v["kind"] == 0)
+    ab = np.flatnonzero(v["kind"] == 1)
+    for i, k in enumerate(nb):                                     # one launch per training sequence
+        h = dev(np.ascontiguousarray(T["midamble"][int(v["tsc"][k])]["seq"]))
+        c = trx.convolve(dec_ref[k:k + 1], h, 71, 19, True)
+        assert np.array_equal(c.cpu().numpy().view(np.float32)[0], v["corr_nb"][i]), k
+    c = trx.convolve(dec_ref[torch.from_numpy(ab).to("cuda:0")].contiguous(), dev(np.ascontiguousarray(T["rach"][0]["seq"])), 39, 79, True)
+    assert np.array_equal(c.cpu().numpy().view(np.float32).reshape(32, -1), v["corr_ab"])
+    c = trx.convolve(dec_ref, dev(np.ascontiguousarray(T["sch"]["seq"])), 63, 93, True)
+    assert np.array_equal(c.cpu().numpy().view(np.float32).reshape(65, -1), v["corr_sch"])
+    delays = ((v["filt"].astype(np.float32) + np.float32(0.5)) / np.float32(64.0)).astype(np.float32)
+    d = trx.delay_vector(dev(xs), dev(delays)).cpu().numpy()
+    got = np.concatenate([d[:, a:b] for a, b in v["delay_win"]], axis=1)
+    assert np.array_equal(got.view(np.float32).reshape(65, -1), v["delay"])
+
+
 def test_demod_only_matches_fused(trx):
     from osmo_trx_amd import synth
     iq, params, _ = synth.make_normal_bursts(512, "cpu", 4, seed=77)

@@ -87,6 +87,40 @@ def test_normal_bursts_4sps_all_tsc(trx):
     check_parity(f_res, f_soft, o_res, o_soft, soft_atol=FUSED_SOFT_ATOL)
 
 
+@pytest.mark.skipif(not O.ref_arch_available("sse"), reason="oracle/_ref/libref_sse.so not built (it travels prebuilt from the build container)")
+def test_against_the_references_sse_path(trx):
+    """North star, literally: "outputs (detected TOA, RSSI, soft bits) must match the reference CPU/SSE path to <= 1e-4
+    relative".  The oracle's call graph over the reference's own SSE3 kernels (arch/x86/convolve_sse_3.c compiled unmodified
+    into oracle/_ref/libref_sse.so, orc_set_arch) IS that path.  Both demodulators against it, normal and access bursts:
+    rc, TSC and TOA identical; RSSI within 2e-5 dB; amplitude within 2e-6 relative; soft bits within 2e-5 of full scale (the
+    SSE path itself sits up to 3e-6 from the generic-C path, the fused demodulator up to 1e-5: both inside 1e-4)."""
+    from osmo_trx_amd import synth
+    loads = [synth.make_normal_bursts(4096, "cpu", 4, seed=901)[:2], synth.make_access_bursts(2048, "cpu", seed=902)[:2],
+             synth.make_normal_bursts(1024, "cpu", 4, seed=903, max_toa=40, delay_sym=(-2.0, 38.0))[:2]]
+    try:
+        O.use_ref_arch("sse")
+        refs = [O.pull_batch(iq.numpy(), 4, p) for iq, p in loads]
+    finally:
+        O.use_ref_arch(None)
+    for (iq, p), (o_res, o_soft) in zip(loads, refs):
+        for exact in (True, False):
+            g_res, g_soft = run_gpu(trx, iq, p, 4, exact=exact)
+            for f in ("rc", "tsc", "idle", "nbits_div4"):
+                assert np.array_equal(g_res[f], o_res[f]), f
+            assert np.array_equal(g_res["toa"], o_res["toa"])
+            det = o_res["rc"] > 0
+            assert det.sum() > 0.85 * len(p)
+            amp = np.hypot(o_res["amp_re"], o_res["amp_im"])[det]
+            d_amp = np.hypot(g_res["amp_re"] - o_res["amp_re"], g_res["amp_im"] - o_res["amp_im"])[det]
+            assert (d_amp / amp).max() < 2e-6
+            fin = np.isfinite(o_res["rssi"])
+            assert np.abs(g_res["rssi"][fin] - o_res["rssi"][fin]).max() < 2e-5
+            # soft bits: absolute on full scale 1, amplitude-aware on noise slots as in check_parity
+            ratio = np.where(det, np.sqrt(np.maximum(o_res["energy"], 0)) / np.maximum(np.hypot(o_res["amp_re"], o_res["amp_im"]), 1e-30), 1.0)
+            bar = (2e-5 * np.maximum(1.0, ratio / 4.0))[:, None]
+            assert (np.abs(g_soft - o_soft) <= bar).all()
+
+
 def test_normal_bursts_wide_window_raw_soft(trx):
     from osmo_trx_amd import synth
     iq, params, _ = synth.make_normal_bursts(1024, "cpu", 4, seed=11, max_toa=63, delay_sym=(-2.0, 40.0))

@@ -302,3 +302,125 @@ def test_va_access_burst_and_quirks():
                 errs += int(((soft[:88] > 0).astype(np.uint8) != bits).sum())
     assert errs <= 8, errs
     assert O.demod_any_burst_va(y, O.TSC, 9, 3)[0] == -1          # tsc > 7
+
+
+# ---- the oracle's call graph over the reference's own compiled arch kernels (oracle/_ref, orc_set_arch) ----
+def _workloads():
+    from osmo_trx_amd import synth
+    w = []
+    iq, p, _ = synth.make_normal_bursts(192, "cpu", 4, seed=501)
+    w.append(("normal, max_toa 3", iq.numpy(), p, 4))
+    iq, p, _ = synth.make_normal_bursts(96, "cpu", 4, seed=502, max_toa=40, delay_sym=(-2.0, 38.0))
+    w.append(("normal, max_toa 40", iq.numpy(), p, 4))
+    iq, p, _ = synth.make_access_bursts(96, "cpu", seed=503)
+    w.append(("access", iq.numpy(), p, 4))
+    iq, p, _ = synth.make_access_bursts(64, "cpu", seed=504, ext=True)
+    w.append(("extended access", iq.numpy(), p, 4))
+    iq, p, _ = synth.make_edge_bursts(64, "cpu", seed=505)
+    w.append(("EDGE", iq.numpy(), p, 4))
+    iq, p, _ = synth.make_normal_bursts(64, "cpu", 1, seed=506, burst_len=156)
+    w.append(("1 SPS", iq.numpy(), p, 1))
+    return w
+
+
+def _tables_bytes():
+    t = O.lib().orc_get_tables().contents
+    return bytes(t)
+
+
+@pytest.mark.skipif(not O.ref_arch_available("generic"), reason="oracle/_ref not built (no /root/reference at build time)")
+def test_call_graph_over_the_references_generic_kernels_is_bit_identical():
+    """Every FIR of the detect / demod call graph and of the table generator executed by the reference's OWN convolve_real /
+    convolve_complex (arch/common/convolve_base.c through arch/x86/convolve.c, compiled unmodified: oracle/_ref/
+    libref_generic.so) instead of the oracle's restated loops: tables byte-identical, every result record and every soft bit
+    identical, for normal / access / extended access / EDGE / 1-SPS bursts and the captured burst.  This pins the restated
+    kernels, the zero padding of convolve() (sigProcLib.cpp:309-358) and the arguments of every call site against the
+    reference's objects inside the full call graph -- not only stage by stage."""
+    loads = _workloads()
+    cap = np.fromfile(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "nb_chunk_tsc7.cfile"), dtype=np.complex64)
+    try:
+        O.use_ref_arch(None)
+        base_t = _tables_bytes()
+        base = [O.pull_batch(iq, sps, p, soft_stride=444 if name == "EDGE" else 156, slice_bits=False) for name, iq, p, sps in loads]
+        rc0, e0 = O.detect_any_burst(cap, 7, 4.0, 4, O.TSC, 40)
+        s0 = O.demod_any_burst(cap, rc0, 4, e0)
+        O.use_ref_arch("generic")
+        assert _tables_bytes() == base_t
+        for (name, iq, p, sps), (r0, sf0) in zip(loads, base):
+            r1, sf1 = O.pull_batch(iq, sps, p, soft_stride=444 if name == "EDGE" else 156, slice_bits=False)
+            assert r1.tobytes() == r0.tobytes(), name
+            assert np.array_equal(sf1.view(np.uint32), sf0.view(np.uint32)), name
+            assert (r0["rc"] > 0).sum() > 0.7 * len(p), name
+        rc1, e1 = O.detect_any_burst(cap, 7, 4.0, 4, O.TSC, 40)
+        assert rc1 == rc0 == O.TSC and bytes(e1) == bytes(e0)
+        assert np.array_equal(O.demod_any_burst(cap, rc1, 4, e1), s0)
+    finally:
+        O.use_ref_arch(None)
+
+
+@pytest.mark.skipif(not O.ref_arch_available("sse"), reason="oracle/_ref not built (no /root/reference at build time)")
+def test_the_references_sse_path_stays_within_the_north_star_bar():
+    """The same with the reference's SSE3 kernels (arch/x86/convolve_sse_3.c, compiled unmodified: libref_sse.so): the oracle
+    then IS the reference's SSE path.  Against the generic-C path: rc identical, TOA identical, amp and soft bits within the
+    SSE kernels' own summation-order spread -- far inside north star's 1e-4 relative."""
+    loads = _workloads()
+    try:
+        O.use_ref_arch(None)
+        base = [O.pull_batch(iq, sps, p, soft_stride=444 if name == "EDGE" else 156, slice_bits=False) for name, iq, p, sps in loads]
+        O.use_ref_arch("sse")
+        worst = {}
+        for (name, iq, p, sps), (r0, sf0) in zip(loads, base):
+            r1, sf1 = O.pull_batch(iq, sps, p, soft_stride=444 if name == "EDGE" else 156, slice_bits=False)
+            assert np.array_equal(r1["rc"], r0["rc"]) and np.array_equal(r1["tsc"], r0["tsc"]), name
+            assert np.array_equal(r1["toa"], r0["toa"]), name
+            det = r0["rc"] > 0
+            amp0 = np.hypot(r0["amp_re"], r0["amp_im"])[det]
+            d_amp = np.hypot(r1["amp_re"] - r0["amp_re"], r1["amp_im"] - r0["amp_im"])[det] / amp0
+            assert d_amp.max() < 2e-6, (name, d_amp.max())
+            assert np.abs(r1["ci"] - r0["ci"])[det].max() < 1e-3, name
+            tol = 5e-5 if name == "EDGE" else 1e-5
+            assert np.abs(sf1 - sf0).max() < tol, (name, np.abs(sf1 - sf0).max())
+            worst[name] = (float(d_amp.max()), float(np.abs(sf1 - sf0).max()))
+        assert max(v[1] for v in worst.values()) > 0          # it really is a different summation order
+    finally:
+        O.use_ref_arch(None)
+
+
+def _stage_inputs(v):
+    cap = np.fromfile(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "nb_chunk_tsc7.cfile"), dtype=np.complex64)[:625]
+    return [cap] + [b.astype(np.float32).view(np.complex64).reshape(625) for b in v["iq"]]
+
+
+def test_stage_vectors_of_the_reference_kernels(golden_dir):
+    """tests/golden/ref_stage_vectors.npz (tests/golden/make_stage_vectors.py): decimator, correlation at N = 16 / 40 / 64 and the
+    20-tap fractional delay of the captured burst and 64 seeded bursts, computed by the reference's unmodified arch objects with
+    the arguments of the reference's call sites.  The oracle's own stage functions reproduce every value bit for bit."""
+    v = np.load(os.path.join(golden_dir, "ref_stage_vectors.npz"))
+    L = O.lib()
+    T = O.tables()
+    xs = _stage_inputs(v)
+    assert len(xs) == 65
+    r = L.orc_resampler_new(1, 4, 16, 1.0)
+    i_nb = i_ab = 0
+    for k, x in enumerate(xs):
+        buf = np.concatenate([np.zeros(16, np.complex64), x[:624]])
+        dec = np.zeros(156, dtype=np.complex64)
+        assert L.orc_resampler_rotate(r, buf[16:].ctypes.data, 624, dec.ctypes.data, 156) == 156
+        assert np.array_equal(dec.view(np.float32), v["dec"][k]), k
+        if v["kind"][k] == 0:
+            c = O.convolve(dec, T["midamble"][int(v["tsc"][k])]["seq"], 71, 19, True)
+            assert np.array_equal(c.view(np.float32), v["corr_nb"][i_nb]), k
+            i_nb += 1
+        else:
+            c = O.convolve(dec, T["rach"][0]["seq"], 39, 79, True)
+            assert np.array_equal(c.view(np.float32), v["corr_ab"][i_ab]), k
+            i_ab += 1
+        c = O.convolve(dec, T["sch"]["seq"], 63, 93, True)
+        assert np.array_equal(c.view(np.float32), v["corr_sch"][k]), k
+        # delayVector with a purely fractional delay that selects filter `filt`: floorf(frac * 64) = filt, no integer shift
+        out = np.zeros(625, dtype=np.complex64)
+        L.orc_delay_vector(np.ascontiguousarray(x).ctypes.data, 625, float(np.float32((int(v["filt"][k]) + 0.5) / 64.0)), out.ctypes.data)
+        got = np.concatenate([out[a:b] for a, b in v["delay_win"]])
+        assert np.array_equal(got.view(np.float32), v["delay"][k]), k
+    L.orc_resampler_free(r)
+    assert i_nb == 33 and i_ab == 32
