@@ -41,11 +41,26 @@ def usable_cores():
     return n
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(iq_host, params, target_seconds=6.0):
     """Time the CPU oracle (oracle/trx_oracle.c, a port of the reference's generic-C path, gcc -O2) on a
     bounded sample of the same workload: one thread per usable host core, each thread looping over its own
     contiguous slice of the sample (bursts are independent, so a static split is the fair CPU ceiling;
-    ctypes releases the GIL).  A one-pass calibration sizes the repeat count to ~target_seconds."""
+    ctypes releases the GIL).  A one-pass calibration sizes the repeat count to ~target_seconds.
+
+    Second entry (`sse_path`), when oracle/_ref/libref_sse.so travelled with the snapshot: the same call graph with every
+    FIR executed by the reference's OWN SSE3 kernels (arch/x86/convolve_sse_3.c compiled unmodified; orc_set_arch) and the
+    reference's per-call padded copies -- the reference's x86 path as closely as this image can build it (sigProcLib.cpp
+    itself needs libosmocore headers the image lacks)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     from concurrent.futures import ThreadPoolExecutor
@@ -53,34 +68,52 @@ def cpu_baseline(iq_host, params, target_seconds=6.0):
     O.lib()
     n_sample = len(iq_host)
     per = max(256, n_sample // cores)
-    n1 = min(n_sample, 8192)
-    t0 = time.perf_counter()
-    O.pull_batch(iq_host[:n1], 4, params[:n1])
-    t1 = time.perf_counter() - t0
     slices = [(min(i * per, n_sample - per), min(i * per, n_sample - per) + per) for i in range(cores)]
 
-    def run(reps):
-        def work(b):
-            for _ in range(reps):
-                O.pull_batch(iq_host[b[0]:b[1]], 4, params[b[0]:b[1]])
+    def timed(seconds):
+        n1 = min(n_sample, 8192)
         t0 = time.perf_counter()
-        with ThreadPoolExecutor(cores) as ex:
-            list(ex.map(work, slices))
-        return time.perf_counter() - t0
+        O.pull_batch(iq_host[:n1], 4, params[:n1])
+        t1 = time.perf_counter() - t0
 
-    tcal = run(1)                                                    # calibration pass, all threads
-    reps = max(1, min(200, int(target_seconds / max(tcal, 1e-3))))
-    tn = run(reps)
-    done = per * reps * cores
-    return {
+        def run(reps):
+            def work(b):
+                for _ in range(reps):
+                    O.pull_batch(iq_host[b[0]:b[1]], 4, params[b[0]:b[1]])
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(cores) as ex:
+                list(ex.map(work, slices))
+            return time.perf_counter() - t0
+
+        tcal = run(1)                                                # calibration pass, all threads
+        reps = max(1, min(200, int(seconds / max(tcal, 1e-3))))
+        tn = run(reps)
+        return per * reps * cores, tn, reps, n1 / t1
+
+    done, tn, reps, single = timed(target_seconds)
+    out = {
         "value": round(done / tn / 1e6, 6), "unit": "Mbursts/s", "cores": cores, "kind": "port",
         "sample": f"first {n_sample} bursts of the same batch split over {cores} threads ({per} bursts each, "
                   f"repeated {reps}x: {done} bursts in {tn:.1f} s); oracle/trx_oracle.c, generic-C order, gcc -O2",
-        "single_thread_kbursts_s": round(n1 / t1 / 1e3, 2),
+        "single_thread_kbursts_s": round(single / 1e3, 2),
+        "cpu_model": cpu_model(),
         "host": {"affinity_cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
                  "cgroup_cpu_max": (open("/sys/fs/cgroup/cpu.max").read().strip()
                                     if os.path.exists("/sys/fs/cgroup/cpu.max") else None)},
     }
+    if O.ref_arch_available("sse"):
+        try:
+            O.use_ref_arch("sse")
+            done2, tn2, reps2, single2 = timed(target_seconds * 0.6)
+            out["sse_path"] = {
+                "value": round(done2 / tn2 / 1e6, 6), "unit": "Mbursts/s", "cores": cores, "kind": "port",
+                "kernels": "the reference's own arch/x86 SSE3 convolve kernels, compiled unmodified (oracle/_ref/libref_sse.so), at "
+                           "every convolve() call site incl. the reference's per-call padded copy and aligned taps",
+                "sample": f"same sample and split, repeated {reps2}x: {done2} bursts in {tn2:.1f} s",
+                "single_thread_kbursts_s": round(single2 / 1e3, 2)}
+        finally:
+            O.use_ref_arch(None)
+    return out
 
 
 def side_legs(args, trx, synth, shard, step, iq, n, dev, rank, world, results, soft):

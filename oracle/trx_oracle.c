@@ -660,18 +660,38 @@ const float *orc_resampler_partition(const orc_resampler *r, int path)
 }
 
 /* Resampler.cpp:131-150: out[i] = sum_k in[n - (L-1) + k] * part[path][k], n=(q*i)/p, path=(q*i)%p */
+/* Resampler::rotate over plugged arch kernels: one convolve_real() call per output, len 1, start n, straight on the caller's
+ * buffer as the reference does (Resampler.cpp:143-147; partitions are memalign'ed there: aligned taps here) */
+static int resampler_rotate_arch(const orc_resampler *r, const orc_cf *in, int in_len, orc_cf *out, int out_len)
+{
+	float *hp = NULL;
+	const int L = r->filt_len;
+	if (posix_memalign((void **)&hp, 16, (size_t)r->p * ((size_t)L + 4) * 2 * sizeof(float)))
+		return -1;
+	for (int path = 0; path < r->p; path++)
+		for (int k = 0; k < L; k++) {
+			hp[((size_t)path * (L + 4) + k) * 2] = r->part[(size_t)path * L + k];
+			hp[((size_t)path * (L + 4) + k) * 2 + 1] = 0.0f;
+		}
+	for (int i = 0; i < out_len; i++) {
+		int n = (r->q * i) / r->p;
+		int path = (r->q * i) % r->p;
+		orc_cf y = cf(0.0f, 0.0f);
+		A_real((const float *)(in - L), in_len + L, &hp[(size_t)path * (L + 4) * 2], L, (float *)&y, out_len - i, n + L, 1);
+		out[i] = y;
+	}
+	free(hp);
+	return out_len;
+}
+
 int orc_resampler_rotate(const orc_resampler *r, const orc_cf *in, int in_len, orc_cf *out, int out_len)
 {
+	if (A_real && (r->filt_len % 4) == 0)
+		return resampler_rotate_arch(r, in, in_len, out, out_len);
 	for (int i = 0; i < out_len; i++) {
 		int n = (r->q * i) / r->p;
 		int path = (r->q * i) % r->p;
 		const float *h = &r->part[(size_t)path * r->filt_len];
-		if (A_real && r->filt_len <= 64) {
-			/* one convolve_real() call per output, len 1, start n (Resampler.cpp:143-147); the vector handed over
-			 * starts filt_len samples early (the caller's history), as the reference's head-room does */
-			conv_span_rtaps(in - r->filt_len, in_len + r->filt_len, h, r->filt_len, &out[i], n + r->filt_len, 1, 1);
-			continue;
-		}
 		float yr = 0.0f, yi = 0.0f;
 		for (int k = 0; k < r->filt_len; k++) {
 			const orc_cf xv = in[n - (r->filt_len - 1) + k];
@@ -749,11 +769,19 @@ void orc_vector_slicer(float *dest, const float *src, size_t len)
 static void downsample_burst(const orc_cf *burst, int in_len, orc_cf *out, int out_len)
 {
 	if (A_real) {
-		/* signalVector in(in_len, dnsampler->len()): 16 zero samples of head-room, then Resampler::rotate() (:1590-1598) */
-		orc_cf *buf = calloc((size_t)in_len + 16, sizeof(orc_cf));
-		memcpy(buf + 16, burst, (size_t)in_len * sizeof(orc_cf));
-		for (int i = 0; i < out_len; i++)
-			conv_span_rtaps(buf, in_len + 16, T.dec_taps, 16, &out[i], 4 * i + 16, 1, 1);
+		/* signalVector in(in_len, dnsampler->len()): 16 samples of zero head-room, then Resampler::rotate() (:1590-1598):
+		 * one convolve_real() call per output, len 1, on that buffer */
+		float *buf = NULL, h2[2 * 16] __attribute__((aligned(16)));
+		if (posix_memalign((void **)&buf, 16, ((size_t)in_len + 16 + 4) * sizeof(orc_cf)))
+			return;
+		memset(buf, 0, ((size_t)in_len + 16 + 4) * sizeof(orc_cf));
+		memcpy(buf + 32, burst, (size_t)in_len * sizeof(orc_cf));
+		for (int k = 0; k < 16; k++) { h2[2 * k] = T.dec_taps[k]; h2[2 * k + 1] = 0.0f; }
+		for (int i = 0; i < out_len; i++) {
+			orc_cf y = cf(0.0f, 0.0f);
+			A_real(buf, in_len + 16, h2, 16, (float *)&y, out_len - i, 4 * i + 16, 1);
+			out[i] = y;
+		}
 		free(buf);
 		return;
 	}
