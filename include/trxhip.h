@@ -119,6 +119,11 @@ int  trxhip_device_count(void);                       /* number of visible HIP d
 int  trxhip_create(trxhip_ctx **out, int device);
 void trxhip_destroy(trxhip_ctx *ctx);
 const char *trxhip_strerror(int err);
+/* Work distribution of the 4-SPS kernel for large batches: 1 (default) = the last eighth of the 16-burst groups is drawn from
+ * a device-wide counter by whichever CU gets there (evens out the eight dies), 0 = every group dealt statically.  Results
+ * never depend on it (tests/test_gpu_parity.py); a measurement switch.  TRXHIP_NO_POOL in the environment makes 0 the
+ * default of contexts created afterwards. */
+int  trxhip_set_work_pool(trxhip_ctx *ctx, int enabled);
 
 /* ---- table blob: generated once on rank 0, broadcast to the other ranks (RCCL), adopted there ---- */
 size_t trxhip_tables_size(void);                                      /* bytes of the device table blob */

@@ -121,7 +121,8 @@ int trxhip_create_from_tables(trxhip_ctx **out, int device, const void *h_blob, 
 	ctx->d_tables = nullptr;
 	ctx->no_unit = trx_unit_masks_match(t) ? 0 : 1;
 	ctx->d_pool = nullptr;
-	ctx->pool_next = 0;
+	ctx->pool_nstreams = 0;
+	ctx->pool_enabled = getenv("TRXHIP_NO_POOL") ? 0 : 1;          /* measurement switch, read once per context */
 	ctx->no_sym = 0;                                           /* the straight-line decimator reads taps 0..7 and mirrors them */
 	for (int k = 0; k < 8; k++)
 		if (memcmp(&t->dec_taps[k], &t->dec_taps[15 - k], sizeof(float)) != 0)
@@ -166,6 +167,14 @@ void trxhip_destroy(trxhip_ctx *ctx)
 	delete ctx;
 }
 
+int trxhip_set_work_pool(trxhip_ctx *ctx, int enabled)
+{
+	if (!ctx)
+		return TRXHIP_EINVAL;
+	ctx->pool_enabled = enabled ? 1 : 0;
+	return TRXHIP_OK;
+}
+
 int trxhip_tables_device_ptr(trxhip_ctx *ctx, void **d_blob)
 {
 	if (!ctx || !d_blob)
@@ -203,11 +212,22 @@ static int pull_common(trxhip_ctx *ctx, const void *d_iq, int cf32, const trxhip
 		flags |= TRXHIP_IFLAG_NO_SYM;
 	/* a zeroed pool counter for this launch (the kernel ignores it for small batches) */
 	unsigned *pool = nullptr;
-	if (ctx->d_pool && n_bursts >= (size_t)ctx->n_cu * 128) {
-		const unsigned slot = __atomic_fetch_add(&ctx->pool_next, 1u, __ATOMIC_RELAXED) % TRX_POOL_SLOTS;
-		pool = ctx->d_pool + slot * 16;
-		if (hipMemsetAsync(pool, 0, sizeof(unsigned), static_cast<hipStream_t>(stream)) != hipSuccess)
-			return TRXHIP_EIO;
+	if (ctx->d_pool && ctx->pool_enabled && n_bursts >= (size_t)ctx->n_cu * 128) {
+		int slot = -1;
+		{
+			std::lock_guard<std::mutex> g(ctx->pool_mu);           /* the stream's own counter (see trx_ctx.h) */
+			for (int k = 0; k < ctx->pool_nstreams; k++)
+				if (ctx->pool_stream[k] == stream) { slot = k; break; }
+			if (slot < 0 && ctx->pool_nstreams < TRX_POOL_SLOTS) {
+				slot = ctx->pool_nstreams++;
+				ctx->pool_stream[slot] = stream;
+			}
+		}
+		if (slot >= 0) {
+			pool = ctx->d_pool + slot * 16;
+			if (hipMemsetAsync(pool, 0, sizeof(unsigned), static_cast<hipStream_t>(stream)) != hipSuccess)
+				return TRXHIP_EIO;
+		}
 	}
 	return trx_launch_pull(pool, d_iq, cf32, d_params, d_results, d_soft, ctx->d_tables, d_ebp_in, n_bursts, burst_len, sps,
 			       threshold, full_scale, soft_stride, flags, ctx->n_cu, static_cast<hipStream_t>(stream));
@@ -223,6 +243,13 @@ int trxhip_select_diversity_batch(trxhip_ctx *ctx, const int16_t *d_iq_paths, si
 {
 	if (!ctx || n_paths < 1 || n_paths > 8 || (sps != 1 && sps != 4) || burst_len < 1 || burst_len > TRXHIP_MAX_BURST_LEN)
 		return TRXHIP_EINVAL;
+	/* energyDetect(path, 20 * sps) reads samples 0, 4, 8, ... of the path (sigProcLib.cpp:1576-1584, window clamped to the
+	 * vector's size): the last one, 4 * (window - 1), must lie inside the path -- 317 samples at 4 SPS, 77 at 1 SPS */
+	{
+		const int window = 20 * sps < burst_len ? 20 * sps : burst_len;
+		if (4 * (window - 1) >= burst_len)
+			return TRXHIP_EINVAL;
+	}
 	if (n_bursts == 0)
 		return TRXHIP_OK;
 	if (!d_iq_paths || !d_iq_sel || !d_avg_energy || (reinterpret_cast<uintptr_t>(d_iq_paths) & 3) ||

@@ -2,6 +2,7 @@
 #ifndef TRX_CTX_H
 #define TRX_CTX_H
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include "../../include/trxhip.h"
 #include "trx_tables.h"
 
@@ -11,10 +12,17 @@ struct trxhip_ctx {
 	trx_tables *d_tables;
 	int no_unit;        /* tables do not have the compiled-in unit structure: keep the multiplying correlation */
 	int no_sym;         /* decimator taps not bitwise symmetric: the kernels' straight-line paths (mirrored taps) are off */
-	/* cross-die work pool of the 4-SPS kernel (trx_kernel4.hip): one 64-byte counter per launch in flight, handed out
-	 * round-robin so that concurrent launches of one context (several host threads, several streams) never share one */
+	/* cross-die work pool of the 4-SPS kernel (trx_kernel4.hip): one 64-byte counter PER STREAM.  Launches on one stream
+	 * run in order, so the hipMemsetAsync in front of a launch can never zero a counter an earlier launch still draws
+	 * from; launches on different streams never share one (round 3 handed the slots out round-robin per launch: launch i
+	 * and launch i + 64, outstanding at the same time on different streams, shared a counter).  A context that sees more
+	 * than TRX_POOL_SLOTS distinct streams runs the surplus ones without the pool (static split: same results).  A launch
+	 * captured into a HIP graph keeps the slot of the stream it was captured on. */
 	unsigned *d_pool;
-	unsigned pool_next;
+	int pool_enabled;                  /* trxhip_set_work_pool(); default 1, 0 when TRXHIP_NO_POOL is set at creation */
+	void *pool_stream[64];
+	int pool_nstreams;
+	std::mutex pool_mu;
 };
 #define TRX_POOL_SLOTS 64
 

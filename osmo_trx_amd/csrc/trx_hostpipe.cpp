@@ -48,7 +48,12 @@ struct trxhip_hostpipe {
 	} slot[16];
 };
 
-static bool pin(void **p, size_t bytes) { return hipHostMalloc(p, bytes ? bytes : 16, hipHostMallocDefault) == hipSuccess; }
+/* pinned, device-mapped and coherent, stated explicitly: the kernels read small batches in place and the TRXD packer writes
+ * datagrams straight into these buffers -- that must not hang on a runtime default (HIP_HOST_COHERENT) */
+static bool pin(void **p, size_t bytes)
+{
+	return hipHostMalloc(p, bytes ? bytes : 16, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
+}
 static bool dev(void **p, size_t bytes) { return hipMalloc(p, bytes ? bytes : 16) == hipSuccess; }
 
 extern "C" {
@@ -69,6 +74,11 @@ int trxhip_hostpipe_create(trxhip_ctx *ctx, const trxhip_hostpipe_cfg *c, trxhip
 		return TRXHIP_EINVAL;
 	if (c->n_paths < 0 || c->n_paths > 8)
 		return TRXHIP_EINVAL;
+	if (c->n_paths > 1) {                                      /* the diversity energy scan must stay inside a path (trx_capi.cpp) */
+		const int window = 20 * c->sps < c->burst_len ? 20 * c->sps : c->burst_len;
+		if (4 * (window - 1) >= c->burst_len)
+			return TRXHIP_EINVAL;
+	}
 	if (with_device(ctx))
 		return TRXHIP_EIO;
 

@@ -1115,7 +1115,7 @@ extern "C" int trx_launch_pull4(unsigned *d_pool_ctr, const void *d_iq, int cf32
 				   full_scale, soft_stride, flags, pool);                                       \
 	} while (0)
 	/* the cross-die pool needs every workgroup to own >= 7 static groups and the grid to be the persistent one */
-	unsigned *const pool = (d_pool_ctr && grid == (size_t)n_cu && need >= 8 * grid && !getenv("TRXHIP_NO_POOL")) ? d_pool_ctr : nullptr;
+	unsigned *const pool = (d_pool_ctr && grid == (size_t)n_cu && need >= 8 * grid) ? d_pool_ctr : nullptr;   /* (TRXHIP_NO_POOL: trx_capi.cpp) */
 	if (cf32)        { if (exact) LAUNCH4(true, true, false); else LAUNCH4(true, false, false); }
 	else if (common) { if (exact) LAUNCH4(false, true, true); else LAUNCH4(false, false, true); }
 	else             { if (exact) LAUNCH4(false, true, false); else LAUNCH4(false, false, false); }

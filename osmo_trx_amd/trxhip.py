@@ -48,6 +48,7 @@ SYMBOLS = {
     "trxhip_create": (_I, [C.POINTER(_VP), _I]),
     "trxhip_destroy": (None, [_VP]),
     "trxhip_strerror": (C.c_char_p, [_I]),
+    "trxhip_set_work_pool": (_I, [_VP, _I]),
     "trxhip_tables_size": (_SZ, []),
     "trxhip_tables_generate_host": (_I, [_VP, _SZ]),
     "trxhip_create_from_tables": (_I, [C.POINTER(_VP), _I, _VP, _SZ]),
@@ -178,6 +179,10 @@ class TrxHip:
         p = _VP()
         _check(self.L.trxhip_tables_device_ptr(self.h, C.byref(p)), "trxhip_tables_device_ptr")
         return p.value, int(self.L.trxhip_tables_size())
+
+    def set_work_pool(self, enabled):
+        """Cross-die work pool of the 4-SPS kernel on / off (results never depend on it; a measurement switch)."""
+        _check(self.L.trxhip_set_work_pool(self.h, 1 if enabled else 0), "trxhip_set_work_pool")
 
     def params_tensor(self, params_np):
         """PARAMS_DTYPE[n] numpy -> uint8[n, 8] device tensor."""

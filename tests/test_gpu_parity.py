@@ -569,11 +569,8 @@ def test_cross_die_pool_equals_static_split(trx):
     d_p = trx.params_tensor(params)
     for n in (32768 - 1, 32768, 65536 + 15, 131072 + 1, n_max):
         outs = []
-        for no_pool in ("1", None):
-            if no_pool:
-                os.environ["TRXHIP_NO_POOL"] = no_pool
-            else:
-                os.environ.pop("TRXHIP_NO_POOL", None)
+        for no_pool in (True, False):
+            trx.set_work_pool(not no_pool)
             res = torch.full((n, 32), 0xA5, dtype=torch.uint8, device="cuda:0")
             soft = torch.full((n, 148), float("nan"), dtype=torch.float32, device="cuda:0")
             for exact in (False, True):
@@ -603,3 +600,15 @@ def test_cross_die_pool_equals_static_split(trx):
     torch.cuda.synchronize()
     for r, so in outs:
         assert torch.equal(r, ref_res) and torch.equal(so.view(torch.int32), ref_soft.view(torch.int32))
+    # more streams than the context has counters (64: one per stream), two launches on each, all outstanding together: the
+    # surplus streams run the static split, nobody shares a counter (round 3 handed counters out per launch, modulo 64)
+    streams = [torch.cuda.Stream() for _ in range(70)]
+    n = 32768 + 16
+    outs = []
+    for rep in range(2):
+        for s in streams:
+            with torch.cuda.stream(s):
+                outs.append(trx.detect_demod(iq[:n], d_p[:n], sps=4, stream=s))
+    torch.cuda.synchronize()
+    for r, so in outs:
+        assert torch.equal(r, ref_res[:n]) and torch.equal(so.view(torch.int32), ref_soft[:n].view(torch.int32))
