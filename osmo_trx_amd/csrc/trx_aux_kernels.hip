@@ -8,8 +8,6 @@
 // taps in LDS, sums in the reference's generic-C order (compiled with -ffp-contract=off).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
-#include <string.h>
 
 #include "trx_tables.h"
 #include "../../include/trxhip.h"
@@ -766,234 +764,14 @@ frontend_fused_kernel(const uint4 *__restrict__ in4, size_t n_total, c32 *__rest
 	}
 }
 
-// ------------------------------------------------------------------------------------------------
-// Round 4: the same one-pass front end with a tile per WAVE instead of per workgroup.  frontend_fused_kernel above is one
-// latency chain per workgroup and tile -- stage, barrier, channelize, barrier, write, barrier, resample -- and a CU holds four of
-// them: vector ALU 44 % busy, waves waiting 65 % of their time (profiles/r03_ab_runs.txt).  Here a wave owns its tile alone:
-// 16 independent chains per CU, no workgroup barrier anywhere in the loop (a wave's LDS operations execute in order, so a
-// compiler-level fence is all the hand-off between its phases needs), 8.5 KB of LDS per wave.
-//   tile = tm resampler periods = q*tm channel-rate steps with q*tm + 15 <= 256 (65/48: tm 5, 240 steps, 325 outputs per
-//   channel): lane l stages wideband steps l, l+64, ... of [T0 - 30, T0 + q*tm) (register prefetch one tile ahead), computes
-//   the channel-rate times 4l .. 4l+3 of [T0 - 15, T0 + q*tm) for all four channels (one pass: 64 lanes x 4 = 256 times),
-//   writes them over the staging area, then owns the outputs l, l + p, l + 2p, ... of the tile in every channel -- all of them
-//   on filter path (q*l) mod p, so its 16 taps stay in registers -- and the p - 64 residues per period that no lane owns are
-//   swept in one more round with taps from LDS.  Same sums in the same order as channelize_kernel + resample_kernel:
-//   bit-identical to them and to frontend_fused_kernel (tests/test_gpu_aux_kernels.py).
-// ------------------------------------------------------------------------------------------------
-#define FW_WPB 4                        // waves per workgroup (each with its own tile run); 4 workgroups per CU
-#define FW_PHA 68                       // entries per phase array: 270 staged steps / 4, = 4 (mod 16): conflict-free loader writes
-#define FW_CS 272                       // entries per channel in the aliased array (>= q*tm + 15); 4 * FW_CS = 16 * FW_PHA
-#define FW_SLICE (CH_M * 4 * FW_PHA)
-#define FW_NLD 5                        // staged steps per lane: 5 * 64 >= q*tm + 30
-
-__device__ __forceinline__ void fw_wave_sync()
-{
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-	__builtin_amdgcn_wave_barrier();
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-__global__ void __launch_bounds__(FW_WPB * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
-frontend_wave_kernel(const uint4 *__restrict__ in4, size_t n_total, c32 *__restrict__ out, size_t n_out, size_t out_stride,
-		     int p, int q, int tm, size_t n_tiles, const float *__restrict__ parts,
-		     const trx_tables *__restrict__ tab, const uint4 *__restrict__ wide_hist,
-		     const c32 *__restrict__ chan_hist_in, c32 *__restrict__ chan_hist_out)
-{
-	__shared__ __attribute__((aligned(16))) c32 xs_all[FW_WPB][FW_SLICE];
-	__shared__ __attribute__((aligned(16))) float taps[CH_M][CH_H];
-	extern __shared__ __attribute__((aligned(16))) char fe_smem[];        // resampler taps [16][p + 1] (residue sweep)
-	float *rtaps = reinterpret_cast<float *>(fe_smem);
-	static_assert(CH_M * FW_CS == 4 * CH_M * FW_PHA, "the channel samples alias the wideband staging exactly");
-	const int lane = threadIdx.x & 63;
-	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-	const int pst = p + 1;
-	if (threadIdx.x < CH_M * CH_H)
-		taps[threadIdx.x / CH_H][threadIdx.x % CH_H] = tab->chan_taps[threadIdx.x / CH_H][threadIdx.x % CH_H];
-	for (int i = threadIdx.x; i < p * 16; i += FW_WPB * 64)
-		rtaps[(i % 16) * pst + (i / 16)] = parts[i];
-	__syncthreads();                                                       // the only workgroup barrier of the kernel
-	c32 (*const xs)[4][FW_PHA] = reinterpret_cast<c32 (*)[4][FW_PHA]>(&xs_all[wave][0]);
-	c32 *const cs = &xs_all[wave][0];
-	const int tile_in = q * tm, tile_out = p * tm;
-	const int n_stage = tile_in + 30, n_cs = tile_in + 15;
-	const bool owner = lane < p;
-	const unsigned ql = (unsigned)q * (unsigned)lane;
-	const int n_l = (int)(ql / (unsigned)p), path_l = (int)(ql % (unsigned)p);
-	const size_t n_waves = (size_t)gridDim.x * FW_WPB, gw = (size_t)blockIdx.x * FW_WPB + wave;
-	const size_t per_w = (n_tiles + n_waves - 1) / n_waves;
-	const size_t tile_lo = gw * per_w;
-	const size_t tile_hi = (tile_lo + per_w < n_tiles) ? tile_lo + per_w : n_tiles;
-	uint4 pre[FW_NLD];
-	auto prefetch = [&](size_t tile) {
-		const long long t0 = (long long)tile * tile_in - 30;               // first staged wideband step
-#pragma unroll
-		for (int i = 0; i < FW_NLD; i++) {
-			const int j = i * 64 + lane;
-			const long long ts = t0 + j;
-			uint4 v = make_uint4(0u, 0u, 0u, 0u);
-			if (j < n_stage) {
-				if (ts >= 0) { if ((size_t)ts < n_total) v = in4[ts]; }
-				else if (ts >= -(CH_H - 1) && wide_hist) v = wide_hist[(CH_H - 1) + ts];   // carried history: steps -15 .. -1
-			}
-			pre[i] = v;
-		}
-	};
-	if (tile_lo < tile_hi)
-		prefetch(tile_lo);
-	for (size_t tile = tile_lo; tile < tile_hi; tile++) {
-		fw_wave_sync();                                                     // (the previous tile's channel samples are done with)
-#pragma unroll
-		for (int i = 0; i < FW_NLD; i++) {
-			const int j = i * 64 + lane;
-			if (j < n_stage) {
-				const uint32_t w[4] = { pre[i].x, pre[i].y, pre[i].z, pre[i].w };
-#pragma unroll
-				for (int n = 0; n < CH_M; n++)                                 // path M-1-n <- wideband sample n of the time step
-					xs[CH_M - 1 - n][j & 3][j >> 2] = make_float2((float)(int16_t)(w[n] & 0xffffu), (float)(int16_t)(w[n] >> 16));
-			}
-		}
-		fw_wave_sync();
-
-		// ---- channelizer: channel-rate times u = 4 lane .. 4 lane + 3 of the tile (time T0 - 15 + u); tap k of output u is staged step u + k
-		c32 o[CH_M][CH_J];
-		const bool active = CH_J * lane < n_cs;
-		if (active) {
-			c32 yp[CH_J][CH_M];
-#pragma unroll
-			for (int pp = 0; pp < CH_M; pp++) {
-				ch_v2f x[CH_J + CH_H - 1];
-#pragma unroll
-				for (int v = 0; v < CH_J + CH_H - 1; v++)
-					x[v] = ch_lds(&xs[pp][v & 3][lane + (v >> 2)]);
-				const float2 *g2 = reinterpret_cast<const float2 *>(&taps[pp][0]);
-				ch_v2f acc[CH_J];
-#pragma unroll
-				for (int j = 0; j < CH_J; j++)
-					acc[j] = (ch_v2f){ 0.0f, 0.0f };
-#pragma unroll
-				for (int k = 0; k < CH_H; k++) {
-					const float2 gq = g2[k >> 1];
-					const ch_v2f gp = (ch_v2f){ gq.x, gq.y };
-#pragma unroll
-					for (int j = 0; j < CH_J; j++)
-						acc[j] = acc[j] + ((k & 1) ? ch_mul_tap<1>(x[j + k], gp) : ch_mul_tap<0>(x[j + k], gp));
-					if (k & 1)
-						__builtin_amdgcn_sched_barrier(0);
-				}
-#pragma unroll
-				for (int j = 0; j < CH_J; j++) {
-					asm volatile("" : "+v"(acc[j]));
-					yp[j][pp] = make_float2(acc[j].x, acc[j].y);
-				}
-				__builtin_amdgcn_sched_barrier(0);
-			}
-#pragma unroll
-			for (int j = 0; j < CH_J; j++) {                                   // forward 4-point DFT (exact +-1 / +-j twiddles)
-				const c32 t1 = make_float2(yp[j][0].x + yp[j][2].x, yp[j][0].y + yp[j][2].y);
-				const c32 t2 = make_float2(yp[j][0].x - yp[j][2].x, yp[j][0].y - yp[j][2].y);
-				const c32 t3 = make_float2(yp[j][1].x + yp[j][3].x, yp[j][1].y + yp[j][3].y);
-				const c32 t4 = make_float2(yp[j][1].x - yp[j][3].x, yp[j][1].y - yp[j][3].y);
-				o[0][j] = make_float2(t1.x + t3.x, t1.y + t3.y);
-				o[1][j] = make_float2(t2.x + t4.y, t2.y - t4.x);
-				o[2][j] = make_float2(t1.x - t3.x, t1.y - t3.y);
-				o[3][j] = make_float2(t2.x - t4.y, t2.y + t4.x);
-			}
-		}
-		if (tile + 1 < tile_hi)                                            // (here, not before the filters: 20 registers they need)
-			prefetch(tile + 1);
-		fw_wave_sync();                                                     // every window has been read: the staging area is free
-		if (active) {
-#pragma unroll
-			for (int c = 0; c < CH_M; c++) {
-				float4 *dst = reinterpret_cast<float4 *>(cs + c * FW_CS + CH_J * lane);
-				dst[0] = make_float4(o[c][0].x, o[c][0].y, o[c][1].x, o[c][1].y);
-				dst[1] = make_float4(o[c][2].x, o[c][2].y, o[c][3].x, o[c][3].y);
-			}
-		}
-		if (tile == 0) {                                                   // the stream's first tile: times -15 .. -1 are the carried history
-			fw_wave_sync();
-			if (lane < CH_M * 15)
-				cs[(lane / 15) * FW_CS + (lane % 15)] = chan_hist_in ? chan_hist_in[(lane / 15) * 16 + (lane % 15)] : make_float2(0.0f, 0.0f);
-		}
-		fw_wave_sync();
-
-		// ---- resampler: cs[c][j] = channel c at time T0 - 15 + j; lane l owns the tile's outputs l, l + p, ... (path (q l) mod p)
-		const size_t o0 = tile * (size_t)tile_out;
-		if (owner) {
-			// this lane's 16 taps (path (q l) mod p), re-read from LDS per tile: 16 registers the channelizer above needs
-			ch_v2f h2[8];
-#pragma unroll
-			for (int k = 0; k < 8; k++)
-				h2[k] = (ch_v2f){ rtaps[(2 * k) * pst + path_l], rtaps[(2 * k + 1) * pst + path_l] };
-#pragma nounroll
-			for (int c = 0; c < CH_M; c++) {
-				const c32 *xp = cs + c * FW_CS + n_l;
-				c32 *yo = out + c * out_stride + o0 + lane;
-				size_t oo = o0 + lane;
-				for (int it = 0; it < tm && oo < n_out; it++, oo += p, xp += q, yo += p) {
-					ch_v2f acc = { 0.0f, 0.0f };
-#pragma unroll
-					for (int k = 0; k < 16; k++) {
-						const ch_v2f xv = ch_lds(xp + k);
-						acc = acc + ((k & 1) ? ch_mul_tap<1>(xv, h2[k >> 1]) : ch_mul_tap<0>(xv, h2[k >> 1]));   // product, then sum
-					}
-					*yo = make_float2(acc.x, acc.y);
-				}
-			}
-		}
-		const int nres = p > 64 ? p - 64 : 0;                              // residues of every period, all channels
-		for (int idx = lane; idx < nres * tm * CH_M; idx += 64) {
-			const int c = idx / (nres * tm), r = idx % (nres * tm);
-			const int oi = 64 + r % nres + p * (r / nres);
-			if (o0 + oi >= n_out)
-				continue;
-			const unsigned qi = (unsigned)q * (unsigned)oi;
-			const int n = (int)(qi / (unsigned)p), path = (int)(qi % (unsigned)p);
-			const c32 *xp = cs + c * FW_CS + n;
-			float yr = 0.0f, yi = 0.0f;
-#pragma unroll
-			for (int k = 0; k < 16; k++) {
-				const c32 xv = xp[k];
-				const float h = rtaps[k * pst + path];
-				yr += xv.x * h;
-				yi += xv.y * h;
-			}
-			out[c * out_stride + o0 + oi] = make_float2(yr, yi);
-		}
-		if (chan_hist_out && tile + 1 == n_tiles && lane < CH_M * 15) {     // the call's last 15 channel samples
-			const long long j = (long long)n_total - (long long)tile * tile_in + (lane % 15);   // time n_total - 15 + i -> cs index
-			chan_hist_out[(lane / 15) * 16 + (lane % 15)] = cs[(lane / 15) * FW_CS + j];
-		}
-	}
-}
-
 // fused front end; returns 1 when the geometry does not fit (the caller then runs the two kernels), 0 / TRXHIP_EIO otherwise
 extern "C" int trx_launch_frontend_fused(const int16_t *d_wide, float *d_out, size_t n_total, int p, int q, size_t out_stride,
 					 const float *parts, const trx_tables *d_tab, void *d_wide_hist_io, const void *d_chan_hist_in,
 					 void *d_chan_hist_out, hipStream_t stream)
 {
-	const size_t n_out = n_total / q * p;
-	{
-		/* round 4: a tile per wave (frontend_wave_kernel); TRXHIP_FE_KERNEL=wg keeps the tile-per-workgroup form for A/B runs */
-		static const bool use_wg = getenv("TRXHIP_FE_KERNEL") && !strcmp(getenv("TRXHIP_FE_KERNEL"), "wg");
-		const int tmw = (256 - 15) / q;                                   /* periods per wave tile: q*tm + 15 <= 256 channel times in one pass */
-		if (!use_wg && tmw >= 1 && q * tmw + 30 <= FW_NLD * 64 && p <= 128 && p * 16 <= 4096 && (n_total % (size_t)q) == 0 && n_total >= 30 && n_out > 0) {
-			const size_t n_tiles_w = (n_out + (size_t)p * tmw - 1) / ((size_t)p * tmw);
-			const size_t n_wg = (n_tiles_w + FW_WPB - 1) / FW_WPB;
-			const size_t gxw = n_wg < 1024 ? n_wg : 1024;                 /* 4 workgroups (35 KB of LDS, 4 waves) per CU, a run of tiles per wave */
-			const size_t ldsw = (size_t)16 * (p + 1) * sizeof(float);
-			hipLaunchKernelGGL(frontend_wave_kernel, dim3((unsigned)gxw), dim3(FW_WPB * 64), ldsw, stream,
-					   reinterpret_cast<const uint4 *>(d_wide), n_total, reinterpret_cast<c32 *>(d_out), n_out, out_stride, p, q, tmw,
-					   n_tiles_w, parts, d_tab, reinterpret_cast<const uint4 *>(d_wide_hist_io),
-					   reinterpret_cast<const c32 *>(d_chan_hist_in), reinterpret_cast<c32 *>(d_chan_hist_out));
-			if (d_wide_hist_io)
-				hipLaunchKernelGGL(save_wide_hist_kernel, dim3(1), dim3(64), 0, stream, reinterpret_cast<const uint4 *>(d_wide),
-						   n_total, reinterpret_cast<uint4 *>(d_wide_hist_io));
-			return hipGetLastError() == hipSuccess ? 0 : TRXHIP_EIO;
-		}
-	}
 	const int m = (CH_TPB + p - 1) / p;                                  // outputs o and o + p*m share a filter path
 	const int tm = (4 * CH_TPB - 30) / q / m * m;                         // periods per tile: staging fits 4 loads per thread
+	const size_t n_out = n_total / q * p;
 	if (tm < m || p * m < CH_TPB || p * m > 2 * CH_TPB || q * tm + 15 > FE_CS || (n_total % (size_t)q) != 0 || n_total < 30 || n_out == 0)
 		return 1;
 	const size_t n_tiles = (n_out + (size_t)p * tm - 1) / ((size_t)p * tm);

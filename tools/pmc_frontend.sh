@@ -11,7 +11,7 @@ for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_L
 	   "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT" \
 	   "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum TCC_EA0_WRREQ_sum TCC_EA0_RDREQ_sum TCP_PENDING_STALL_CYCLES_sum"; do
 	i=$((i + 1))
-	timeout 300 rocprofv3 --output-format csv --kernel-include-regex "channelize_kernel|resample_kernel|frontend_fused_kernel" --pmc $SET -d $O/pmcfe$i -o $TAG -- python3 $R/tools/bench_frontend.py > $O/${TAG}_pmcfe$i.log 2>&1 || true
+	timeout 300 rocprofv3 --output-format csv --kernel-include-regex "channelize_kernel|resample_kernel|frontend_fused_kernel|frontend_wave_kernel" --pmc $SET -d $O/pmcfe$i -o $TAG -- python3 $R/tools/bench_frontend.py > $O/${TAG}_pmcfe$i.log 2>&1 || true
 done
 python3 - "$O" "$TAG" > $O/${TAG}_pmcfe.txt <<'PY'
 import csv, glob, sys, collections
