@@ -616,10 +616,6 @@ frontend_fused_kernel(const uint4 *__restrict__ in4, size_t n_total, c32 *__rest
 	const bool owner = t < S;
 	const unsigned qt = (unsigned)q * (unsigned)t;
 	const int n_t = (int)(qt / (unsigned)p), path_t = (int)(qt % (unsigned)p);
-	ch_v2f h2[8];                                                        // this thread's 16 resampler taps, in pairs
-#pragma unroll
-	for (int k = 0; k < 8; k++)
-		h2[k] = owner ? (ch_v2f){ parts[path_t * 16 + 2 * k], parts[path_t * 16 + 2 * k + 1] } : (ch_v2f){ 0.0f, 0.0f };
 	const int nstep = q * m;
 
 	const size_t per_wg = (n_tiles + gridDim.x - 1) / gridDim.x;
@@ -722,19 +718,45 @@ frontend_fused_kernel(const uint4 *__restrict__ in4, size_t n_total, c32 *__rest
 		// ---- resampler: cs[c][j] = channel c at time T0 - 15 + j
 		const size_t o0 = tile * (size_t)tile_out;
 		if (owner) {
-#pragma nounroll
-			for (int c = 0; c < CH_M; c++) {
-				const c32 *xp = cs + c * FE_CS + n_t;
-				c32 *yo = out + c * out_stride + o0 + t;
-				size_t oo = o0 + t;
-				for (int it = 0; it < iters && oo < n_out; it++, oo += S, xp += nstep, yo += S) {
-					ch_v2f acc = { 0.0f, 0.0f };
+			// this thread's 16 taps (path (q t) mod p), re-read from LDS per tile: 16 registers the channelizer above needs more
+			// than this loop does.  Two CHANNELS of an output position per pass: the same taps and offsets, 32 LDS reads in
+			// flight and two independent sum chains instead of one (the waves of this kernel wait two thirds of their time:
+			// profiles/r04_ab_runs.txt); each output's sum still runs k = 0..15, product then add.
+			ch_v2f h2[8];
 #pragma unroll
-					for (int k = 0; k < 16; k++) {
-						const ch_v2f xv = ch_lds(xp + k);
-						acc = acc + ((k & 1) ? ch_mul_tap<1>(xv, h2[k >> 1]) : ch_mul_tap<0>(xv, h2[k >> 1]));   // product, then sum
+			for (int k = 0; k < 8; k++)
+				h2[k] = (ch_v2f){ rtaps[(2 * k) * pst + path_t], rtaps[(2 * k + 1) * pst + path_t] };
+			{
+				// all four channels of an output position per pass: four independent sum chains over the same taps and offsets,
+				// 16 LDS reads in flight per block of four taps
+				const c32 *xa = cs + n_t;
+				c32 *ya = out + o0 + t;
+				size_t oo = o0 + t;
+				for (int it = 0; it < iters && oo < n_out; it++, oo += S, xa += nstep, ya += S) {
+					ch_v2f acc[CH_M];
+#pragma unroll
+					for (int c = 0; c < CH_M; c++)
+						acc[c] = (ch_v2f){ 0.0f, 0.0f };
+#pragma unroll
+					for (int k0 = 0; k0 < 16; k0 += 4) {
+						ch_v2f x[CH_M][4];
+#pragma unroll
+						for (int k = 0; k < 4; k++)
+#pragma unroll
+							for (int c = 0; c < CH_M; c++)
+								x[c][k] = ch_lds(xa + c * FE_CS + k0 + k);
+#pragma unroll
+						for (int k = 0; k < 4; k++) {
+							const int kk = k0 + k;
+#pragma unroll
+							for (int c = 0; c < CH_M; c++)
+								acc[c] = acc[c] + ((kk & 1) ? ch_mul_tap<1>(x[c][k], h2[kk >> 1]) : ch_mul_tap<0>(x[c][k], h2[kk >> 1]));   // product, then sum
+						}
+						__builtin_amdgcn_sched_barrier(0);
 					}
-					*yo = make_float2(acc.x, acc.y);
+#pragma unroll
+					for (int c = 0; c < CH_M; c++)
+						ya[c * out_stride] = make_float2(acc[c].x, acc[c].y);
 				}
 			}
 		}
