@@ -103,6 +103,15 @@ def sq_counters(tag, bursts=1 << 20, waves_per_simd=4, waves_per_cu=16):
                    "fewer than its 4 waves (mean_resident_waves_per_simd)"}
     json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_sq_counters.json"), "w"), indent=1)
     print(json.dumps(d, indent=1))
+    # what bench.py quotes as roofline.compute (the vector-issue bound of the kernel), next to the HBM traffic
+    tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tp) and "valu_busy" in d:
+        t = json.load(open(tp))
+        t["compute"] = {"valu_busy": d.get("valu_busy"), "salu_busy": d.get("salu_busy"), "lds_busy": d.get("lds_busy"),
+                        "valu_insts_per_burst": per.get("SQ_INSTS_VALU"), "salu_insts_per_burst": per.get("SQ_INSTS_SALU"),
+                        "lds_insts_per_burst": per.get("SQ_INSTS_LDS"),
+                        "mean_resident_waves_per_simd": d.get("mean_resident_waves_per_simd")}
+        json.dump(t, open(tp, "w"))
 
 
 if __name__ == "__main__":
