@@ -136,6 +136,12 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 		prefetch(burst_of((unsigned)wave));
 
 	DIAG_DECL;
+#ifdef TRX_WHATIF_PAIR
+	WhatIf wi_none = { 0, 0 };
+#define WI_1SPS , wi_none
+#else
+#define WI_1SPS
+#endif
 	unsigned j_next = 0;
 	for (unsigned j = (unsigned)wave; j < items; j = j_next) {
 		const unsigned b = burst_of(j);
@@ -232,6 +238,23 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 					};
 					rc = detect_any_burst<true, false>(type, tsc, max_toa, clip, decimate, dec, 156, cz, lseq, lhdr, thresh, sincv,
 								    pkc, lane, slice, 1 /* multiplying correlation */, &d DIAG_PASS);
+				} else if (type == TRXHIP_TSC && tsc < 8 && max_toa <= 33 && L >= 148 && !(slice & TRX_IFLAG_NO_UNIT)) {
+					// Round 4: the common slot at 1 SPS, straight-line, as in burst_pull4_kernel.  A normal burst is ONE
+					// detectGeneralBurst() window (analyzeTrafficBurst, :1887-1904: start 71, len 16 + max_toa <= 49) over the
+					// burst itself (no decimation at 1 SPS); its 31 + max_toa samples xs[56 ..] lie inside the burst and the
+					// 20 zero samples either side of it cover every padded read, so the correlation is the addition-only
+					// corr_unit() form (same bits, guard below) with lane = lag in one round -- where the generic dispatch
+					// multiplies every tap, range-checks every read and walks the candidate loop (~170 scalar, ~100 vector
+					// instructions per burst more).
+					const int len = 16 + max_toa;
+					const int unit_bad = (__ballot(unit_unsafe(xs[56 + lane]) && lane < 15 + len) != 0ull) ? 1 : 0;
+					const float *const hdr = lhdr + 8 * tsc;
+					const int hit = detect_burst_h<true, false>(xs, L, cz, lseq + LSEQ_TSC(tsc), hdr, 16, thresh, 71, len, sincv, pkc, lane,
+										    &d.toa, &d.amp, &d.ci, NoToaHook(), nullptr, slice, unit_bad ? -1 : tsc DIAG_PASS WI_1SPS);
+					wave_sync();
+					rc = hit ? TRXHIP_TSC : (clip ? -TRXHIP_SIGERR_CLIP : 0);                      // :1764, :1953-1954
+					d.toa -= 10.0f;                                                                 // :1768
+					d.tsc = tsc;
 				} else {
 					auto nothing = [](int, int) {};
 					rc = detect_any_burst<false, false>(type, tsc, max_toa, clip, nothing, xs, L, cz, lseq, lhdr, thresh, sincv,
@@ -276,17 +299,22 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 						hh[4 * q + 0] = h4.x; hh[4 * q + 1] = h4.y; hh[4 * q + 2] = h4.z; hh[4 * q + 3] = h4.w;
 					}
 					constexpr int D = 3;                                    // LDS read-ahead, in taps
+					// Taps 0, 17, 18, 19 are exactly 0.0f in all 64 filters (the sinc LUT is zero beyond 8 pi, sigProcLib.cpp:990-998;
+					// tests/test_capi_cpu.py): fl(x * 0) = +-0 and y + (+-0) == y for every finite x (y starts at +0 and can never
+					// become -0), so those four steps of the reference's loop change nothing and are skipped -- 16 multiply-adds per
+					// output instead of 20, same bits (as in burst_pull4_kernel's exact demodulator)
+					constexpr int K0 = 1, K1 = 17;
 					c32 xr[R + 19];
 #pragma unroll
 					for (int j = 0; j < R; j++)
 						yv[j] = make_float2(0.0f, 0.0f);
 #pragma unroll
-					for (int j = 0; j < R - 1 + D; j++)
+					for (int j = K0; j < K0 + R - 1 + D; j++)
 						xr[j] = xp[j];
 #pragma unroll
-					for (int k = 0; k < 20; k++) {
+					for (int k = K0; k < K1; k++) {
 						const float h = hh[k];
-						if (R - 1 + D + k < R + 19)
+						if (R - 1 + D + k < R + K1 - 1)
 							xr[R - 1 + D + k] = xp[R - 1 + D + k];
 #pragma unroll
 						for (int j = 0; j < R; j++) {
