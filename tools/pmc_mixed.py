@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One workload per launch for counter passes: WORKLOAD=normal|rach|ext|mixed python tools/pmc_mixed.py (2 warm + 2 timed launches)."""
+"""One workload per launch for counter passes: WORKLOAD=normal|rach|ext|mixed [EXACT=1] python tools/pmc_mixed.py (4 launches)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -17,5 +17,5 @@ dp = trx.params_tensor(p)
 res = torch.empty((n, 32), dtype=torch.uint8, device="cuda:0")
 soft = torch.empty((n, 148), dtype=torch.float32, device="cuda:0")
 for _ in range(4):
-    trx.detect_demod(iq, dp, sps=4, soft_stride=148, slice_bits=True, results=res, soft=soft)
+    trx.detect_demod(iq, dp, sps=4, soft_stride=148, slice_bits=True, results=res, soft=soft, exact=bool(os.environ.get("EXACT")))
 torch.cuda.synchronize()
