@@ -775,29 +775,50 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 					// x (y starts at +0 and can never become -0), so those four steps of the reference's loop change nothing and
 					// are skipped: 16 multiply-adds per output instead of 20, same bits.
 					constexpr int D = 1, K0 = 1, K1 = 17;
+					// Round 4: written with explicit packed instructions.  From the scalar form (yv.x += x.x * h; yv.y += x.y * h) the
+					// compiler built this block out of 385 v_add_f32, 147 v_mul_f32, 146 v_pk_mul_f32, 90 v_mov_b32 and 80 s_nop --
+					// 868 vector instructions for 192 complex-by-real multiply-adds, and the exact kernel is vector-issue saturated
+					// (profiles/r04_workload_counters.txt).  One v_pk_mul_f32 (tap picked by op_sel) + one v_pk_add_f32 per step:
+					// product, then sum, k ascending -- the reference's two roundings per step, 384 instructions.
 					const float2 *hp2 = reinterpret_cast<const float2 *>(dfilt + fidx * TRX_DELAY_HLEN);
-					c32 xr[R + 19];
+					v2f xr[R + 19];
+					v2f ya[R];
 #pragma unroll
 					for (int j = 0; j < R; j++)
-						yv[j] = make_float2(0.0f, 0.0f);
+						ya[j] = (v2f){ 0.0f, 0.0f };
 #pragma unroll
-					for (int j = K0; j < K0 + R - 1 + D; j++)
-						xr[j] = lds_c32(pb.p[j & 3] + (j >> 2));
+					for (int j = K0; j < K0 + R - 1 + D; j++) {
+						const c32 t = lds_c32(pb.p[j & 3] + (j >> 2));
+						xr[j] = (v2f){ t.x, t.y };
+					}
 					float2 hq = hp2[K0 >> 1];
 #pragma unroll
 					for (int k = K0; k < K1; k++) {
-						const float h = (k & 1) ? hq.y : hq.x;
-						if (R - 1 + D + k < R + K1 - 1)
-							xr[R - 1 + D + k] = lds_c32(pb.p[(R - 1 + D + k) & 3] + ((R - 1 + D + k) >> 2));
+						const v2f hpair = { hq.x, hq.y };                       // taps 2 (k >> 1) and 2 (k >> 1) + 1
+						if (R - 1 + D + k < R + K1 - 1) {
+							const c32 t = lds_c32(pb.p[(R - 1 + D + k) & 3] + ((R - 1 + D + k) >> 2));
+							xr[R - 1 + D + k] = (v2f){ t.x, t.y };
+						}
+						// the R products first, then the R sums: a v_pk_add_f32 straight behind the v_pk_mul_f32 it consumes costs a wait
+						// state each time (the compiler's own order reused one temporary pair and paid 156 s_nop in this block)
+						v2f pr[R];
 #pragma unroll
 						for (int j = 0; j < R; j++) {
-							yv[j].x += xr[j + k].x * h;
-							yv[j].y += xr[j + k].y * h;
+							if (k & 1)
+								asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(pr[j]) : "v"(xr[j + k]), "v"(hpair));
+							else
+								asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(pr[j]) : "v"(xr[j + k]), "v"(hpair));
 						}
+#pragma unroll
+						for (int j = 0; j < R; j++)
+							asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(ya[j]) : "v"(pr[j]));
 						if ((k & 1) && k + 1 < K1)
 							hq = hp2[(k + 1) >> 1];
 						__builtin_amdgcn_sched_barrier(0);
 					}
+#pragma unroll
+					for (int j = 0; j < R; j++)
+						yv[j] = make_float2(ya[j].x, ya[j].y);
 				}
 #pragma unroll
 				for (int j = 0; j < R; j++) {
