@@ -11,9 +11,12 @@ trx = TrxHip(0)
 wide = synth.make_wideband_stream(n_blocks, "cuda:0")
 
 
-def timeit(fn, reps=5):
+def timeit(fn, reps=20):
     keep = [fn(), fn()]; torch.cuda.synchronize()      # two live outputs: the timed calls below allocate nothing new
     del keep
+    for _ in range(60):                                # settled clocks (the GPU needs tens of ms of load)
+        fn()
+    torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(reps):
