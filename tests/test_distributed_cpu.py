@@ -15,7 +15,7 @@ sys.path.insert(0, sys.argv[1])
 import numpy as np, torch, torch.distributed as dist
 from osmo_trx_amd import shard, trxhip
 rank, local_rank, world = shard.init_distributed("gloo")
-assert world == 2 and dist.get_backend() == "gloo"
+assert world == int(os.environ["WORLD_SIZE"]) and dist.get_backend() == "gloo"
 blob = shard.broadcast_tables()                      # rank 0 generates, rank 1 receives + verifies checksum
 ck = trxhip.tables_checksum(blob)
 lo, hi = shard.shard_range(1000003, rank, world)
@@ -103,3 +103,32 @@ def test_bench_self_spawn_refuses_more_ranks_than_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert r.returncode != 0 and "--gpus 2 but this node shows" in r.stderr and '"metric"' not in r.stdout
+
+
+def test_eight_rank_world_matches_the_eight_gpu_layout(tmp_path):
+    """BASELINE.json configs[4]'s layout -- 8 ranks -- over gloo on the CPU: the table broadcast reaches every rank with the
+    same checksum, the contiguous shards of 1,000,003 bursts partition exactly, max / sum reductions and the device-list
+    gather return the same on every rank.  (The 8-GPU run itself needs an 8-GPU node; this is its control path.)"""
+    import json
+    from osmo_trx_amd import build as trx_build, trxhip
+    trx_build.build_lib()
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = free_port()
+    world = 8
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=600)
+        assert p.returncode == 0, e[-2000:]
+        outs.append(json.loads(o.strip().splitlines()[-1]))
+    outs.sort(key=lambda d: d["rank"])
+    ck = trxhip.tables_checksum(trxhip.generate_tables_host())
+    assert all(o["ck"] == ck for o in outs)
+    assert outs[0]["lo"] == 0 and outs[-1]["hi"] == 1000003 and all(outs[k]["hi"] == outs[k + 1]["lo"] for k in range(world - 1))
+    assert all(o["tot"] == 1000003 and o["mx"] == float(world) for o in outs)
+    assert all(o["names"] == [f"rank {k}: cpu worker" for k in range(world)] for o in outs)
