@@ -172,6 +172,15 @@ def test_hostpipe_argument_checks(trx):
         HostPipe(trx, 256, soft_stride=0, pkt_stride=0)
     with pytest.raises(TrxHipError):
         HostPipe(trx, 256, pkt_stride=158)
+    # diversity paths shorter than the energy scan reaches (energyDetect reads samples 0, 4, ..., 4 * (20 sps - 1): 317 samples at
+    # 4 SPS): refused, not read past the path (round 3's advisor finding)
+    with pytest.raises(TrxHipError):
+        HostPipe(trx, 64, burst_len=300, n_paths=2)
+    with pytest.raises(TrxHipError):
+        trx.select_diversity(torch.zeros((4, 2, 316, 2), dtype=torch.int16, device="cuda:0"))
+    sel, avg, path = trx.select_diversity(torch.ones((4, 2, 317, 2), dtype=torch.int16, device="cuda:0"))
+    torch.cuda.synchronize()
+    assert sel.shape == (4, 317, 2) and float(avg[0]) == 2.0
     p = HostPipe(trx, 64, depth=2)
     with pytest.raises(TrxHipError):
         p.submit(0, 65)
