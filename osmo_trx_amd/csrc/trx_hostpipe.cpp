@@ -231,6 +231,7 @@ int trxhip_hostpipe_wait(trxhip_hostpipe *p, int slot)
 	trxhip_hostpipe::Slot &sl = p->slot[slot];
 	if (!sl.busy)
 		return TRXHIP_OK;
+	(void)with_device(p->ctx);                                 /* (a multi-device gatherer waits for pipes of several GPUs from one thread) */
 	const bool ok = hipStreamSynchronize(sl.stream) == hipSuccess && !sl.failed;
 	sl.busy = false;
 	return ok ? TRXHIP_OK : TRXHIP_EIO;
@@ -243,6 +244,7 @@ int trxhip_hostpipe_query(trxhip_hostpipe *p, int slot)
 	trxhip_hostpipe::Slot &sl = p->slot[slot];
 	if (!sl.busy || sl.failed)
 		return 0;
+	(void)with_device(p->ctx);
 	const hipError_t e = hipEventQuery(sl.done);
 	return e == hipSuccess ? 0 : (e == hipErrorNotReady ? 1 : TRXHIP_EIO);
 }

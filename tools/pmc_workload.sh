@@ -11,7 +11,7 @@ i=0
 for SET in "SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
 	   "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT"; do
 	i=$((i + 1))
-	timeout 300 rocprofv3 --output-format csv --kernel-include-regex burst_pull4 --pmc $SET -d $O/pmcw$i -o $TAG -- python3 $R/tools/pmc_mixed.py > $O/${TAG}_pmcw$i.log 2>&1
+	timeout 300 rocprofv3 --output-format csv --kernel-include-regex burst_pull --pmc $SET -d $O/pmcw$i -o $TAG -- python3 $R/tools/pmc_mixed.py > $O/${TAG}_pmcw$i.log 2>&1
 done
 python3 - "$O" "$TAG" > $O/${TAG}_pmcw.txt <<'PY'
 import csv, glob, sys, collections
