@@ -166,7 +166,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 		   unsigned n_bursts, int L_arg, float thresh, float full_scale, int soft_stride_arg, int slice_arg,
 		   unsigned *__restrict__ pool_ctr)
 {
-	static_assert(!(COMMON && CF32), "the common instantiation reads int16 bursts");
+	static_assert(!(COMMON && CF32 && EXACT), "complex64 input: the common instantiation exists for the fused demodulator only (16 waves per CU)");
 	static_assert(K4_TABLES_BYTES % 16 == 0 && (K4_SLICE * 8) % 16 == 0 && (K4_XS * 8) % 16 == 0 &&
 		      ((TRX_DEC_NARROW + TRX_CZ_PAD) * 8) % 16 == 0, "dec[] and cz[] are read / written 16 bytes at a time");
 	const int L = COMMON ? 625 : L_arg;
@@ -1115,7 +1115,7 @@ extern "C" int trx_launch_pull4(unsigned *d_pool_ctr, const void *d_iq, int cf32
 #endif
 	if (grid > need) grid = need;
 	/* the instantiation with the common launch parameters folded (see the kernel) */
-	const bool common = !cf32 && L == 625 && d_soft && !d_ebp_in && soft_stride == 148 &&
+	const bool common = (!cf32 || !exact) && L == 625 && d_soft && !d_ebp_in && soft_stride == 148 &&
 			    (flags & ~TRXHIP_FLAG_EXACT_DEMOD) == TRXHIP_FLAG_SLICE;
 #define LAUNCH4(CF_, EX_, CM_)                                                                                  \
 	do {                                                                                                    \
@@ -1137,7 +1137,7 @@ extern "C" int trx_launch_pull4(unsigned *d_pool_ctr, const void *d_iq, int cf32
 	} while (0)
 	/* the cross-die pool needs every workgroup to own >= 7 static groups and the grid to be the persistent one */
 	unsigned *const pool = (d_pool_ctr && grid == (size_t)n_cu && need >= 8 * grid) ? d_pool_ctr : nullptr;   /* (TRXHIP_NO_POOL: trx_capi.cpp) */
-	if (cf32)        { if (exact) LAUNCH4(true, true, false); else LAUNCH4(true, false, false); }
+	if (cf32)        { if (exact) LAUNCH4(true, true, false); else if (common) LAUNCH4(true, false, true); else LAUNCH4(true, false, false); }
 	else if (common) { if (exact) LAUNCH4(false, true, true); else LAUNCH4(false, false, true); }
 	else             { if (exact) LAUNCH4(false, true, false); else LAUNCH4(false, false, false); }
 #undef LAUNCH4
