@@ -186,6 +186,22 @@ def side_legs(args, trx, synth, shard, step, iq, n, dev, rank, world, results, s
 PRECONDITION_S = 0.2
 
 
+def read_sclk(out, device_index):
+    """Current shader clock (MHz) of the device as rocm-smi reports it; {} left untouched when the tool is missing or slow."""
+    import re
+    import shutil
+    import subprocess
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    try:
+        time.sleep(0.25)                                           # let the launches settle in
+        r = subprocess.run([exe, "-d", str(device_index), "--showclocks"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=4.0)
+        m = re.search(r"sclk clock level:\s*\d+:\s*\((\d+)Mhz\)", r.stdout)
+        if m:
+            out["sclk_mhz"] = int(m.group(1))
+    except Exception:
+        pass
+
+
 def warm_clocks(fn, seconds=PRECONDITION_S):
     """Untimed launches of `fn` for `seconds`: the GPU's clocks need tens of milliseconds of load to settle (a leg that
     follows synthetic-data generation or the CPU baseline otherwise starts on idle clocks and reads 4-6 % low)."""
@@ -465,17 +481,28 @@ def main():
     sustained = None
     if args.sustain_seconds > 0:
         k_sus = max(args.steps, int(args.sustain_seconds * 1.05 / max(kernel_ms * 1e-3, 1e-6)) + 1)
+        # the shader clock while the kernel runs, read once by rocm-smi from a side thread (rank 0): the boxes of a pool differ --
+        # round 4 met one that ran every kernel at half clock -- and a reader of the line should see that next to the rate
+        clock = {}
+        watcher = None
+        if rank == 0:
+            import threading
+            watcher = threading.Thread(target=read_sclk, args=(clock, local_rank), daemon=True)
         shard.barrier()
         torch.cuda.synchronize()
         t0s = time.perf_counter()
+        if watcher:
+            watcher.start()
         for _ in range(k_sus):
             step()
         torch.cuda.synchronize()
         t_sus = time.perf_counter() - t0s
+        if watcher:
+            watcher.join(timeout=5.0)
         shard.barrier()
         t_sus = shard.max_over_ranks(t_sus, dev if world > 1 else None)
         sustained = {"seconds": round(t_sus, 3), "launches": k_sus, "mbursts_per_s_all_gpus": round(n * world * k_sus / t_sus / 1e6, 3),
-                     "ms_per_step": round(t_sus / k_sus * 1e3, 4),
+                     "ms_per_step": round(t_sus / k_sus * 1e3, 4), "sclk_mhz_under_load": clock.get("sclk_mhz"),
                      "note": "back-to-back launches behind the timed region, no host synchronisation in between; never `value`"}
 
     # who ran: every rank's device, gathered over the same backend the tables were broadcast on
