@@ -37,7 +37,8 @@ extern "C" int trx_launch_energy_detect(const float *d_x, size_t n_bursts, int b
 					hipStream_t stream);
 extern "C" int trx_launch_sch_detect(const float *d_iq, size_t buf_stride, trxhip_burst_result *d_results,
 				     const trx_tables *d_tab, size_t n_bufs, int len, int start, int toa_sub, float thresh,
-				     hipStream_t stream);
+				     int unit_tables, hipStream_t stream);
+extern "C" int trx_unit_mask_sch_match(const trx_tables *t);   /* trx_sch.hip: the SCH sequence's compiled-in sign mask vs the tables */
 extern "C" int trx_launch_delay_vector(const float *d_in, float *d_out, const float *d_delays, const trx_tables *d_tab,
 				       size_t n_vec, int len, hipStream_t stream);
 extern "C" int trx_launch_scale_vector(float *d_x, size_t len, float sr, float si, hipStream_t stream);
@@ -120,6 +121,7 @@ int trxhip_create_from_tables(trxhip_ctx **out, int device, const void *h_blob, 
 	ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 	ctx->d_tables = nullptr;
 	ctx->no_unit = trx_unit_masks_match(t) ? 0 : 1;
+	ctx->sch_unit = trx_unit_mask_sch_match(t) ? 1 : 0;
 	ctx->d_pool = nullptr;
 	ctx->pool_nstreams = 0;
 	ctx->pool_enabled = getenv("TRXHIP_NO_POOL") ? 0 : 1;          /* measurement switch, read once per context */
@@ -430,7 +432,7 @@ int trxhip_detect_sch_batch_cf32(trxhip_ctx *ctx, const float *d_iq, trxhip_burs
 		return TRXHIP_EIO;
 	const int toa_sub = (state == TRXHIP_SCH_DETECT_BUFFER) ? 3 + 39 + 64 : head;      /* :1853-1858 */
 	return trx_launch_sch_detect(d_iq, buf_len, d_results, ctx->d_tables, n_bufs, len, start, toa_sub, threshold,
-				     static_cast<hipStream_t>(stream));
+				     ctx->sch_unit, static_cast<hipStream_t>(stream));
 }
 
 int trxhip_delay_vector_batch_cf32(trxhip_ctx *ctx, const float *d_in, float *d_out, const float *d_delays, size_t n_vec,

@@ -11,6 +11,7 @@ struct trxhip_ctx {
 	int n_cu;
 	trx_tables *d_tables;
 	int no_unit;        /* tables do not have the compiled-in unit structure: keep the multiplying correlation */
+	int sch_unit;       /* the SCH sequence has the unit structure the kernel's compiled-in mask expects (trx_sch.hip) */
 	int no_sym;         /* decimator taps not bitwise symmetric: the kernels' straight-line paths (mirrored taps) are off */
 	/* cross-die work pool of the 4-SPS kernel (trx_kernel4.hip): one 64-byte counter PER STREAM.  Launches on one stream
 	 * run in order, so the hipMemsetAsync in front of a launch can never zero a counter an earlier launch still draws

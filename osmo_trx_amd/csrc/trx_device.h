@@ -319,7 +319,7 @@ __device__ __forceinline__ float norm2(c32 v) { return v.y * v.y + v.x * v.x; }
 //
 // Every GMSK correlation sequence of the reference (TSC 0..7, RACH TS0..2, dummy) is conj(+-1 rotated by k*pi/2) with
 // the rotation table's fp64 phase residue left in: tap k is (+-1, e) for even k and (e, +-1) for odd k with
-// |e| <= 4.6e-14 (checked when the tables are generated: trx_tables.unit_neg / unit_ok).  mac_cmplx() evaluates
+// |e| <= 4.6e-14 (7e-14 for the SCH sequence; bound 1e-13 checked when the tables are generated: trx_tables.unit_neg / unit_ok).  mac_cmplx() evaluates
 //     y0 += x0*h0 - x1*h1;   y1 += x0*h1 + x1*h0;
 // For an even tap h = (s, e): fl(s*x0) = +-x0 exactly and |fl(x1*e)| <= |x1| * 4.6e-14, which is below a quarter ulp
 // of x0 -- so that fl(+-x0 - fl(x1*e)) == +-x0 -- whenever |x1| <= 2^17 |x0| (2^17 * 4.6e-14 = 6.0e-9 < 2^-26);
@@ -346,6 +346,7 @@ __device__ __forceinline__ float norm2(c32 v) { return v.y * v.y + v.x * v.x; }
 #define TRX_UNIT_NEG_RACH1  0xfd6df886b3ull
 #define TRX_UNIT_NEG_RACH2  0x4429f37d6eull
 #define TRX_UNIT_NEG_DUMMY  0x1212ull
+#define TRX_UNIT_NEG_SCH    0x41f73b2d69b9df04ull     /* 64 taps (trx_sch.hip); residue up to 7e-14: 2^17 * 7e-14 = 9.2e-9 < 2^-26 */
 
 // acc += x * u for the unit tap u of parity ODD and sign NEG:  even: +-(x0, x1);  odd: h = (e, s): (-s*x1, s*x0)
 template <bool ODD, bool NEG>

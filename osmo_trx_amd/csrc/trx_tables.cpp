@@ -92,7 +92,8 @@ public:
 	}
 
 	// Which sequences are "+-1 rotated by k*pi/2 with an fp64 phase residue" tap by tap (the premise of corr_unit(),
-	// trx_device.h): even taps (+-1, e), odd taps (e, +-1), |e| <= 5e-14.
+	// trx_device.h): even taps (+-1, e), odd taps (e, +-1), |e| <= 1e-13 (2^17 * 1e-13 = 1.3e-8 stays below a quarter ulp, 2^-26:
+	// the exactness argument of corr_unit(); the 64-tap SCH sequence's residue reaches 7e-14 at its last taps, the others 4.6e-14).
 	void unit_structure()
 	{
 		t_->unit_ok = 0;
@@ -103,7 +104,7 @@ public:
 			for (int k = 0; ok && k < q.n; k++) {
 				const float one = (k & 1) ? q.taps[k].im : q.taps[k].re;
 				const float eps = (k & 1) ? q.taps[k].re : q.taps[k].im;
-				ok = (one == 1.0f || one == -1.0f) && std::fabs(eps) <= 5e-14f;
+				ok = (one == 1.0f || one == -1.0f) && std::fabs(eps) <= 1e-13f;
 				if (one < 0.0f)
 					neg |= 1ull << k;
 			}

@@ -59,7 +59,7 @@ struct trx_tables {
 	float    edge_step;                                 // 2.0f * M_PI_F / 8.0f
 	float    edge_pad;
 	// unit structure of the GMSK correlation sequences (trx_device.h, corr_unit()): bit s of unit_ok is set when every
-	// tap k of seq[s] is (+-1, e) for even k / (e, +-1) for odd k with |e| <= 5e-14; bit k of unit_neg[s] = that +-1 is -1
+	// tap k of seq[s] is (+-1, e) for even k / (e, +-1) for odd k with |e| <= 1e-13; bit k of unit_neg[s] = that +-1 is -1
 	uint64_t unit_neg[TRX_NSEQ];
 	uint32_t unit_ok;
 	uint32_t unit_pad;
@@ -82,7 +82,7 @@ struct trx_tables {
 static_assert(offsetof(trx_tables, edge8) % 16 == 0, "edge8 rows are fetched as float4");
 
 #define TRX_TABLES_MAGIC   0x54585254u
-#define TRX_TABLES_VERSION 6u
+#define TRX_TABLES_VERSION 7u
 
 // XOR swizzle of the sincv index: conflict-free LDS gathers both for lanes whose positions differ
 // by multiples of 16/512 (coarse bisection levels) and by 1/512 steps (fine levels).

@@ -196,13 +196,13 @@ def test_unit_tap_structure_of_gmsk_sequences(lib):
     hdr = open(os.path.join(ROOT, "osmo_trx_amd", "csrc", "trx_device.h")).read()
     compiled = {m.group(1): int(m.group(2), 16) for m in re.finditer(r"#define TRX_UNIT_NEG_(\w+)\s+0x([0-9a-f]+)ull", hdr)}
     seqs = [("TSC%d" % i, i, o["midamble"][i]) for i in range(8)] + [("RACH%d" % i, 8 + i, o["rach"][i]) for i in range(3)] + \
-        [("DUMMY", 11, o["dummy"])]
+        [("DUMMY", 11, o["dummy"]), ("SCH", 20, o["sch"])]           # (SCH: 64 taps, trx_sch.hip; residue up to 7e-14 at its last taps)
     for name, s, ref in seqs:
         taps = ref["seq"]
         neg = 0
         for k, h in enumerate(taps):
             one, eps = (h.imag, h.real) if k & 1 else (h.real, h.imag)
-            assert abs(one) == 1.0 and abs(eps) <= 5e-14, (name, k, h)
+            assert abs(one) == 1.0 and abs(eps) <= (1e-13 if name == "SCH" else 5e-14), (name, k, h)
             if one < 0:
                 neg |= 1 << k
         assert (int(t["unit_ok"]) >> s) & 1
