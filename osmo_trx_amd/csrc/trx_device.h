@@ -1033,7 +1033,6 @@ __device__ __forceinline__ float edge_post(const c32 *dec, int n_dec, const trx_
 {
 	const c32 r_pi8 = make_float2(tab->edge_rot2[0].re, tab->edge_rot2[0].im);
 	const c32 r_pi4 = make_float2(tab->edge_rot2[1].re, tab->edge_rot2[1].im);
-	const float step = tab->edge_step;
 	float err = 0.0f;
 	for (int i = lane; i < n_dec; i += WAVE) {
 		float er = 0.0f, ei = 0.0f;
@@ -1049,7 +1048,13 @@ __device__ __forceinline__ float edge_post(const c32 *dec, int n_dec, const trx_
 		const trx_c32 d = tab->edge_derot[i & 15];
 		const c32 rot = cmul(make_float2(er, ei), make_float2(d.re, d.im));
 		if (i >= 8 && i < n_dec - 8) {
-			const int k = (int)roundf(atan2f(rot.y, rot.x) / step);
+			// computeEdgeCI's nearest 8-PSK point, k = round(atan2f(y, x) / (pi/4)) (:2081-2084), decided on the octant
+			// boundaries |y| = tan(pi/8) |x| instead of through the arc tangent: the same k except for a symbol within the
+			// arc tangent's own rounding of a boundary, where both neighbours are equally far and the error sum is the same
+			const float ax = fabsf(rot.x), ay = fabsf(rot.y);
+			int k = (ay <= 0.41421356237f * ax) ? 0 : (ax <= 0.41421356237f * ay) ? 2 : 1;
+			if (rot.x < 0.0f) k = 4 - k;
+			if (__builtin_signbit(rot.y)) k = -k;
 			const trx_c32 id = tab->edge_ideal[k + 4];
 			const c32 e = make_float2(id.re - rot.x, id.im - rot.y);
 			err += norm2(e);

@@ -647,6 +647,42 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 					}
 					rc = hit ? type : (clip ? -TRXHIP_SIGERR_CLIP : 0);                       // :1764, :1797-1800
 					toa -= 8.0f;                                                               // :1768
+				} else if (!COMMON && type == TRXHIP_EDGE && tsc < 8 && max_toa <= 33 && !(slice & TRX_IFLAG_NO_SYM)) {
+					// EDGE slots, straight-line: detectEdgeBurst (:1906-1924: target 82, head 6, tail 6 + max_toa -> start 75,
+					// len 12 + max_toa <= 45, 16 taps of the 8-PSK sequence, multiplying correlation) reads dec[60 .. 87 + max_toa);
+					// on a miss detectAnyBurst falls through to the GMSK training sequence (:1933-1941), whose window is the normal
+					// burst's dec[56 .. 87 + max_toa).  One decimation round with lane = sample 56 + lane serves both.
+					const int len = 16 + max_toa;
+					__builtin_assume(len >= 16 && len <= 49);
+					{
+						const c32 y = decimate16_sym(P + PH_M0 + (56 + lane) - 4, gdec);
+						dec[56 + lane] = y;
+						unit_bad |= (__ballot(unit_unsafe(y) && lane < 15 + len) != 0ull) ? 1 : 0;
+						wave_sync();
+					}
+					DIAG_MARK(2);
+					int hit = detect_burst_h<true, true>(dec, 156, cz, lseq + LSEQ_EDGE(tsc), lhdr + 8 * (11 + tsc), 16, thresh, 75, len - 4,
+									     sincv, pkc, lane, &toa, &amp, &ci, NoToaHook(), wa4, slice, -1 DIAG_PASS
+#ifdef TRX_WHATIF_PAIR
+									     , wi_full
+#endif
+									     );
+					wave_sync();
+					if (hit) {
+						rc = TRXHIP_EDGE;                                                          // :1953-1954
+						toa -= 6.0f;                                                               // :1768
+					} else {
+						hit = detect_burst_h<true, true>(dec, 156, cz, lseq + LSEQ_TSC(tsc), lhdr + 8 * tsc, 16, thresh, 71, len, sincv,
+										 pkc, lane, &toa, &amp, &ci, NoToaHook(), wa4, slice, unit_bad ? -1 : tsc DIAG_PASS
+#ifdef TRX_WHATIF_PAIR
+										 , wi_full
+#endif
+										 );
+						wave_sync();
+						rc = hit ? TRXHIP_TSC : (clip ? -TRXHIP_SIGERR_CLIP : 0);
+						toa -= 10.0f;
+					}
+					out_tsc = tsc;
 				} else {
 					DetectOut d;
 					rc = detect_any_burst<true, true>(type, tsc, max_toa, clip, decimate, dec, 156, cz, lseq, lhdr, thresh, sincv, pkc,

@@ -294,6 +294,8 @@ def test_edge_8psk_bursts(trx):
     from osmo_trx_amd import synth
     iq, params, bits = synth.make_edge_bursts(1024, "cpu")
     params["type"][7::16] = O.TSC            # GMSK detection attempted on an 8-PSK burst
+    params["max_toa"][1::5] = 33             # the widest window of the kernel's straight-line EDGE branch ...
+    params["max_toa"][2::5] = 34             # ... and the first one that takes the general candidate loop
     for slice_bits in (False, True):
         o_res, o_soft = O.pull_batch(iq.numpy(), 4, params, soft_stride=444, slice_bits=slice_bits)
         assert (o_res["rc"] == O.EDGE).sum() > 900 and (o_res["nbits_div4"] == 111).sum() > 900
