@@ -493,7 +493,7 @@ size_t BurstGatherer::pushSlot(const size_t *chans, const BurstRequest *rqs, siz
 {
 	Impl &m = *impl_;
 	Impl::User user(m);
-	if (!user.ok || !chans || !rqs || m.stopping || !m.running) {
+	if (!user.ok || !chans || !rqs || n > 65535 || m.stopping || !m.running) {     /* (ok_idx[] holds 16-bit positions) */
 		if (accepted)
 			for (size_t k = 0; k < n; k++) accepted[k] = false;
 		return 0;
