@@ -314,7 +314,7 @@ def test_edge_8psk_bursts(trx):
     o2_soft = np.zeros((64, 444), dtype=np.float32)
     for i in range(64):
         x = cf700[i].numpy()
-        rc, e = O.detect_any_burst(x, int(params["tsc"][i]), 4.0, 4, int(params["type"][i]), 3)
+        rc, e = O.detect_any_burst(x, int(params["tsc"][i]), 4.0, 4, int(params["type"][i]), int(params["max_toa"][i]))
         o2_res["rc"][i] = rc
         if rc > 0:
             s = O.demod_any_burst(x, rc, 4, e)
