@@ -41,6 +41,12 @@ for name, (iq, params, _) in (("normal, 1M", synth.make_normal_bursts(1 << 20, "
 
 # EDGE 8-PSK (444 soft bits) and the generic kernel (1 SPS, 156/157-sample bursts)
 iq, params, _ = synth.make_edge_bursts(1 << 16, "cpu", seed=0xCA15)
+# every search window of the straight-line EDGE branch (max_toa <= 33) and of the general candidate loop beside it, and GMSK
+# bursts in EDGE slots (detectAnyBurst's fall-through to the training sequence, sigProcLib.cpp:1933-1941)
+params["max_toa"] = np.array([3, 0, 20, 33, 34, 63, 3, 12], dtype=params["max_toa"].dtype)[np.arange(len(params)) % 8]
+nb_iq, nb_p, _ = synth.make_normal_bursts(1 << 13, "cpu", 4, seed=0xCA1E)
+iq[3::8] = nb_iq
+params["tsc"][3::8] = nb_p["tsc"]
 o_res, o_soft = O.pull_batch(iq.numpy(), 4, params, soft_stride=444, slice_bits=False)
 g_res, g_soft = run_gpu(trx, iq, params, 4, soft_stride=444, slice_bits=False, exact=True)
 check_parity(g_res, g_soft, o_res, o_soft)
