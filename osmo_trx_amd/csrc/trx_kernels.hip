@@ -171,7 +171,7 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 					if (CF32) v = pre_c[r];
 					else v = make_float2((float)(int16_t)(pre_i[r] & 0xffffu), (float)(int16_t)(pre_i[r] >> 16));
 					xs[i] = v;
-					amax = fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y)));
+					asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(v.x), "v"(v.y));   // maxAmplitude(): one instruction per sample
 					if (r * WAVE < 4 * 20 * SPS)                    // compile-time: rounds that can hold samples 4i, i < win
 						if ((lane & 3) == 0 && i < 4 * win)
 							epart += norm2(v);
@@ -200,8 +200,7 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 		}
 
 		if (type != TRXHIP_OFF) {                                   // Transceiver.cpp:704-707
-			amax = wave_max(amax);                                  // maxAmplitude(), :1711-1722
-			clip = amax > TRX_CLIP_THRESH;
+			clip = __ballot(amax > TRX_CLIP_THRESH) != 0ull;        // maxAmplitude() > 30000 (:1711-1722, :1746): some lane saw a larger component
 			// energyDetect(burst, 20*sps) (:1573-1585), tree-summed; RSSI (Transceiver.cpp:741,751) in fp32
 			energy = wave_sum(epart) / (float)win;
 			if (!ABL(2))
@@ -292,11 +291,12 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 					// fshift[m] = sum_k X(m - 9 + k) * h[k]  (convolve NO_DELAY, 20 real taps; :1060)
 					// tap-outer / output-inner: each output still accumulates k = 0..19 in order, but only a
 					// sliding window of R samples (+ R accumulators) is live instead of all R+19 inputs
-					float hh[TRX_DELAY_HLEN];
+					trx_v2f hp[TRX_DELAY_HLEN / 2];                             // taps 2q, 2q + 1 in one register pair
 #pragma unroll
 					for (int q = 0; q < TRX_DELAY_HLEN / 4; q++) {          // 5 LDS broadcast reads
 						const float4 h4 = hf4[q];
-						hh[4 * q + 0] = h4.x; hh[4 * q + 1] = h4.y; hh[4 * q + 2] = h4.z; hh[4 * q + 3] = h4.w;
+						hp[2 * q + 0] = (trx_v2f){ h4.x, h4.y };
+						hp[2 * q + 1] = (trx_v2f){ h4.z, h4.w };
 					}
 					constexpr int D = 3;                                    // LDS read-ahead, in taps
 					// Taps 0, 17, 18, 19 are exactly 0.0f in all 64 filters (the sinc LUT is zero beyond 8 pi, sigProcLib.cpp:990-998;
@@ -304,25 +304,42 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 					// become -0), so those four steps of the reference's loop change nothing and are skipped -- 16 multiply-adds per
 					// output instead of 20, same bits (as in burst_pull4_kernel's exact demodulator)
 					constexpr int K0 = 1, K1 = 17;
-					c32 xr[R + 19];
+					// As there, in explicit packed instructions: one v_pk_mul_f32 (the tap picked from its pair by op_sel) and one
+					// v_pk_add_f32 per step -- product, then sum, k ascending: the reference's two roundings per step.  (From the
+					// scalar form the compiler builds unpacked multiplies and adds with moves in between.)
+					trx_v2f xr[R + 19];
+					trx_v2f ya[R];
 #pragma unroll
 					for (int j = 0; j < R; j++)
-						yv[j] = make_float2(0.0f, 0.0f);
+						ya[j] = (trx_v2f){ 0.0f, 0.0f };
 #pragma unroll
-					for (int j = K0; j < K0 + R - 1 + D; j++)
-						xr[j] = xp[j];
+					for (int j = K0; j < K0 + R - 1 + D; j++) {
+						const c32 t = xp[j];
+						xr[j] = (trx_v2f){ t.x, t.y };
+					}
 #pragma unroll
 					for (int k = K0; k < K1; k++) {
-						const float h = hh[k];
-						if (R - 1 + D + k < R + K1 - 1)
-							xr[R - 1 + D + k] = xp[R - 1 + D + k];
+						const trx_v2f hpair = hp[k >> 1];
+						if (R - 1 + D + k < R + K1 - 1) {
+							const c32 t = xp[R - 1 + D + k];
+							xr[R - 1 + D + k] = (trx_v2f){ t.x, t.y };
+						}
+						trx_v2f pr[R];
 #pragma unroll
 						for (int j = 0; j < R; j++) {
-							yv[j].x += xr[j + k].x * h;
-							yv[j].y += xr[j + k].y * h;
+							if (k & 1)
+								asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(pr[j]) : "v"(xr[j + k]), "v"(hpair));
+							else
+								asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(pr[j]) : "v"(xr[j + k]), "v"(hpair));
 						}
+#pragma unroll
+						for (int j = 0; j < R; j++)
+							asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(ya[j]) : "v"(pr[j]));
 						__builtin_amdgcn_sched_barrier(0);              // keep the window short: no load hoisting
 					}
+#pragma unroll
+					for (int j = 0; j < R; j++)
+						yv[j] = make_float2(ya[j].x, ya[j].y);
 				} else {
 #pragma unroll
 					for (int j = 0; j < R; j++)
