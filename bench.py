@@ -384,8 +384,10 @@ def spawn_ranks(n):
     port = free_port()
     procs = []
     for r in range(n):
+        # (HSA_ENABLE_IPC_MODE_LEGACY=0: the hosts of this pool support dmabuf IPC only; RCCL needs it for its peer buffers)
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TRXHIP_BENCH_LAUNCHER="bench.py self-spawn")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     pending = list(procs)

@@ -27,6 +27,7 @@ def init_distributed(backend=None):
             # a 1-GPU box; RCCL refuses two ranks on one device, gloo moves the same device tensors through the host)
             backend = os.environ.get("TRXHIP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (RCCL peer buffers on hosts without the legacy mode)
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
