@@ -22,12 +22,13 @@ def env_world():
 def init_distributed(backend=None):
     rank, local_rank, world = env_world()
     if world > 1 and not dist.is_initialized():
+        # before anything initialises the GPU runtime: dmabuf IPC (RCCL peer buffers on hosts without the legacy mode)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
             # TRXHIP_DIST_BACKEND=gloo: ranks that share one GPU (tests/test_gpu_sharded.py runs bench.py's N = 2 path on
             # a 1-GPU box; RCCL refuses two ranks on one device, gloo moves the same device tensors through the host)
             backend = os.environ.get("TRXHIP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (RCCL peer buffers on hosts without the legacy mode)
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
