@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TRXHIP_ABI_VERSION 3
+#define TRXHIP_ABI_VERSION 4
 
 /* error codes */
 #define TRXHIP_OK          0
@@ -61,12 +61,24 @@ enum trxhip_signal_error {
 
 /* `flags` of the detect/demod entry points */
 #define TRXHIP_FLAG_SLICE        1  /* soft bits through vectorSlicer(): 0..1, 148 per burst (else raw -1..+1) */
-#define TRXHIP_FLAG_EXACT_DEMOD  2  /* demodulate with the reference's two FIR stages in its operand order: soft bits
-                                     * bit-identical to the generic-C reference.  Default (flag clear) is the fused
-                                     * delay-o-decimate filter with FMA (24 of its 35 taps): soft bits within
-                                     * TRXHIP_FUSED_SOFT_ATOL (below) of the reference's, ~4x fewer multiply-adds.
-                                     * Detection (rc, TOA, amp) is bit-exact either way.
+#define TRXHIP_FLAG_EXACT_DEMOD  2  /* the bit-exact kernel: demodulate with the reference's two FIR stages in its operand order and
+                                     * search the TOA with the reference's sums: rc, TOA, amp, C/I and soft bits bit-identical to the
+                                     * generic-C reference.  Default (flag clear) is the fused kernel: delay-o-decimate filter with
+                                     * FMA (24 of its 35 taps), soft bits within TRXHIP_FUSED_SOFT_ATOL (below) of the reference's,
+                                     * ~4x fewer multiply-adds; and the FAST detector (round 5): rc, TSC and TOA still IDENTICAL to
+                                     * the reference's -- every early / late decision of peakDetect()'s bisection is either
+                                     * certified by a proven rounding-error margin or re-run in the reference's operand order
+                                     * (csrc/trx_device.h, peak_detect_fast) -- while the interpolated peak value is an FMA sum:
+                                     * amp within TRXHIP_FAST_AMP_RTOL, C/I within TRXHIP_FAST_CI_ATOL_DB(ci) of the reference's.
                                      * Only the 4-SPS / 625-sample kernel has a fused path; others are always exact. */
+/* The FAST detector's tolerance statement (fused kernels only; tests quote these).  amp = interpolated correlation peak / gain:
+ * one 16-term sum per component, FMA against product-then-sum; |amp - ref| <= TRXHIP_FAST_AMP_RTOL * |ref| (complex distance;
+ * proven bound 2.6 * 25 u = 3.9e-6 relative to the correlation's arg-max magnitude, measured <= 3e-7).
+ * C/I = 10 log10(C / (S - C)) with C = |peak|^2 / den and S the mean sample power (tree-summed in the FAST detector: within
+ * 1.2e-6 of the reference's ordered sum): S - C cancels by the factor 1 + C/I, so relative errors eC of C and eS of S become
+ * (eC + eS) (1 + 10^(ci/10)) of the ratio:  |ci - ref| <= 1e-4 dB + 4.35 * (2 * TRXHIP_FAST_AMP_RTOL + 1.2e-6) * (1 + 10^(ci/10)) dB. */
+#define TRXHIP_FAST_AMP_RTOL        1e-6f
+#define TRXHIP_FAST_CI_ATOL_DB(ci)  (1e-4f + 1.4e-5f * (1.0f + powf(10.0f, (ci) * 0.1f)))
 /* The one statement of the default (fused) demodulator's tolerance; tests/, tools/parity_campaign.py, bench.py and DESIGN.md
  * quote these two numbers and nothing else.  ABSOLUTE error of a soft bit against the generic-C reference, on soft bits
  * whose full scale is 1 (raw -1..+1 or sliced 0..1):
@@ -124,6 +136,10 @@ const char *trxhip_strerror(int err);
  * never depend on it (tests/test_gpu_parity.py); a measurement switch.  TRXHIP_NO_POOL in the environment makes 0 the
  * default of contexts created afterwards. */
 int  trxhip_set_work_pool(trxhip_ctx *ctx, int enabled);
+/* Counters of the fused kernels' FAST detector on the context's device since the last reset (synchronises the device):
+ * out4[0] = bursts whose TOA search found an uncertified early / late decision on its path and was re-run in the
+ * reference's operand order; out4[1..3] reserved.  Diagnostics (tests and tools report the re-run rate). */
+int  trxhip_fast_stats(trxhip_ctx *ctx, uint64_t *out4, int reset);
 
 /* ---- table blob: generated once on rank 0, broadcast to the other ranks (RCCL), adopted there ---- */
 size_t trxhip_tables_size(void);                                      /* bytes of the device table blob */

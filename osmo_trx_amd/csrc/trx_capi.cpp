@@ -3,6 +3,7 @@
 // device is usable trxhip_create() fails with TRXHIP_ENODEV and nothing else can be called.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -52,6 +53,8 @@ extern "C" int trx_launch_vector_slicer(float *d_dst, const float *d_src, size_t
 #define TRXHIP_FLAG_DIAG_MASK 0x7fffff00   /* phase-ablation bits of the -DTRX_DIAG profiling build (tools/) */
 #define TRXHIP_IFLAG_NO_UNIT  0x40         /* internal: see trx_device.h */
 #define TRXHIP_IFLAG_NO_SYM   0x80
+#define TRXHIP_IFLAG_NO_FAST  0x20
+extern "C" int trx_fast_stats_read(unsigned long long *out4, int reset);   /* trx_kernel4.hip */
 
 extern "C" {
 
@@ -129,6 +132,20 @@ int trxhip_create_from_tables(trxhip_ctx **out, int device, const void *h_blob, 
 	for (int k = 0; k < 8; k++)
 		if (memcmp(&t->dec_taps[k], &t->dec_taps[15 - k], sizeof(float)) != 0)
 			ctx->no_sym = 1;
+	/* the FAST detector's margin assumes sum_u |w_u| <= 2.6 for the 16 sinc weights of every fractional position
+	 * (trx_device.h, TRX_FAST_W): taps i <= fl use q = 512 k + f, taps i > fl use q = 512 k + (512 - f), k = 0 .. 7 */
+	ctx->no_fast = 0;
+	for (int f = 0; f < 512 && !ctx->no_fast; f++) {
+		double sum = 0.0;
+		for (int k = 0; k < 8; k++) {
+			const int qa = 512 * k + f, qb = 512 * k + (512 - f);
+			sum += fabs((double)t->sincv[trx_sincv_swz(qa)]);
+			if (qb < TRX_SINCV_LEN)
+				sum += fabs((double)t->sincv[trx_sincv_swz(qb)]);
+		}
+		if (!(sum <= 2.6))
+			ctx->no_fast = 1;
+	}
 	if (hipMalloc(reinterpret_cast<void **>(&ctx->d_tables), sizeof(trx_tables)) != hipSuccess) {
 		delete ctx;
 		return TRXHIP_ENOMEM;
@@ -177,6 +194,20 @@ int trxhip_set_work_pool(trxhip_ctx *ctx, int enabled)
 	return TRXHIP_OK;
 }
 
+int trxhip_fast_stats(trxhip_ctx *ctx, uint64_t *out4, int reset)
+{
+	if (!ctx || !out4)
+		return TRXHIP_EINVAL;
+	if (with_device(ctx))
+		return TRXHIP_EIO;
+	unsigned long long v[4] = { 0, 0, 0, 0 };
+	if (trx_fast_stats_read(v, reset) != 0)
+		return TRXHIP_EIO;
+	for (int k = 0; k < 4; k++)
+		out4[k] = v[k];
+	return TRXHIP_OK;
+}
+
 int trxhip_tables_device_ptr(trxhip_ctx *ctx, void **d_blob)
 {
 	if (!ctx || !d_blob)
@@ -212,6 +243,8 @@ static int pull_common(trxhip_ctx *ctx, const void *d_iq, int cf32, const trxhip
 		flags |= TRXHIP_IFLAG_NO_UNIT;
 	if (ctx->no_sym)
 		flags |= TRXHIP_IFLAG_NO_SYM;
+	if (ctx->no_fast)
+		flags |= TRXHIP_IFLAG_NO_FAST;
 	/* a zeroed pool counter for this launch (the kernel ignores it for small batches) */
 	unsigned *pool = nullptr;
 	if (ctx->d_pool && ctx->pool_enabled && n_bursts >= (size_t)ctx->n_cu * 128) {

@@ -13,6 +13,7 @@ struct trxhip_ctx {
 	int no_unit;        /* tables do not have the compiled-in unit structure: keep the multiplying correlation */
 	int sch_unit;       /* the SCH sequence has the unit structure the kernel's compiled-in mask expects (trx_sch.hip) */
 	int no_sym;         /* decimator taps not bitwise symmetric: the kernels' straight-line paths (mirrored taps) are off */
+	int no_fast;        /* sinc LUT row sums above TRX_FAST_W: the fused kernels' FAST detector (proven margins) is off */
 	/* cross-die work pool of the 4-SPS kernel (trx_kernel4.hip): one 64-byte counter PER STREAM.  Launches on one stream
 	 * run in order, so the hipMemsetAsync in front of a launch can never zero a counter an earlier launch still draws
 	 * from; launches on different streams never share one (round 3 handed the slots out round-robin per launch: launch i

@@ -333,6 +333,7 @@ __device__ __forceinline__ float norm2(c32 v) { return v.y * v.y + v.x * v.x; }
 #define TRX_UNIT_RATIO_LOG2 17
 #define TRX_IFLAG_NO_UNIT 0x40      // bit of the kernels' `slice` argument set by the C ABI when the tables lack the unit structure
 #define TRX_IFLAG_NO_SYM  0x80      // ... when the /4 decimator's taps are not bitwise symmetric (g[k] == g[15-k]): no straight-line paths
+#define TRX_IFLAG_NO_FAST 0x20      // ... when the sinc LUT's absolute row sums exceed TRX_FAST_W (the FAST detector's proven margin): exact TOA search
 // bit k set: the +-1 component of tap k is -1 (from the generated tables; tests/test_capi_cpu.py pins them)
 #define TRX_UNIT_NEG_TSC0   0x447bull
 #define TRX_UNIT_NEG_TSC1   0xc5bbull
@@ -647,6 +648,164 @@ __device__ __forceinline__ void peak_detect_spec(const c32 *cz, int max_idx, con
 }
 
 // ------------------------------------------------------------------------------------------------
+// The FAST detector of the fused 4-SPS kernels (round 5): the two interpolation rounds of the TOA bisection with FMA --
+// 16 v_pk_fma_f32 per round instead of 16 v_pk_mul_f32 + 16 v_pk_add_f32 -- and every early / late decision certified by a
+// PROVEN margin; a burst with an uncertified decision on its path re-runs peak_detect_spec() in the reference's operand order.
+// rc and TOA are therefore identical to the reference's by construction; the interpolated peak value (-> amp, C/I) differs
+// from the reference's by the rounding of one 16-term sum (TRXHIP_FAST_AMP_RTOL, include/trxhip.h).
+//
+// The bound.  u = 2^-24.  Per component, the reference's sum s = fl(s + fl(c w)) is within gamma_16 * sum |c_u| |w_u| of the true
+// sum (a term passes through at most 16 roundings); the FMA sum -- two chains of eight, s = fl(s + c w), joined by one addition --
+// within gamma_9 * sum |c_u| |w_u|;  gamma_n < 1.0001 n u.  Every correlation sample the interpolation reads has
+// |c_u|^2 <= m, the arg-max power (the zero pads included), and sum_u |w_u| <= W = 2.6 over all 512 fractional positions
+// (TRX_FAST_W; the sinc LUT's maximum is 2.573, checked when the context is created).  So per component
+//     |p_fma - p_ref| <= e1 = 25.003 u * 2.6 * sqrt(m) < 3.88e-6 sqrt(m),
+// and for the powers N = |p|^2:
+//     |N_fma - N_ref| <= |p_fma - p_ref| (|p_fma| + |p_ref|) <= sqrt(2) e1 (2 sqrt(N_fma) + sqrt(2) e1)
+//                     <= sqrt(2) * 3.88e-6 * (m + N_fma) + 3.1e-11 m                 (2 sqrt(m N) <= m + N).
+// norm2() rounds three times: the computed nv is within 2.0001 u N of N on both sides.  Together
+//     |nv_ref - nv_fma| <= 5.75e-6 * (m + nv_fma)   and the kernel uses   r = TRX_FAST_KAPPA * (nv_fma + m), KAPPA = 6e-6
+// (the 2.5e-7 (m + nv) of slack covers the roundings of r, nv - r, nv + r themselves): nv_ref lies in [nv - r, nv + r].
+// "early < late" is certain when  nv_E + r_E < nv_L - r_L,  "early > late" when  nv_L + r_L < nv_E - r_E  -- one compare
+// per lane of its own upper bound with its neighbour's lower bound gives both (even lanes: the first, odd lanes: the second).
+// ------------------------------------------------------------------------------------------------
+#define TRX_FAST_W      2.6f
+#define TRX_FAST_KAPPA  6e-6f
+// [0]: bursts whose TOA search was re-run in the reference's operand order since the last reset (one atomic per such burst,
+// in the cold path; read through trxhip_fast_stats()).  One copy per translation unit; only trx_kernel4.hip's is ever written.
+static __device__ unsigned long long g_trx_fast_stats[4];
+
+__device__ __forceinline__ trx_v2f pk_fma_w(trx_v2f x, float w, trx_v2f acc)
+{
+	// acc += x * w, w broadcast from the low half of its register pair (the high half is never read)
+	return __builtin_elementwise_fma(x, (trx_v2f){ w, w }, acc);
+}
+
+// Two chains (even / odd taps) joined by one addition: a dependent v_pk_fma_f32 needs a wait state behind its predecessor,
+// two independent ones do not -- and a term then passes through at most 9 roundings, not 16.  The sixteen taps run as two
+// blocks of eight reads + eight FMAs (the empty volatile asm between them pins the order: with all sixteen samples and
+// weights in flight the kernel needs 48 registers here and spills elsewhere).
+__device__ __forceinline__ c32 interp_taps_fma(const c32 *c, const float *sa, const float *sb)
+{
+	typedef const volatile trx_v2f __attribute__((address_space(3))) *lds_ptr;
+	lds_ptr cp = (lds_ptr)c;
+	asm("" : "+v"(cp));
+	trx_v2f p0 = { 0.0f, 0.0f }, p1 = { 0.0f, 0.0f };
+#pragma unroll
+	for (int h = 0; h < 2; h++) {
+		trx_v2f x[8];
+		float w[8];
+#pragma unroll
+		for (int u = 0; u < 8; u++) {
+			x[u] = cp[8 * h + u];
+			w[u] = h ? sb[512 * u] : sa[512 * (7 - u)];
+		}
+#pragma unroll
+		for (int u = 0; u < 8; u += 2) {
+			p0 = pk_fma_w(x[u], w[u], p0);
+			p1 = pk_fma_w(x[u + 1], w[u + 1], p1);
+		}
+		asm volatile("" : "+v"(p0), "+v"(p1));
+	}
+	const trx_v2f p = p0 + p1;
+	return make_float2(p.x, p.y);
+}
+
+// the same with the weights in an LDS table of float4: quad q of this lane at wq[64 q] (round A: functions of the lane only)
+__device__ __forceinline__ c32 interp_taps_w_fma(const c32 *c, const float4 *wq)
+{
+	typedef const volatile trx_v2f __attribute__((address_space(3))) *lds_ptr;
+	lds_ptr cp = (lds_ptr)c;
+	asm("" : "+v"(cp));
+	trx_v2f p0 = { 0.0f, 0.0f }, p1 = { 0.0f, 0.0f };
+#pragma unroll
+	for (int h = 0; h < 2; h++) {
+		trx_v2f x[8];
+		const float4 qa = wq[64 * (2 * h)], qb = wq[64 * (2 * h + 1)];
+#pragma unroll
+		for (int u = 0; u < 8; u++)
+			x[u] = cp[8 * h + u];
+#pragma unroll
+		for (int u = 0; u < 8; u += 2) {
+			const float4 q = (u & 4) ? qb : qa;
+			const trx_v2f hp = (u & 2) ? (trx_v2f){ q.z, q.w } : (trx_v2f){ q.x, q.y };
+			p0 = pk_fma_tap<0>(x[u], hp, p0);
+			p1 = pk_fma_tap<1>(x[u + 1], hp, p1);
+		}
+		asm volatile("" : "+v"(p0), "+v"(p1));
+	}
+	const trx_v2f p = p0 + p1;
+	return make_float2(p.x, p.y);
+}
+
+// walk_tree() on certified comparisons: lanes 2n / 2n+1 hold nv of heap node n's early / late position, km = KAPPA * m.
+// Returns the accumulated step; sets `unsure` when a node ON THE PATH has no certified decision (an exact tie included).
+template <int LEVELS>
+__device__ __forceinline__ int walk_tree_fast(float nv, float km, int inc0, bool &unsure)
+{
+	const float r = fmaf(nv, TRX_FAST_KAPPA, km);
+	const float lo = nv - r, hi = nv + r;
+	const float other_lo = dpp<DPP_QUAD_XOR1, 0xf>(lo);
+	const unsigned long long c = __ballot(hi < other_lo);          // even bits: early < late for sure; odd bits: early > late for sure
+	constexpr unsigned long long NODES = (LEVELS == 5) ? 0x1555555555555555ull : 0x15555555ull;
+	if (__builtin_expect(((c | (c >> 1)) & NODES) == NODES, 1)) {  // every node of the tree decided: the three-instruction walk
+		unsigned p = 0, pos;
+#pragma unroll
+		for (int Lw = 0; Lw < LEVELS; Lw++)
+			asm volatile("s_lshl1_add_u32 %1, %0, %3\n\t"
+				     "s_bitcmp1_b64 %2, %1\n\t"
+				     "s_addc_u32 %0, %0, %0"
+				     : "+s"(p), "=&s"(pos) : "s"(c), "n"(2 * ((1 << Lw) - 1)) : "scc");
+		const int s_last = inc0 >> (LEVELS - 1);
+		return 2 * s_last * (int)p - (2 * inc0 - s_last);
+	}
+	// some node undecided: only those on the path matter
+	unsigned node = 0;
+	int off = 0;
+#pragma unroll
+	for (int Lw = 0; Lw < LEVELS; Lw++) {
+		const unsigned bit = 2u * node;
+		const unsigned l = (unsigned)(c >> bit) & 1u, g = (unsigned)(c >> (bit + 1u)) & 1u;
+		if (!(l | g))
+			unsure = true;
+		const int step = inc0 >> Lw;
+		off += l ? step : -step;
+		node = 2u * node + 1u + l;
+	}
+	return off;
+}
+
+// peak_detect_spec() with FMA sums; *unsure: a decision on the path is not certified (the caller re-runs the exact one)
+//   wa4: round A's weight table (see peak_detect_spec); every caller of the FAST detector has one
+__device__ __forceinline__ void peak_detect_fast(const c32 *cz, int max_idx, float m, const float *sincv, const PeakConst &pc,
+						  int lane, int *toa512_out, c32 *val_out, const float4 *wa4, bool *unsure_out)
+{
+	int E = (max_idx - 1) * 512;
+	bool unsure = false;
+	const float km = TRX_FAST_KAPPA * m;
+	{
+		const c32 *const ca = cz + ((max_idx - 1) + pc.flA - 7);
+		const float nv = norm2(interp_taps_w_fma(ca, wa4 + lane));
+		E += walk_tree_fast<5>(nv, km, 256, unsure);
+	}
+	c32 val = make_float2(0.0f, 0.0f);
+	int final_ix = E + 512;
+	if (!unsure) {
+		const int ixb = E + pc.offB;
+		const c32 pv = interp_taps_fma(cz + ((ixb >> 9) - 7), sincv + sinc_base_lo(ixb & 511), sincv + sinc_base_hi(ixb & 511));
+		const int offB = walk_tree_fast<4>(norm2(pv), km, 8, unsure);
+		E += offB;
+		final_ix = E + 512;
+		const int src = 32 + ((offB + 15) >> 1);
+		val.x = lane_val(pv.x, src);
+		val.y = lane_val(pv.y, src);
+	}
+	*toa512_out = final_ix;
+	*val_out = val;
+	*unsure_out = unsure;
+}
+
+// ------------------------------------------------------------------------------------------------
 // detectBurst() after fastPeakDetect (sigProcLib.cpp:1683-1708): edge gate, computePeakRatio gate, peakDetect,
 // computeCI, amp and toa.  One wave; `bidx` is the wave-uniform index of the first strict maximum of |corr|^2.
 //   cz     : correlation with TRX_CZ_PAD zeros either side; only cz[bidx-12 .. bidx+12] is read, so a caller
@@ -658,7 +817,7 @@ __device__ __forceinline__ void peak_detect_spec(const c32 *cz, int max_idx, con
 //   on_toa : called with the refined position (1/512 symbol units, before "- sync->toa" and "- head") as soon as peakDetect
 //            has it -- the 4-SPS kernel starts fetching what its demodulator needs for that TOA behind computeCI
 struct NoToaHook { __device__ __forceinline__ void operator()(int) const {} };
-template <typename Hook>
+template <bool FAST, typename Hook>
 __device__ __forceinline__ int detect_tail_h(const c32 *sig, int sig_len, c32 *cz, const float *hdr, int N, float thresh,
 					      int start, int len, int bidx, const float *sincv, const PeakConst &pc, int lane,
 					      float *toa_out, c32 *amp_out, float *ci_out, Hook on_toa, const float4 *wa4, int slice DIAG_ARG WI_ARG)
@@ -675,12 +834,28 @@ __device__ __forceinline__ int detect_tail_h(const c32 *sig, int sig_len, c32 *c
 	if (!WI_SKIP) {
 		// lane k (mod 8) squares the k-th term of the reference's loop (peak-2, peak+2, peak-3, ... peak+5; out-of-range
 		// ones read the zero pads), a serial DPP scan adds them left to right: lane 7 holds the reference's avg
-		float acc = norm2(cz[bidx + pc.ratio_off]);
-		const float pwr = acc;
+		const float pwr = norm2(cz[bidx + pc.ratio_off]);
+		auto ordered_avg = [&]() {
+			float acc = pwr;
 #pragma unroll
-		for (int i = 1; i < 8; i++)
-			asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(pwr));
-		const float avg = lane_val(acc, 7);
+			for (int i = 1; i < 8; i++)
+				asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(pwr));
+			return lane_val(acc, 7);
+		};
+		float avg;
+		if (FAST) {
+			// FAST: the eight terms tree-summed inside their group of eight lanes (3 DPP steps instead of 7): within
+			// (7 + 3) u = 6e-7 of the ordered sum, which the estimate's margin below absorbs; the exactly rounded path
+			// behind the margin re-sums them in the reference's order
+			float acc = pwr;
+			asm volatile(TRX_DPP_STEP("v_add_f32_dpp", "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+				     TRX_DPP_STEP("v_add_f32_dpp", "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+				     TRX_DPP_STEP("v_add_f32_dpp", "row_half_mirror row_mask:0xf bank_mask:0xf")
+				     : "+v"(acc));
+			avg = lane_val(acc, 0);
+		} else {
+			avg = ordered_avg();
+		}
 		// number of in-range terms (:1555-1562).  The edge gate above left 3 <= bidx <= len - 3, so the four terms at
 		// distance 2 and 3 always exist except peak + 3 == len: 7 or 8 >= 5 ("num < 5: return 0" can never fire here)
 		// = 3 + (bidx + 3 < len) + (bidx >= 4) + (bidx + 4 < len) + (bidx >= 5) + (bidx + 5 < len), as scalar min / add:
@@ -698,9 +873,12 @@ __device__ __forceinline__ int detect_tail_h(const c32 *sig, int sig_len, c32 *c
 		const float rms_e = __builtin_amdgcn_sqrtf(avg * rnum) + 0.00001f;
 		const float t_e = thresh * rms_e;
 		const float t2 = t_e * t_e;
-		if (amp2 < t2 * (1.0f - 8e-6f))
+		const float gm = FAST ? 1.2e-5f : 8e-6f;                   // (FAST: + the tree sum's 6e-7, with room)
+		if (amp2 < t2 * (1.0f - gm))
 			return 0;
-		if (!(amp2 > t2 * (1.0f + 8e-6f))) {
+		if (!(amp2 > t2 * (1.0f + gm))) {
+			if (FAST)
+				avg = ordered_avg();
 			const float rms = (float)((double)sqrtf(avg / (float)num) + 0.00001);
 			const float ratio = sqrtf(amp2) / rms;
 			if (ratio < thresh)
@@ -717,7 +895,17 @@ __device__ __forceinline__ int detect_tail_h(const c32 *sig, int sig_len, c32 *c
 		cz[len - 1] = make_float2(0.0f, 0.0f);
 	wave_sync();
 	if (ABL(1)) { toa512 = bidx * 512; xcorr = amp0; }
-	else
+	else if (FAST && !(slice & TRX_IFLAG_NO_FAST)) {
+		// FMA sums, decisions certified against m = |corr[bidx]|^2 (no correlation sample is larger); the exact search
+		// only for the bursts with an uncertified decision on their path
+		bool unsure;
+		peak_detect_fast(cz, bidx, norm2(amp0), sincv, pc, lane, &toa512, &xcorr, wa4, &unsure);
+		if (unsure) {
+			if (lane == 0)
+				atomicAdd(&g_trx_fast_stats[0], 1ull);
+			peak_detect_spec(cz, bidx, sincv, pc, lane, &toa512, &xcorr, wa4);
+		}
+	} else
 		peak_detect_spec(cz, bidx, sincv, pc, lane, &toa512, &xcorr, wa4);
 	toa512 = uni(toa512);
 	xcorr.x = unif(xcorr.x);
@@ -739,24 +927,41 @@ __device__ __forceinline__ int detect_tail_h(const c32 *sig, int sig_len, c32 *c
 			// lane N-1 ends with the reference's S (one DPP add per term instead of a readlane + add)
 			float acc = pw;
 #define TRX_SCAN_STEP asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(pw))
-			if (N == 16) {                                   // normal bursts: straight-line
-#pragma unroll
-				for (int i = 1; i < 16; i++)
-					TRX_SCAN_STEP;
+			float S;
+			if (FAST) {
+				// FAST: C/I is a tolerance quantity already (C is an FMA sum), so S is tree-summed: 4 DPP steps over the
+				// first row of lanes (N = 16), the wave tree over the first N lanes otherwise (access bursts: 6 steps for 39)
+				if (N == 16) {
+					S = lane_val(row_sum(pw), 0);
+				} else {
+					S = wave_sum(lane < N ? pw : 0.0f);
+				}
 			} else {
-				for (int i = 1; i < N; i++)
-					TRX_SCAN_STEP;
+				if (N == 16) {                                   // normal bursts: straight-line
+#pragma unroll
+					for (int i = 1; i < 16; i++)
+						TRX_SCAN_STEP;
+				} else {
+					for (int i = 1; i < N; i++)
+						TRX_SCAN_STEP;
+				}
+				S = lane_val(acc, N - 1);
 			}
 #undef TRX_SCAN_STEP
-			float S = lane_val(acc, N - 1);
 			// S - C cancels (by a factor C/I), so S and C themselves must round as the reference's do; only the last
 			// quotient and the log may be approximate (2 ulp, hardware log2).  a / b with a correctly rounded
 			// reciprocal y of b: q = a*y, r = fma(-q, b, a), q' = fma(r, y, q) is the correctly rounded quotient
 			// (Markstein) -- three instructions instead of an IEEE division sequence.
 			auto div_y = [](float a, float b, float y) { const float q = a * y; return fmaf(fmaf(-q, b, a), y, q); };
-			if (N == 40) S = div_y(S, 40.0f, 0.025f);        // S /= N (:1631); 1/16 and 1/64 are exact
-			else S *= (N == 16) ? 0.0625f : 0.015625f;
-			const float C = div_y(norm2(xcorr), hdr[4], hdr[7]);   // / ((N-1)*|gain|) (:1633), table: ci_den and RN(1/ci_den)
+			float C;
+			if (FAST) {                                   // tolerance quantities: one rounding each instead of the exact quotients
+				S *= (N == 40) ? 0.025f : (N == 16) ? 0.0625f : 0.015625f;
+				C = norm2(xcorr) * hdr[7];
+			} else {
+				if (N == 40) S = div_y(S, 40.0f, 0.025f);        // S /= N (:1631); 1/16 and 1/64 are exact
+				else S *= (N == 16) ? 0.0625f : 0.015625f;
+				C = div_y(norm2(xcorr), hdr[4], hdr[7]);         // / ((N-1)*|gain|) (:1633), table: ci_den and RN(1/ci_den)
+			}
 			ci = 3.0103f * __log2f(C * __builtin_amdgcn_rcpf(S - C));
 		}
 	}
@@ -774,8 +979,8 @@ __device__ __forceinline__ int detect_tail(const c32 *sig, int sig_len, c32 *cz,
 					    float *toa_out, c32 *amp_out, float *ci_out, int slice DIAG_ARG)
 {
 	WI_LOCAL;
-	return detect_tail_h(sig, sig_len, cz, hdr, N, thresh, start, len, bidx, sincv, pc, lane, toa_out, amp_out, ci_out,
-			     NoToaHook(), nullptr, slice DIAG_PASS WI_PASS);
+	return detect_tail_h<false>(sig, sig_len, cz, hdr, N, thresh, start, len, bidx, sincv, pc, lane, toa_out, amp_out, ci_out,
+				    NoToaHook(), nullptr, slice DIAG_PASS WI_PASS);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -789,15 +994,16 @@ __device__ __forceinline__ int detect_tail(const c32 *sig, int sig_len, c32 *cz,
 //           recomputed for the tail, exactly as the SCH buffer search does (trx_sch.hip)
 //   unit_slot >= 0: the sequence is the GMSK one of that LDS slot and every sample the window reads passed
 //           unit_unsafe(): correlate with corr_unit() (additions only, same bits); < 0: multiply as written
-template <bool PADDED, bool NARROW, typename Hook>
+//   FAST  : the TOA search with FMA sums and certified decisions (peak_detect_fast); amp and C/I are then tolerance quantities
+template <bool PADDED, bool NARROW, bool FAST, typename Hook>
 __device__ __forceinline__ int detect_burst_h(const c32 *sig, int sig_len, c32 *cz, const c32 *taps, const float *hdr,
 					       int N, float thresh, int start, int len, const float *sincv, const PeakConst &pc, int lane,
 					       float *toa_out, c32 *amp_out, float *ci_out, Hook on_toa, const float4 *wa4, int slice, int unit_slot DIAG_ARG WI_ARG)
 {
 #ifdef TRX_WHATIF_PAIR
 	if (wi.skip)                                     // the neighbour's pass "already" correlated and gated this burst
-		return detect_tail_h(sig, sig_len, cz, hdr, N, thresh, start, len, wi.bidx, sincv, pc, lane, toa_out, amp_out, ci_out,
-				     on_toa, wa4, slice DIAG_PASS WI_PASS);
+		return detect_tail_h<FAST>(sig, sig_len, cz, hdr, N, thresh, start, len, wi.bidx, sincv, pc, lane, toa_out, amp_out, ci_out,
+					   on_toa, wa4, slice DIAG_PASS WI_PASS);
 #endif
 	const bool wide = NARROW && (len > TRX_CORR_NARROW || start + len > TRX_DEC_NARROW);
 	// corr[i] with range-checked reads, taps in order (cold: wide windows only)
@@ -924,8 +1130,8 @@ __device__ __forceinline__ int detect_burst_h(const c32 *sig, int sig_len, c32 *
 #ifdef TRX_WHATIF_PAIR
 	wi.bidx = (bidx < 3) ? 3 : (bidx > len - 3 ? len - 3 : bidx);
 #endif
-	const int r = detect_tail_h(sig, sig_len, czp, hdr, N, thresh, start, len, bidx, sincv, pc, lane, toa_out, amp_out, ci_out,
-				    on_toa, wa4, slice DIAG_PASS WI_PASS);
+	const int r = detect_tail_h<FAST>(sig, sig_len, czp, hdr, N, thresh, start, len, bidx, sincv, pc, lane, toa_out, amp_out, ci_out,
+					  on_toa, wa4, slice DIAG_PASS WI_PASS);
 	if (wide) {
 		wave_sync();
 		if (lane < TRX_CZ_PAD)
@@ -940,8 +1146,8 @@ __device__ __forceinline__ int detect_burst(const c32 *sig, int sig_len, c32 *cz
 					     float *toa_out, c32 *amp_out, float *ci_out, int slice, int unit_slot DIAG_ARG)
 {
 	WI_LOCAL;
-	return detect_burst_h<PADDED, NARROW>(sig, sig_len, cz, taps, hdr, N, thresh, start, len, sincv, pc, lane, toa_out, amp_out,
-					      ci_out, NoToaHook(), nullptr, slice, unit_slot DIAG_PASS WI_PASS);
+	return detect_burst_h<PADDED, NARROW, false>(sig, sig_len, cz, taps, hdr, N, thresh, start, len, sincv, pc, lane, toa_out, amp_out,
+						     ci_out, NoToaHook(), nullptr, slice, unit_slot DIAG_PASS WI_PASS);
 }
 
 

@@ -133,6 +133,9 @@ __device__ __forceinline__ void fir24x3(const PhBase &pb, const float4 *c4, v2f 
 // schedule interleaves reads and waits with 2-5 reads in flight and exposes the LDS latency six times -- and the taps come as
 // g[0..7] only (two 16-byte broadcast reads): the filter is bitwise symmetric, g[k] == g[15-k] (checked when the context
 // is created; TRX_IFLAG_NO_SYM otherwise keeps callers on the generic path).
+//   FROM_P0: start the sum at the first product instead of adding it to +0 (one instruction less; differs from the reference
+//   only in the sign of a zero result when every product is -0: the fused kernels take it, the bit-exact ones do not)
+template <bool FROM_P0 = false>
 __device__ __forceinline__ c32 decimate16_sym(const c32 *pd, const float *gdec)
 {
 	const float4 *g4 = reinterpret_cast<const float4 *>(gdec);
@@ -142,14 +145,34 @@ __device__ __forceinline__ c32 decimate16_sym(const c32 *pd, const float *gdec)
 		xs[k] = lds_c32(pd + ((k + 1) & 3) * PH_A + ((k + 1) >> 2));
 	const float4 gA = g4[0], gB = g4[1];
 	__builtin_amdgcn_sched_barrier(0);
-	v2f ya = { 0.0f, 0.0f };
-#pragma unroll
-	for (int k = 0; k < 16; k++) {
+	// product k + 1 is issued between sum k - 1 and sum k: a v_pk_add_f32 straight behind the v_pk_add_f32 it depends on costs
+	// a wait state each time (the compiler's order -- sixteen products, then sixteen sums -- paid fifteen s_nop)
+	auto prod = [&](int k) {
 		const int kk = k < 8 ? k : 15 - k;
 		const float4 gq = (kk >> 2) ? gB : gA;
 		const v2f gp = (kk & 2) ? (v2f){ gq.z, gq.w } : (v2f){ gq.x, gq.y };
 		const v2f xv = { xs[k].x, xs[k].y };
-		ya = ya + ((kk & 1) ? pk_mul_tap<1>(xv, gp) : pk_mul_tap<0>(xv, gp));
+		v2f r;
+		if (kk & 1)
+			asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(xv), "v"(gp));
+		else
+			asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(r) : "v"(xv), "v"(gp));
+		return r;
+	};
+	v2f p_cur = prod(0), p_next = prod(1);
+	v2f ya;
+	if (FROM_P0) {
+		ya = p_cur;
+	} else {
+		ya = (v2f){ 0.0f, 0.0f };
+		asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(ya) : "v"(p_cur));
+	}
+#pragma unroll
+	for (int k = 1; k < 16; k++) {
+		p_cur = p_next;
+		if (k + 1 < 16)
+			p_next = prod(k + 1);
+		asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(ya) : "v"(p_cur));
 	}
 	return make_float2(ya.x, ya.y);
 }
@@ -379,7 +402,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 				if (r < 2) {
 					sp[r * WAVE] = sv;
 				} else {
-					sv = (i < pend_nwrite) ? sv : 0.0f;
+					sv = (i < (COMMON ? 148 : pend_nwrite)) ? sv : 0.0f;   // (COMMON: GMSK rows only, vectorSlicer on)
 					if (i < soft_stride)
 						sp[2 * WAVE] = sv;
 				}
@@ -463,8 +486,13 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 			idle = 0;
 			// park the low-edge rows: lane l < 48 holds floats 4l .. 4l+3 of the 8 x 24 block
 			float *const stage = reinterpret_cast<float *>(dec);
+#ifdef TRX_WHATIF_NOFETCHWAIT   /* timing only (tools/): what the wait for the edge8 rows costs -- the rows are not used */
+			if (lane < 48)
+				*reinterpret_cast<float4 *>(stage + 4 * lane) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#else
 			if (lane < 48)
 				*reinterpret_cast<float4 *>(stage + 4 * lane) = fast_rows;
+#endif
 			wave_sync();
 			// lanes 0..49: outputs 3l .. 3l+2 with the burst's composite row; lanes 52..55: output l - 52, main part of its
 			// truncated row; lanes 56..59: the same outputs' taps u < 8 (window 8 samples = 2 outputs earlier); the rest idle
@@ -588,7 +616,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 					const int len = 16 + max_toa;
 					__builtin_assume(len >= 16 && len <= 49);
 					{
-						const c32 y = decimate16_sym(P + PH_M0 + (56 + lane) - 4, gdec);
+						const c32 y = decimate16_sym<!EXACT>(P + PH_M0 + (56 + lane) - 4, gdec);
 						dec[56 + lane] = y;
 						unit_bad |= (__ballot(unit_unsafe(y) && lane < 15 + len) != 0ull) ? 1 : 0;
 						wave_sync();
@@ -601,7 +629,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 #ifdef TRX_WHATIF_PAIR
 					wi.skip ^= 1;
 #endif
-					const int hit = detect_burst_h<true, true>(dec, 156, cz, lseq + LSEQ_TSC(tsc), hdr, 16, thresh, 71, len, sincv,
+					const int hit = detect_burst_h<true, true, !EXACT>(dec, 156, cz, lseq + LSEQ_TSC(tsc), hdr, 16, thresh, 71, len, sincv,
 										   pkc, lane, &toa, &amp, &ci, on_toa, wa4, slice, unit_bad ? -1 : tsc DIAG_PASS WI_PASS);
 					wave_sync();
 					rc = hit ? TRXHIP_TSC : (clip ? -TRXHIP_SIGERR_CLIP : 0);                 // :1764, :1953-1954
@@ -617,14 +645,14 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 #pragma unroll
 					for (int r = 0; r < 2; r++) {
 						const int i = lane + r * WAVE;                          // < 128 <= TRX_DEC_NARROW
-						const c32 y = decimate16_sym(P + PH_M0 + i - 4, gdec);
+						const c32 y = decimate16_sym<!EXACT>(P + PH_M0 + i - 4, gdec);
 						dec[i] = y;
 						bad |= unit_unsafe(y) && i < 39 + len;
 					}
 					unit_bad |= (__ballot(bad) != 0ull) ? 1 : 0;
 					wave_sync();
 					DIAG_MARK(2);
-					int hit = detect_burst_h<true, true>(dec, 156, cz, lseq + LSEQ_RACH(0), lhdr + 8 * 8, 40, thresh, 39, len, sincv,
+					int hit = detect_burst_h<true, true, !EXACT>(dec, 156, cz, lseq + LSEQ_RACH(0), lhdr + 8 * 8, 40, thresh, 39, len, sincv,
 									     pkc, lane, &toa, &amp, &ci, NoToaHook(), wa4, slice, unit_bad ? -1 : 8 DIAG_PASS
 #ifdef TRX_WHATIF_PAIR
 									     , wi_full
@@ -635,7 +663,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 					if (!hit && type == TRXHIP_EXT_RACH) {
 						// extended access bursts: TS1, then TS2 over the same window, first hit wins (:1791-1800)
 						for (int c = 1; c < 3 && !hit; c++) {
-							hit = detect_burst_h<true, true>(dec, 156, cz, lseq + LSEQ_RACH(c), lhdr + 8 * (8 + c), 40, thresh, 39, len,
+							hit = detect_burst_h<true, true, !EXACT>(dec, 156, cz, lseq + LSEQ_RACH(c), lhdr + 8 * (8 + c), 40, thresh, 39, len,
 											 sincv, pkc, lane, &toa, &amp, &ci, NoToaHook(), wa4, slice, unit_bad ? -1 : 8 + c DIAG_PASS
 #ifdef TRX_WHATIF_PAIR
 											 , wi_full
@@ -655,13 +683,13 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 					const int len = 16 + max_toa;
 					__builtin_assume(len >= 16 && len <= 49);
 					{
-						const c32 y = decimate16_sym(P + PH_M0 + (56 + lane) - 4, gdec);
+						const c32 y = decimate16_sym<!EXACT>(P + PH_M0 + (56 + lane) - 4, gdec);
 						dec[56 + lane] = y;
 						unit_bad |= (__ballot(unit_unsafe(y) && lane < 15 + len) != 0ull) ? 1 : 0;
 						wave_sync();
 					}
 					DIAG_MARK(2);
-					int hit = detect_burst_h<true, true>(dec, 156, cz, lseq + LSEQ_EDGE(tsc), lhdr + 8 * (11 + tsc), 16, thresh, 75, len - 4,
+					int hit = detect_burst_h<true, true, !EXACT>(dec, 156, cz, lseq + LSEQ_EDGE(tsc), lhdr + 8 * (11 + tsc), 16, thresh, 75, len - 4,
 									     sincv, pkc, lane, &toa, &amp, &ci, NoToaHook(), wa4, slice, -1 DIAG_PASS
 #ifdef TRX_WHATIF_PAIR
 									     , wi_full
@@ -672,7 +700,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 						rc = TRXHIP_EDGE;                                                          // :1953-1954
 						toa -= 6.0f;                                                               // :1768
 					} else {
-						hit = detect_burst_h<true, true>(dec, 156, cz, lseq + LSEQ_TSC(tsc), lhdr + 8 * tsc, 16, thresh, 71, len, sincv,
+						hit = detect_burst_h<true, true, !EXACT>(dec, 156, cz, lseq + LSEQ_TSC(tsc), lhdr + 8 * tsc, 16, thresh, 71, len, sincv,
 										 pkc, lane, &toa, &amp, &ci, NoToaHook(), wa4, slice, unit_bad ? -1 : tsc DIAG_PASS
 #ifdef TRX_WHATIF_PAIR
 										 , wi_full
@@ -1117,6 +1145,19 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 	}
 	flush(lane);
 	DIAG_FLUSH();
+}
+
+// counters of the FAST detector on the current device (trx_device.h: g_trx_fast_stats); synchronises the device
+extern "C" int trx_fast_stats_read(unsigned long long *out4, int reset)
+{
+	if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_trx_fast_stats), 4 * sizeof(unsigned long long)) != hipSuccess)
+		return -1;
+	if (reset) {
+		const unsigned long long z[4] = { 0, 0, 0, 0 };
+		if (hipMemcpyToSymbol(HIP_SYMBOL(g_trx_fast_stats), z, sizeof(z)) != hipSuccess)
+			return -1;
+	}
+	return 0;
 }
 
 // the sign patterns compiled into corr_unit() against what the table generator derived from the taps (host side)

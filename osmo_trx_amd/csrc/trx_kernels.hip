@@ -248,7 +248,7 @@ burst_pull_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__res
 					const int len = 16 + max_toa;
 					const int unit_bad = (__ballot(unit_unsafe(xs[56 + lane]) && lane < 15 + len) != 0ull) ? 1 : 0;
 					const float *const hdr = lhdr + 8 * tsc;
-					const int hit = detect_burst_h<true, false>(xs, L, cz, lseq + LSEQ_TSC(tsc), hdr, 16, thresh, 71, len, sincv, pkc, lane,
+					const int hit = detect_burst_h<true, false, false>(xs, L, cz, lseq + LSEQ_TSC(tsc), hdr, 16, thresh, 71, len, sincv, pkc, lane,
 										    &d.toa, &d.amp, &d.ci, NoToaHook(), nullptr, slice, unit_bad ? -1 : tsc DIAG_PASS WI_1SPS);
 					wave_sync();
 					rc = hit ? TRXHIP_TSC : (clip ? -TRXHIP_SIGERR_CLIP : 0);                      // :1764, :1953-1954

@@ -49,6 +49,7 @@ SYMBOLS = {
     "trxhip_destroy": (None, [_VP]),
     "trxhip_strerror": (C.c_char_p, [_I]),
     "trxhip_set_work_pool": (_I, [_VP, _I]),
+    "trxhip_fast_stats": (_I, [_VP, C.POINTER(C.c_uint64), _I]),
     "trxhip_tables_size": (_SZ, []),
     "trxhip_tables_generate_host": (_I, [_VP, _SZ]),
     "trxhip_create_from_tables": (_I, [C.POINTER(_VP), _I, _VP, _SZ]),
@@ -103,6 +104,8 @@ def load_library():
     except OSError as e:  # pragma: no cover
         raise TrxHipError(f"cannot load {path}: {e}") from e
     for name, (res, args) in SYMBOLS.items():
+        if name == "trxhip_fast_stats" and os.environ.get("TRXHIP_LIB") and not hasattr(L, name):
+            continue          # tools/ab_multi.sh against an older measurement build of the library (product: always bound)
         f = getattr(L, name)  # AttributeError if the export is missing
         f.restype = res
         f.argtypes = args
@@ -183,6 +186,13 @@ class TrxHip:
     def set_work_pool(self, enabled):
         """Cross-die work pool of the 4-SPS kernel on / off (results never depend on it; a measurement switch)."""
         _check(self.L.trxhip_set_work_pool(self.h, 1 if enabled else 0), "trxhip_set_work_pool")
+
+    def fast_stats(self, reset=False):
+        """Counters of the fused kernels' FAST detector since the last reset: {"reruns": bursts whose TOA search was re-run in
+        the reference's operand order}.  Synchronises the device."""
+        out = (C.c_uint64 * 4)()
+        _check(self.L.trxhip_fast_stats(self.h, out, 1 if reset else 0), "trxhip_fast_stats")
+        return {"reruns": int(out[0])}
 
     def params_tensor(self, params_np):
         """PARAMS_DTYPE[n] numpy -> uint8[n, 8] device tensor."""

@@ -59,6 +59,27 @@ def build(force=False):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "ref"], stdout=subprocess.DEVNULL)
 
 
+def header_constant(name):
+    """A tolerance constant of include/trxhip.h (the statements live there and nowhere else)."""
+    import re
+    txt = open(os.path.join(ROOT, "include", "trxhip.h")).read()
+    return float(re.search(r"#define\s+" + name + r"\s+([0-9.eE+-]+)f?\b", txt).group(1))
+
+
+def fast_ci_bar(ci_ref):
+    """TRXHIP_FAST_CI_ATOL_DB(ci) of include/trxhip.h -- C/I of the fused kernels' FAST detector against the reference's:
+    S - C cancels by the factor 1 + C/I."""
+    return 1e-4 + 1.4e-5 * (1.0 + np.power(10.0, np.asarray(ci_ref, dtype=np.float64) * 0.1))
+
+
+def assert_fast_ci(ci, ci_ref):
+    """C/I of a fused-kernel result against the oracle's: same NaN pattern (S < C on a noise slot), inside the bar elsewhere."""
+    ci, ci_ref = np.asarray(ci, dtype=np.float64), np.asarray(ci_ref, dtype=np.float64)
+    nan = np.isnan(ci_ref)
+    assert np.array_equal(np.isnan(ci), nan)
+    assert (np.abs(ci - ci_ref)[~nan] <= fast_ci_bar(ci_ref[~nan])).all(), float((np.abs(ci - ci_ref)[~nan] / fast_ci_bar(ci_ref[~nan])).max())
+
+
 _lib = None
 
 

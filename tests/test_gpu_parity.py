@@ -35,15 +35,25 @@ def run_gpu(trx, iq, params, sps, soft_stride=148, slice_bits=True, exact=True, 
     return trx.results_to_numpy(res), soft.cpu().numpy()
 
 
-def header_constant(name):
-    """The tolerance statement lives in include/trxhip.h and nowhere else: read it from there."""
-    import re
-    txt = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "trxhip.h")).read()
-    return float(re.search(r"#define\s+" + name + r"\s+([0-9.eE+-]+)f?\b", txt).group(1))
+header_constant = O.header_constant
+fast_ci_bar = O.fast_ci_bar
+FAST_AMP_RTOL = header_constant("TRXHIP_FAST_AMP_RTOL")                 # fused kernels: amp against the reference's
 
 
 FUSED_SOFT_ATOL = header_constant("TRXHIP_FUSED_SOFT_ATOL")             # fused demodulator, GMSK soft bits (full scale 1)
 FUSED_SOFT_ATOL_8PSK = header_constant("TRXHIP_FUSED_SOFT_ATOL_8PSK")   # 8-PSK rows and the fuzz inputs
+
+
+def assert_same_detection(r, rx):
+    """Result records of the fused kernel (FAST detector) against the bit-exact kernel's (or the oracle's): rc, TSC, flags,
+    TOA, energy and RSSI bit for bit; amp and C/I inside the bars of include/trxhip.h."""
+    for f in ("rc", "tsc", "clip", "idle", "nbits_div4"):
+        assert np.array_equal(r[f], rx[f]), f
+    for f in ("toa", "energy", "rssi"):
+        assert np.array_equal(r[f], rx[f], equal_nan=True), f
+    aref = np.hypot(rx["amp_re"], rx["amp_im"])
+    assert (np.hypot(r["amp_re"] - rx["amp_re"], r["amp_im"] - rx["amp_im"]) <= FAST_AMP_RTOL * aref).all()
+    O.assert_fast_ci(r["ci"], rx["ci"])
 
 
 def check_parity(g_res, g_soft, o_res, o_soft, soft_atol=0.0):
@@ -54,8 +64,15 @@ def check_parity(g_res, g_soft, o_res, o_soft, soft_atol=0.0):
     10 bars of the decision threshold."""
     for f in ("rc", "tsc", "clip", "idle", "nbits_div4"):
         assert np.array_equal(g_res[f], o_res[f]), f
-    for f in ("toa", "amp_re", "amp_im"):
-        assert np.array_equal(g_res[f], o_res[f]), f
+    assert np.array_equal(g_res["toa"], o_res["toa"])                   # TOA: identical in both kernels
+    if soft_atol == 0.0:
+        for f in ("amp_re", "amp_im"):
+            assert np.array_equal(g_res[f], o_res[f]), f
+    else:
+        # fused kernels' FAST detector: the interpolated peak is an FMA sum (include/trxhip.h, TRXHIP_FAST_AMP_RTOL)
+        aref = np.hypot(o_res["amp_re"], o_res["amp_im"])
+        d = np.hypot(g_res["amp_re"] - o_res["amp_re"], g_res["amp_im"] - o_res["amp_im"])
+        assert (d <= FAST_AMP_RTOL * aref).all(), float((d / np.maximum(aref, 1e-30)).max())
     if soft_atol == 0.0:
         assert np.array_equal(g_soft, o_soft)
     else:
@@ -71,7 +88,12 @@ def check_parity(g_res, g_soft, o_res, o_soft, soft_atol=0.0):
     fin = np.isfinite(o_res["rssi"])
     np.testing.assert_allclose(g_res["rssi"][fin], o_res["rssi"][fin], rtol=0, atol=2e-5)
     assert np.array_equal(np.isfinite(g_res["rssi"]), fin)
-    np.testing.assert_allclose(g_res["ci"], o_res["ci"], rtol=0, atol=1e-4 if soft_atol else 2e-5)
+    if soft_atol:
+        nan = np.isnan(o_res["ci"])                                      # (S < C on a noise slot: log of a negative number, both sides)
+        assert np.array_equal(np.isnan(g_res["ci"]), nan)
+        assert (np.abs(g_res["ci"] - o_res["ci"])[~nan] <= fast_ci_bar(o_res["ci"][~nan])).all()
+    else:
+        np.testing.assert_allclose(g_res["ci"], o_res["ci"], rtol=0, atol=2e-5)
 
 
 def test_normal_bursts_4sps_all_tsc(trx):
@@ -246,7 +268,9 @@ def test_full_size_properties(trx):
     tsel = torch.from_numpy(sel).to("cuda:0")
     check_parity(r[sel], soft[tsel].cpu().numpy(), o_res, o_soft, soft_atol=FUSED_SOFT_ATOL)
     check_parity(trx.results_to_numpy(res_x)[sel], soft_x[tsel].cpu().numpy(), o_res, o_soft)
-    assert torch.equal(res, res_x)                                       # detection identical in both modes
+    # detection decisions identical in both kernels over the whole batch: rc, TSC, flags and TOA bit for bit; amp and C/I
+    # of the fused kernel (FAST detector) within the header's bars of the bit-exact kernel's
+    assert_same_detection(r, trx.results_to_numpy(res_x))
     assert float((soft - soft_x).abs().max()) <= FUSED_SOFT_ATOL
 
 
@@ -505,7 +529,8 @@ def test_full_size_mixed(trx):
     assert -7.6 < r["toa"][det & ~is_rach].min() and r["toa"][det & ~is_rach].max() < 6.6
     assert -5.6 < r["toa"][det & is_rach].min() and r["toa"][det & is_rach].max() < 68.6
     assert np.median(r["toa"][det & ~is_rach]) < 4.0 and 20.0 < np.median(r["toa"][det & is_rach]) < 45.0
-    assert torch.equal(res, res_x) and float((soft - soft_x).abs().max()) <= FUSED_SOFT_ATOL
+    assert_same_detection(r, trx.results_to_numpy(res_x))
+    assert float((soft - soft_x).abs().max()) <= FUSED_SOFT_ATOL
     # position independence: an unaligned slice processed alone (different wave <-> burst assignment)
     sl = slice(123_457, 123_457 + 8191)
     res2, soft2 = trx.detect_demod(iq[sl].contiguous(), d_p[sl].contiguous(), sps=4)
@@ -614,3 +639,74 @@ def test_cross_die_pool_equals_static_split(trx):
     torch.cuda.synchronize()
     for r, so in outs:
         assert torch.equal(r, ref_res[:n]) and torch.equal(so.view(torch.int32), ref_soft[:n].view(torch.int32))
+
+
+def _oracle_threaded(iq_np, params, threads):
+    """O.pull_batch over contiguous slices on `threads` host threads (ctypes releases the GIL; bursts are independent)."""
+    from concurrent.futures import ThreadPoolExecutor
+    n = len(iq_np)
+    edges = np.linspace(0, n, threads + 1).astype(int)
+    with ThreadPoolExecutor(threads) as ex:
+        parts = list(ex.map(lambda k: O.pull_batch(iq_np[edges[k]:edges[k + 1]], 4, params[edges[k]:edges[k + 1]]), range(threads)))
+    return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+
+
+def test_fast_detector_campaign_against_oracle(trx, capsys):
+    """Round 5's FAST detector (fused kernels: FMA interpolation rounds, tree-summed gate / C/I terms, every early / late
+    decision certified by a proven margin or re-run in the reference's operand order): over 4M normal bursts, 1M access bursts
+    and the fuzz set, rc / TSC / flags / TOA must be IDENTICAL to the oracle's, amp and C/I inside the header's bars; the
+    re-run rate is reported (profiles/r05_fast_campaign.txt holds the 1M-per-workload table of tools/fast_detect_report.py)."""
+    from osmo_trx_amd import synth
+    import bench
+    threads = max(1, min(32, bench.usable_cores()))
+    n = 1 << 20
+    O.lib()
+    total = reruns = detected = 0
+    worst_amp = worst_ci = 0.0
+    loads = [("nb", k) for k in range(4)] + [("rach", 0)]
+    for wl, k in loads:
+        if wl == "nb":
+            iq, params, _ = synth.make_normal_bursts(n, "cuda:0", 4, seed=synth.SEED + 104729 * (k + 1))
+        else:
+            iq, params, _ = synth.make_access_bursts(n, "cuda:0", seed=synth.SEED + 15485863)
+        dp = trx.params_tensor(params)
+        trx.fast_stats(reset=True)
+        res, soft = trx.detect_demod(iq, dp, sps=4, exact=False)
+        st = trx.fast_stats(reset=True)
+        g = trx.results_to_numpy(res)
+        o_res, o_soft = _oracle_threaded(iq.cpu().numpy(), params, threads)
+        for f in ("rc", "tsc", "clip", "idle", "nbits_div4", "toa"):
+            assert np.array_equal(g[f], o_res[f]), (wl, k, f)
+        det = o_res["rc"] > 0
+        aref = np.hypot(o_res["amp_re"], o_res["amp_im"])
+        d = np.hypot(g["amp_re"] - o_res["amp_re"], g["amp_im"] - o_res["amp_im"])
+        assert (d <= FAST_AMP_RTOL * aref).all()
+        ok = det & ~np.isnan(o_res["ci"])
+        assert np.array_equal(np.isnan(g["ci"]), np.isnan(o_res["ci"]))
+        cie = np.abs(g["ci"] - o_res["ci"])[ok]
+        assert (cie <= fast_ci_bar(o_res["ci"][ok])).all()
+        worst_amp = max(worst_amp, float((d[det] / aref[det]).max()))
+        worst_ci = max(worst_ci, float((cie / fast_ci_bar(o_res["ci"][ok])).max()))
+        total += n
+        reruns += st["reruns"]
+        detected += int(det.sum())
+        del iq, res, soft, o_soft
+    # the fuzz set (random slot types, invalid TSCs, all window sizes, silence / saturation / impulses): decisions identical
+    rng = np.random.default_rng(20261003)
+    iq, params = _fuzz_batch(4096, 625, rng)
+    o_res, _ = O.pull_batch(iq.numpy(), 4, params)
+    big = (params["max_toa"] > 112) & ~np.isin(params["type"], [O.OFF, O.IDLE, O.SCH, 9]) & \
+        ~((params["tsc"] > 7) & np.isin(params["type"], [O.TSC, O.EDGE]))
+    trx.fast_stats(reset=True)
+    g, _ = run_gpu(trx, iq, params, 4, exact=False)
+    st = trx.fast_stats(reset=True)
+    for f in ("rc", "tsc", "clip", "idle", "nbits_div4", "toa"):
+        assert np.array_equal(g[f][~big], o_res[f][~big]), ("fuzz", f)
+    total += len(params)
+    reruns += st["reruns"]
+    rate = reruns / max(1, detected)
+    with capsys.disabled():
+        print(f"\n[fast detector] {total} bursts, {detected} detected (without the fuzz set): rc / TSC / TOA identical to the oracle; "
+              f"{reruns} TOA searches re-run in the reference's operand order ({rate:.3%} of detected); "
+              f"max amp error {worst_amp:.2e} relative (bar {FAST_AMP_RTOL:g}), max C/I error {worst_ci:.3f} of its bar")
+    assert rate < 0.02

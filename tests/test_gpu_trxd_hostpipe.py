@@ -328,7 +328,10 @@ def test_pull_radio_vector_adapter_against_the_oracle_chain(trx, tmp_path):
                 if not bi.idle:
                     n_det += 1
                     assert r["toa"] == bi.toa and r["tsc"] == bi.tsc, i
-                    assert abs(r["ci"] - bi.ci) <= 2e-5
+                    if exact:
+                        assert abs(r["ci"] - bi.ci) <= 2e-5
+                    else:                                                   # fused kernel: FAST detector (include/trxhip.h)
+                        assert (np.isnan(bi.ci) and np.isnan(r["ci"])) or abs(r["ci"] - bi.ci) <= float(O.fast_ci_bar(bi.ci))
                     ref_row = np.frombuffer(bi.rx_burst, dtype=np.float32)[:148]
                     if exact:
                         assert np.array_equal(r["rx"][:148], ref_row), i
@@ -361,11 +364,24 @@ def wire_byte_mismatch(trx, iq, params, oracle_soft=None):
     res_f, soft_f = trx.detect_demod(d_iq, d_p, sps=4, soft_stride=148, slice_bits=True, exact=False)
     pkt_f, len_f = trx.pack_trxd_wire(res_f, d_p, soft_f, d_meta, pkt_stride=160)
     torch.cuda.synchronize()
-    assert torch.equal(res_e, res_f) and torch.equal(len_e, len_f)          # detection and every header field: identical
+    # detection decisions and every header field but C/I: identical.  C/I (bytes 9-10, centibels, truncated) comes from the
+    # FAST detector's FMA peak value (include/trxhip.h, TRXHIP_FAST_CI_ATOL_DB): it may move by one count where 10 ci lies
+    # within the bar of an integer
+    re_, rf_ = trx.results_to_numpy(res_e), trx.results_to_numpy(res_f)
+    for f in ("rc", "tsc", "clip", "idle", "nbits_div4"):
+        assert np.array_equal(re_[f], rf_[f]), f
+    for f in ("toa", "energy", "rssi"):
+        assert np.array_equal(re_[f], rf_[f], equal_nan=True), f
+    O.assert_fast_ci(rf_["ci"], re_["ci"])
+    assert torch.equal(len_e, len_f)
     det = (len_e.view(torch.int16) == 11 + 148)
     a, b = pkt_e[det][:, 11:159].to(torch.int16), pkt_f[det][:, 11:159].to(torch.int16)
     diff = (a - b).abs()
-    hdr = int((pkt_e[:, :11] != pkt_f[:, :11]).sum())
+    hdr = int((pkt_e[:, :9] != pkt_f[:, :9]).sum())
+    ci_e = (pkt_e[:, 9].to(torch.int32) << 8 | pkt_e[:, 10].to(torch.int32)).to(torch.int16)
+    ci_f = (pkt_f[:, 9].to(torch.int32) << 8 | pkt_f[:, 10].to(torch.int32)).to(torch.int16)
+    dci = (ci_e.to(torch.int32) - ci_f.to(torch.int32)).abs()
+    assert int(dci.max()) <= 1 and float((dci != 0).float().mean()) <= 2e-3, (int(dci.max()), float((dci != 0).float().mean()))
     # relative error of the raw (-1..+1) soft value 2 s - 1 where it is not small
     raw_e, raw_f = 2.0 * soft_e[det] - 1.0, 2.0 * soft_f[det] - 1.0
     rel = []
