@@ -96,12 +96,13 @@ __device__ __forceinline__ PhBase ph_bases(const c32 *P, int ph0, int m0)
 // the end of the launch (work claiming, below) another 13 % in round 2.
 #define K4_WPB(CF_, EX_) (((CF_) && (EX_)) ? 12 : 16)
 
-// The fused demodulator's main filter: three ADJACENT outputs per lane over the composite taps u = 8 .. 31 (24 of 35: see the
-// kernel).  pb addresses the lane's first sample (tap u = 8 of its first output), c4 its tap row from u = 8 on -- a per-lane
+// The fused demodulator's main filter: three ADJACENT outputs per lane over the composite taps u = K4_U0 .. K4_U0 + K4_NT - 1
+// (6 .. 29, 24 of 35: trx_tables.h).  pb addresses the lane's first sample (tap K4_U0 of its first output), c4 its tap row from K4_U0 on -- a per-lane
 // LDS address, wave-uniform for the ordinary lanes.  Taps outer, a ring of 16 samples loaded D ahead of use; one
 // sched_barrier per tap keeps the order and the register footprint.
-#define K4_U0 8
-#define K4_NT 24
+#define K4_U0 TRX_FUSED_U0
+#define K4_NT TRX_FUSED_NT
+#define K4_NTP TRX_FUSED_NTP
 __device__ __forceinline__ void fir24x3(const PhBase &pb, const float4 *c4, v2f (&acc)[3])
 {
 	constexpr int D = 4, NV = K4_NT + 8;                            // samples v = 0 .. 31
@@ -238,8 +239,10 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 			dfilt[((u >> 2) * WAVE + l) * 4 + (u & 3)] = (q < TRX_SINCV_LEN) ? tab->sincv[q] : 0.0f;
 		}
 	}
-	for (int i = threadIdx.x; i < K4_DROWS * 36; i += blockDim.x)
-		comp[i] = (&tab->comp_filt[0][0])[i];
+	for (int i = threadIdx.x; i < K4_DROWS * 36; i += blockDim.x) {    // (rows shifted by TRX_FUSED_SH: tap K4_U0 at a multiple of 4)
+		const int f = i / 36, j = i % 36;
+		comp[i] = (j >= TRX_FUSED_SH) ? tab->comp_filt[f][j - TRX_FUSED_SH] : 0.0f;
+	}
 	for (int i = threadIdx.x; i < 160; i += blockDim.x)
 		rrot[i] = make_float2(tab->rrot1[i].re, tab->rrot1[i].im);
 	if (threadIdx.x < 16)
@@ -464,7 +467,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 			fast_nk = nk;
 			const int fr = nk & 127;
 			const int fidx = (fr >= 2) ? (fr >> 1) : TRX_DELAY_FILTS;
-			if (lane < 48)
+			if (lane < 2 * K4_NTP)
 				fast_rows = reinterpret_cast<const float4 *>(&tab->edge8[fidx][0][0])[lane];
 		};
 		// The straight-line fused demodulator of the usual geometry (called below, behind detection).
@@ -487,20 +490,20 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 			// park the low-edge rows: lane l < 48 holds floats 4l .. 4l+3 of the 8 x 24 block
 			float *const stage = reinterpret_cast<float *>(dec);
 #ifdef TRX_WHATIF_NOFETCHWAIT   /* timing only (tools/): what the wait for the edge8 rows costs -- the rows are not used */
-			if (lane < 48)
+			if (lane < 2 * K4_NTP)
 				*reinterpret_cast<float4 *>(stage + 4 * lane) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #else
-			if (lane < 48)
+			if (lane < 2 * K4_NTP)
 				*reinterpret_cast<float4 *>(stage + 4 * lane) = fast_rows;
 #endif
 			wave_sync();
 			// lanes 0..49: outputs 3l .. 3l+2 with the burst's composite row; lanes 52..55: output l - 52, main part of its
 			// truncated row; lanes 56..59: the same outputs' taps u < 8 (window 8 samples = 2 outputs earlier); the rest idle
 			const bool sp = (lane >= 52) && (lane < 60);
-			const float *const tp = sp ? stage + (lane - 52) * 24 : comp + fidx * 36 + K4_U0;
+			const float *const tp = sp ? stage + (lane - 52) * K4_NTP : comp + fidx * 36 + (K4_U0 + TRX_FUSED_SH);
 			int ic = (lane < 50) ? 3 * lane : 150;
 			if (sp) ic = (lane < 56) ? lane - 52 : lane - 58;
-			const int c = -16 - w;                                      // tap u = 8 of output i reads sample 4i + c
+			const int c = -24 - w + K4_U0;                              // tap u = K4_U0 of output i reads sample 4i + c
 			const PhBase pb = ph_bases(P, c & 3, ic + (c >> 2));
 			v2f acc[3] = { { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f } };
 			if (!ABL(5))
@@ -984,8 +987,8 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 					// Of the 35 composite taps only u = 9 .. 27 matter: the decimator's passband sees the fractional-delay
 					// filter as a pure delay, so comp_f is the decimator shifted by 9 + frac and the taps outside carry
 					// < 1.1e-6 (u < 8) of the filter's absolute sum in every one of the 65 rows (tests/test_capi_cpu.py).
-					// The filter runs over u = K4_U0 .. K4_U0 + K4_NT - 1 = 8 .. 31: 24 taps instead of 36.
-					const float4 *c4 = reinterpret_cast<const float4 *>(comp + fidx * 36 + K4_U0);   // broadcast reads
+					// The filter runs over u = K4_U0 .. K4_U0 + K4_NT - 1 = 6 .. 29 (trx_tables.h): 24 taps instead of 36.
+					const float4 *c4 = reinterpret_cast<const float4 *>(comp + fidx * 36 + (K4_U0 + TRX_FUSED_SH));   // broadcast reads
 					const int c_full = -24 - w;                                 // sample of tap 0 of output i: 4i + c_full
 					const int c = c_full + K4_U0;
 					const int i_min = cdiv4(-36 - c_full), i_max = fdiv4(L + 1 - c_full);

@@ -435,9 +435,12 @@ private:
 		// the four rows of the usual geometry, re-packed for the main filter loop (trx_tables.h)
 		for (int f = 0; f <= TRX_DELAY_FILTS; f++)
 			for (int i = 0; i < 4; i++)
-				for (int k = 0; k < 24; k++) {
-					t_->edge8[f][i][k] = t_->edge_lo[f][14 - 4 * i][8 + k];
-					t_->edge8[f][4 + i][k] = (k < 8) ? t_->edge_lo[f][14 - 4 * i][k] : 0.0f;
+				for (int k = 0; k < TRX_FUSED_NTP; k++) {
+					// main part: taps u = U0 + k; early part: the lane's window starts 8 samples early, so its tap k is
+					// u = k - (8 - U0), kept for u < U0
+					const int ue = k - (8 - TRX_FUSED_U0);
+					t_->edge8[f][i][k] = (k < TRX_FUSED_NT) ? t_->edge_lo[f][14 - 4 * i][TRX_FUSED_U0 + k] : 0.0f;
+					t_->edge8[f][4 + i][k] = (ue >= 0 && ue < TRX_FUSED_U0) ? t_->edge_lo[f][14 - 4 * i][ue] : 0.0f;
 				}
 		// high side: the decimator truncated to taps t <= tm
 		for (int f = 0; f <= TRX_DELAY_FILTS; f++)

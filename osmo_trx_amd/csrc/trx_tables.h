@@ -15,6 +15,21 @@
 
 struct trx_c32 { float re, im; };
 
+// The fused demodulator evaluates composite taps u = TRX_FUSED_U0 .. TRX_FUSED_U0 + TRX_FUSED_NT - 1 of the 35 (trx_kernel4.hip,
+// fir24x3): 6 .. 29 since round 5 (rounds 2-4: 8 .. 31 -- but taps 30 / 31 carry 3.7e-7 / 2e-9 of a filter whose taps sum to 1 and
+// taps 6 / 7 carry 6.2e-7 / 3e-8: the same 24 multiply-adds two taps lower halve the error, profiles/r05_fused_taps.txt).
+// Measurement builds (tools/build_variants.py name:all:-DTRX_FUSED_U0=..,-DTRX_FUSED_NT=..) override them to price other windows.
+// Taps are fetched four at a time from 16-byte aligned LDS addresses: the kernel's LDS copy of a composite row is shifted by
+// TRX_FUSED_SH so that tap U0 sits at a multiple of 4.
+#ifndef TRX_FUSED_U0
+#define TRX_FUSED_U0 6
+#endif
+#ifndef TRX_FUSED_NT
+#define TRX_FUSED_NT 24
+#endif
+#define TRX_FUSED_SH ((4 - TRX_FUSED_U0 % 4) % 4)          /* shift of the LDS copy of a composite row */
+#define TRX_FUSED_NTP ((TRX_FUSED_NT + 3) / 4 * 4)        /* taps per edge8 row (rows are fetched as float4) */
+
 enum {
 	TRX_SEQ_TSC0   = 0,   // gMidambles[0..7]
 	TRX_SEQ_RACH0  = 8,   // gRACHSequences[0..2]
@@ -68,18 +83,21 @@ struct trx_tables {
 	// filter f with the decimator truncated to t >= t0:  edge_lo[f][t0-1][u] = sum_{t>=t0, t+k=u} g[t]*h_f[k], u < 35
 	float    edge_lo[TRX_DELAY_FILTS + 1][15][36];
 	// The same four rows re-packed for the usual geometry (n_lo = 0: outputs 0..3 see decimator taps t >= 15, 11, 7, 3),
-	// in the form the main filter loop of the 4-SPS kernel consumes -- 24 taps per lane, tap u = 8..31 of the lane's row:
-	//   edge8[f][i][0..23]     = edge_lo[f][14 - 4i][8..31]              main part of output i (lanes 52..55)
-	//   edge8[f][4 + i][0..23] = edge_lo[f][14 - 4i][0..7], then zeros   its taps u < 8, for a lane whose window starts 8
+	// in the form the main filter loop of the 4-SPS kernel consumes -- 24 taps per lane, tap u = U0 .. U0 + 23 of the lane's row (U0 = TRX_FUSED_U0):
+	//   edge8[f][i][0..23]     = edge_lo[f][14 - 4i][U0 .. U0+23]        main part of output i (lanes 52..55)
+	//   edge8[f][4 + i][k]     = edge_lo[f][14 - 4i][k - (8 - U0)]       its taps u < U0 (zero elsewhere), for a lane whose window starts 8
 	//                                                                     samples early (lanes 56..59); taps u >= 32 are 0
+	// (TRX_FUSED_U0 / TRX_FUSED_NT, below: the window of composite taps the fused demodulator runs; 8 / 24 in the text above)
 	float    edge8_pad[2];                              // (edge8 at a multiple of 16 bytes)
-	float    edge8[TRX_DELAY_FILTS + 1][8][24];
+	float    edge8[TRX_DELAY_FILTS + 1][8][TRX_FUSED_NTP];
 	// high-side partial outputs (a burst delayed by a negative whole shift w <= -2 ends at delayed sample n_hi = L - 1 + w:
 	// output i only sees decimator taps t <= tm = n_hi + 15 - 4i, 0..14).  Composite of delay filter f with the decimator
 	// truncated to t <= tm:  edge_hi[f][tm][u] = sum_{t<=tm, t+k=u} g[t]*h_f[k]  (u <= tm + 19; 0 beyond)
 	float    edge_hi[TRX_DELAY_FILTS + 1][15][36];
 };
 static_assert(offsetof(trx_tables, edge8) % 16 == 0, "edge8 rows are fetched as float4");
+static_assert(TRX_FUSED_U0 >= 0 && TRX_FUSED_U0 <= 8 && TRX_FUSED_U0 + TRX_FUSED_NTP + TRX_FUSED_SH <= 36 && TRX_FUSED_NTP <= 32,
+	      "fused demodulator tap window");
 
 #define TRX_TABLES_MAGIC   0x54585254u
 #define TRX_TABLES_VERSION 7u

@@ -90,9 +90,11 @@ def test_tables_bit_identical_to_oracle(lib):
         np.testing.assert_allclose(t["comp_filt"][f][:35], ref, rtol=1e-7, atol=1e-12)   # products in double, one float rounding
         assert t["comp_filt"][f][35] == 0
     assert np.array_equal(t["comp_filt"][64][9:25], o["dec_taps"]) and not t["comp_filt"][64][:9].any()
-    # the fused demodulator runs taps 8 .. 31 only (trx_kernel4.hip, K4_U0 / K4_NT): what it leaves out is below 1.1e-6 of a
-    # filter whose taps sum to 1, in every row.  (Not so for the truncated rows of the low-edge table, which keep all taps.)
+    # the fused demodulator runs taps 6 .. 29 only (trx_tables.h TRX_FUSED_U0 / TRX_FUSED_NT): what it leaves out is below 8e-7
+    # of a filter whose taps sum to 1, in every row (taps 8 .. 31, rounds 2-4: 1.1e-6).  (Not so for the truncated rows of the
+    # low-edge table, which keep all taps.)
     assert np.abs(t["comp_filt"][:, :8]).sum(axis=1).max() < 1.1e-6 and not t["comp_filt"][:, 32:].any()
+    assert (np.abs(t["comp_filt"][:, :6]).sum(axis=1) + np.abs(t["comp_filt"][:, 30:]).sum(axis=1)).max() < 8e-7
     # truncated composites of the low-side partial outputs: decimator taps t >= t0 only
     for f in (0, 17, 63):
         for t0 in (1, 3, 7, 11, 15):
@@ -113,12 +115,13 @@ def test_tables_bit_identical_to_oracle(lib):
     assert np.array_equal(t["edge_hi"][64][6][9:16], o["dec_taps"][:7]) and not t["edge_hi"][64][6][16:].any()
     # low + high truncations at the same cut add up to the full composite
     np.testing.assert_allclose(t["edge_lo"][:, 7, :] + t["edge_hi"][:, 7, :], t["comp_filt"], rtol=0, atol=2e-7)
-    # the usual-geometry repack the main filter loop consumes (trx_tables.h, edge8): rows of outputs 0..3 from tap 8 on,
-    # their taps below 8 as separate rows; nothing is lost by the 32-tap window (tap 0 and taps >= 32 are exactly zero)
+    # the usual-geometry repack the main filter loop consumes (trx_tables.h, edge8): rows of outputs 0..3 from tap 6 on,
+    # their taps below 6 as separate rows; nothing is lost by the 32-tap window (tap 0 and taps >= 32 are exactly zero)
     assert not t["edge_lo"][:, :, 32:].any() and not t["edge_lo"][:, :, 0].any()
     for i in range(4):
-        assert np.array_equal(t["edge8"][:, i, :], t["edge_lo"][:, 14 - 4 * i, 8:32])
-        assert np.array_equal(t["edge8"][:, 4 + i, :8], t["edge_lo"][:, 14 - 4 * i, :8]) and not t["edge8"][:, 4 + i, 8:].any()
+        assert np.array_equal(t["edge8"][:, i, :], t["edge_lo"][:, 14 - 4 * i, 6:30])                 # taps u = 6 .. 29
+        assert np.array_equal(t["edge8"][:, 4 + i, 2:8], t["edge_lo"][:, 14 - 4 * i, :6])              # its taps u < 6, window 8 samples early
+        assert not t["edge8"][:, 4 + i, :2].any() and not t["edge8"][:, 4 + i, 8:].any()
     # the straight-line decimator mirrors taps 0..7 (trx_kernel4.hip, decimate16_sym): bitwise symmetric filter
     assert np.array_equal(t["dec_taps"].view(np.uint32), t["dec_taps"][::-1].view(np.uint32))
     # resampler / channelizer partitions against the oracle's restatements

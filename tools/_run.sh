@@ -1,6 +1,5 @@
 set -x
 L=osmo_trx_amd/lib
-rocprofv3 -L 2>/dev/null | grep -o "SQ_[A-Z0-9_]*" | sort -u | tr '\n' ' ' > gpurun_out/r05_counters.txt
-bash tools/pmc_insts.sh $L/libtrxhip_base.so $L/libtrxhip_f0.so $L/libtrxhip_f1.so $L/libtrxhip_nofw.so > gpurun_out/r05_pmc5.log 2>&1
-bash tools/ab_multi.sh 3 30 $L/libtrxhip_base.so $L/libtrxhip_f0.so $L/libtrxhip_f1.so $L/libtrxhip_nofw.so > gpurun_out/r05_ab5.log 2>&1
-cat gpurun_out/r05_counters.txt gpurun_out/r05_pmc5.log gpurun_out/r05_ab5.log
+for l in t24 w6n24 w6n26 w5n26 w4n28; do TRXHIP_LIB=$PWD/$L/libtrxhip_$l.so python tools/fused_taps_report.py; done > gpurun_out/r05_taps2.log 2>&1
+bash tools/ab_multi.sh 3 30 $L/libtrxhip_t24.so $L/libtrxhip_w6n24.so $L/libtrxhip_w6n26.so $L/libtrxhip_w5n26.so $L/libtrxhip_w4n28.so > gpurun_out/r05_ab7.log 2>&1
+grep -v "^+\|amdgpu.ids" gpurun_out/r05_taps2.log; cat gpurun_out/r05_ab7.log

@@ -31,15 +31,25 @@ def main():
     variants = []
     for a in sys.argv[1:]:
         name, _, fl = a.partition(":")
-        flags = [f for f in fl.split(",") if f]
+        # "name:all:-DX,..." -- the flags change a shared header (e.g. the table layout): every translation unit is recompiled
+        every = fl.startswith("all:")
+        flags = [f for f in fl[4 if every else 0:].split(",") if f]
         obj = os.path.join(OBJ, f"k4_{name}.o")
         todo.append((os.path.join(B.CSRC, "trx_kernel4.hip"), obj, flags))
-        variants.append((name, obj))
+        rest = []
+        for s in others:
+            if every:
+                o = os.path.join(OBJ, f"{name}_{s}.o")
+                todo.append((os.path.join(B.CSRC, s), o, flags))
+            else:
+                o = os.path.join(OBJ, s + ".o")
+            rest.append(o)
+        variants.append((name, obj, rest))
     with ThreadPoolExecutor(max_workers=6) as ex:
         list(ex.map(lambda t: cc(*t), todo))
-    for name, obj in variants:
+    for name, obj, rest in variants:
         out = os.path.join(B.LIBDIR, f"libtrxhip_{name}.so")
-        B._run([B.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, obj] + [os.path.join(OBJ, s + ".o") for s in others])
+        B._run([B.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, obj] + rest)
         print("built", os.path.relpath(out, ROOT))
 
 
