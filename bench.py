@@ -22,6 +22,8 @@ sys.path.insert(0, ROOT)
 import re
 FUSED_SOFT_ATOL = float(re.search(r"#define\s+TRXHIP_FUSED_SOFT_ATOL\s+([0-9.eE+-]+)f?\b",       # the one tolerance statement
                                   open(os.path.join(ROOT, "include", "trxhip.h")).read()).group(1))
+FAST_AMP_RTOL = float(re.search(r"#define\s+TRXHIP_FAST_AMP_RTOL\s+([0-9.eE+-]+)f?\b",
+                                open(os.path.join(ROOT, "include", "trxhip.h")).read()).group(1))
 BYTES_PER_BURST = 3132          # 2500 B int16 IQ + 8 B params + 592 B soft bits + 32 B result
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -376,11 +378,8 @@ def spawn_ranks(n):
     through.  The parent never touches the GPU (torch.cuda.device_count() does not initialise it): nothing that has
     made a HIP call is ever re-executed.  A rank that dies takes the others with it (their exact PIDs)."""
     import subprocess
-    import torch
-    have = torch.cuda.device_count()
-    if have < n and not os.environ.get("TRXHIP_ONE_DEVICE"):
-        raise SystemExit(f"--gpus {n} but this node shows {have} GPU(s) (TRXHIP_ONE_DEVICE=1 with TRXHIP_DIST_BACKEND=gloo "
-                         "runs every rank on cuda:0: tests only)")
+    # (no device count here: on ROCm torch.cuda.device_count() falls back to hipGetDeviceCount() -- a HIP call in the launcher --
+    # when amdsmi is unavailable; each rank reports a missing device itself)
     port = free_port()
     procs = []
     for r in range(n):
@@ -391,17 +390,28 @@ def spawn_ranks(n):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     pending = list(procs)
-    while pending:
-        for p in list(pending):
+    try:
+        while pending:
+            for p in list(pending):
+                try:
+                    r = p.wait(timeout=0.5)
+                except subprocess.TimeoutExpired:
+                    continue
+                pending.remove(p)
+                if r != 0 and rc == 0:
+                    rc = r
+                    for q in pending:                                # one rank failed: the others would wait in a collective
+                        q.terminate()
+    finally:
+        # interrupted (or an exception above): do not leave ranks waiting in a collective -- their exact PIDs, nothing else
+        for q in pending:
+            if q.poll() is None:
+                q.terminate()
+        for q in pending:
             try:
-                r = p.wait(timeout=0.5)
+                q.wait(timeout=5.0)
             except subprocess.TimeoutExpired:
-                continue
-            pending.remove(p)
-            if r != 0 and rc == 0:
-                rc = r
-                for q in pending:                                    # one rank failed: the others would wait in a collective
-                    q.terminate()
+                q.kill()
     return rc
 
 
@@ -437,6 +447,9 @@ def main():
         raise SystemExit("bench.py needs a GPU: osmo_trx_amd has no CPU path")
     if os.environ.get("TRXHIP_ONE_DEVICE"):              # test hook: every rank on cuda:0 (with TRXHIP_DIST_BACKEND=gloo)
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but this node shows {torch.cuda.device_count()} GPU(s) "
+                         "(TRXHIP_ONE_DEVICE=1 with TRXHIP_DIST_BACKEND=gloo runs every rank on cuda:0: tests only)")
     dev = f"cuda:{local_rank}"
     torch.cuda.set_device(local_rank)
 
@@ -565,10 +578,15 @@ def main():
                                          "and in front of every side leg: the timed steps run on settled clocks",
                 "parallelism": f"batch-sharded x{world} (no data-path collective; tables RCCL-broadcast once)",
                 "detected_fraction": round(detected / n, 4),
-                "demodulator": "fused delay-o-decimate composite filter, 24 of 35 taps (default); rc, TOA, amp bit-exact; "
+                "demodulator": "fused delay-o-decimate composite filter, taps 6..29 of 35 (default since round 5; profiles/r05_fused_taps.txt: "
+                               "max relative error of a soft value with |soft| >= 0.05: 6.1e-5, 26 / 28 taps measured at -1.6 % / -3.2 %); "
                                f"|soft - ref| <= {FUSED_SOFT_ATOL:g} * max(1, rms / (4 |amp|)), absolute on full scale 1 "
                                f"(include/trxhip.h: plain {FUSED_SOFT_ATOL:g} on every real detection, amplitude-scaled on noise "
                                "slots detected far below their samples' level)",
+                "detector": "FAST (fused kernels, round 5): rc / TSC / TOA identical to the reference -- FMA interpolation rounds, every "
+                            "early / late decision certified by a proven rounding margin or re-run in the reference's operand order "
+                            f"(0.5 % of detections); amp within {FAST_AMP_RTOL:g} relative (measured 5e-7), C/I within "
+                            "1e-4 + 1.4e-5 (1 + 10^(ci/10)) dB; TRXHIP_FLAG_EXACT_DEMOD = the bit-exact kernel",
                 "sustained": sustained,
                 "exact_demod_mbursts_per_gpu": round(n / exact_ms / 1e3, 2) if side else None,
                 "mixed_7to1_nb_rach": ({"workload": "BASELINE.json configs[4] per-GPU share: 7:1 NB:RACH, RACH max_toa 63",
@@ -580,7 +598,8 @@ def main():
             "roofline": {
                 # `bound` names the roofline the fraction is priced against (the measurement contract: HBM bytes); what limits
                 # the kernel in practice is in `compute` -- the vector ALU's issue rate, not HBM
-                "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "bound": "hbm", "bound_note": "valu-issue in practice (see compute): `bound` names the roofline `frac` is priced against",
+                "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,
                 "compute": compute,
                 "kernel": "burst_pull4_kernel<false, false, true>", "kernel_ms": round(kernel_ms, 4),

@@ -126,7 +126,7 @@ int trxhip_create_from_tables(trxhip_ctx **out, int device, const void *h_blob, 
 	ctx->no_unit = trx_unit_masks_match(t) ? 0 : 1;
 	ctx->sch_unit = trx_unit_mask_sch_match(t) ? 1 : 0;
 	ctx->d_pool = nullptr;
-	ctx->pool_nstreams = 0;
+	ctx->pool_next.store(0u);
 	ctx->pool_enabled = getenv("TRXHIP_NO_POOL") ? 0 : 1;          /* measurement switch, read once per context */
 	ctx->no_sym = 0;                                           /* the straight-line decimator reads taps 0..7 and mirrors them */
 	for (int k = 0; k < 8; k++)
@@ -155,8 +155,11 @@ int trxhip_create_from_tables(trxhip_ctx **out, int device, const void *h_blob, 
 		delete ctx;
 		return TRXHIP_EIO;
 	}
-	if (hipMalloc(reinterpret_cast<void **>(&ctx->d_pool), TRX_POOL_SLOTS * 64) != hipSuccess)
+	if (hipMalloc(reinterpret_cast<void **>(&ctx->d_pool), TRX_POOL_SLOTS * 64) != hipSuccess ||
+	    hipMemset(ctx->d_pool, 0, TRX_POOL_SLOTS * 64) != hipSuccess) {
+		if (ctx->d_pool) (void)hipFree(ctx->d_pool);
 		ctx->d_pool = nullptr;                                 /* (the kernels run without the pool) */
+	}
 	*out = ctx;
 	return TRXHIP_OK;
 }
@@ -245,25 +248,10 @@ static int pull_common(trxhip_ctx *ctx, const void *d_iq, int cf32, const trxhip
 		flags |= TRXHIP_IFLAG_NO_SYM;
 	if (ctx->no_fast)
 		flags |= TRXHIP_IFLAG_NO_FAST;
-	/* a zeroed pool counter for this launch (the kernel ignores it for small batches) */
+	/* a counter pair for this launch (zero: the previous user's last workgroup re-armed it; trx_ctx.h) */
 	unsigned *pool = nullptr;
-	if (ctx->d_pool && ctx->pool_enabled && n_bursts >= (size_t)ctx->n_cu * 128) {
-		int slot = -1;
-		{
-			std::lock_guard<std::mutex> g(ctx->pool_mu);           /* the stream's own counter (see trx_ctx.h) */
-			for (int k = 0; k < ctx->pool_nstreams; k++)
-				if (ctx->pool_stream[k] == stream) { slot = k; break; }
-			if (slot < 0 && ctx->pool_nstreams < TRX_POOL_SLOTS) {
-				slot = ctx->pool_nstreams++;
-				ctx->pool_stream[slot] = stream;
-			}
-		}
-		if (slot >= 0) {
-			pool = ctx->d_pool + slot * 16;
-			if (hipMemsetAsync(pool, 0, sizeof(unsigned), static_cast<hipStream_t>(stream)) != hipSuccess)
-				return TRXHIP_EIO;
-		}
-	}
+	if (ctx->d_pool && ctx->pool_enabled && n_bursts >= (size_t)ctx->n_cu * 128)
+		pool = ctx->d_pool + (size_t)(ctx->pool_next.fetch_add(1u, std::memory_order_relaxed) % TRX_POOL_SLOTS) * 16;
 	return trx_launch_pull(pool, d_iq, cf32, d_params, d_results, d_soft, ctx->d_tables, d_ebp_in, n_bursts, burst_len, sps,
 			       threshold, full_scale, soft_stride, flags, ctx->n_cu, static_cast<hipStream_t>(stream));
 }

@@ -2,6 +2,7 @@
 #ifndef TRX_CTX_H
 #define TRX_CTX_H
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <mutex>
 #include "../../include/trxhip.h"
 #include "trx_tables.h"
@@ -14,19 +15,18 @@ struct trxhip_ctx {
 	int sch_unit;       /* the SCH sequence has the unit structure the kernel's compiled-in mask expects (trx_sch.hip) */
 	int no_sym;         /* decimator taps not bitwise symmetric: the kernels' straight-line paths (mirrored taps) are off */
 	int no_fast;        /* sinc LUT row sums above TRX_FAST_W: the fused kernels' FAST detector (proven margins) is off */
-	/* cross-die work pool of the 4-SPS kernel (trx_kernel4.hip): one 64-byte counter PER STREAM.  Launches on one stream
-	 * run in order, so the hipMemsetAsync in front of a launch can never zero a counter an earlier launch still draws
-	 * from; launches on different streams never share one (round 3 handed the slots out round-robin per launch: launch i
-	 * and launch i + 64, outstanding at the same time on different streams, shared a counter).  A context that sees more
-	 * than TRX_POOL_SLOTS distinct streams runs the surplus ones without the pool (static split: same results).  A launch
-	 * captured into a HIP graph keeps the slot of the stream it was captured on. */
+	/* cross-die work pool of the 4-SPS kernel (trx_kernel4.hip): TRX_POOL_SLOTS counter pairs {drawn, workgroups done} of 64
+	 * bytes each, handed out round-robin PER LAUNCH.  The kernel re-arms its pair itself -- the last workgroup to finish
+	 * zeroes both words -- so there is no memset in front of a launch: nothing that two host threads launching on one stream
+	 * could interleave (round 4's per-stream counter was zeroed by a hipMemsetAsync queued separately from the launch: memset A,
+	 * memset B, kernel A, kernel B left kernel B without a pool), no table of streams that fills up, and a launch
+	 * captured into a HIP graph is complete in itself (replays of one graph serialise).  Two launches share a pair only when
+	 * they are TRX_POOL_SLOTS pooled launches apart and still overlap -- 1024 outstanding batches of >= 32768 bursts. */
 	unsigned *d_pool;
 	int pool_enabled;                  /* trxhip_set_work_pool(); default 1, 0 when TRXHIP_NO_POOL is set at creation */
-	void *pool_stream[64];
-	int pool_nstreams;
-	std::mutex pool_mu;
+	std::atomic<unsigned> pool_next;
 };
-#define TRX_POOL_SLOTS 64
+#define TRX_POOL_SLOTS 1024
 
 /* the TRXD wire packer's launcher (trx_aux_kernels.hip); d_results_copy (may be NULL): every result record is also written
  * there -- the host pipe points it at pinned memory and saves the download */

@@ -1147,6 +1147,18 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 		DIAG_MARK(12);
 	}
 	flush(lane);
+	// re-arm the pool's counter pair for the next launch that is handed it: every wave of this workgroup is past its last draw
+	// here, and the workgroup that arrives last at the second word zeroes both (no memset in front of a launch: trx_ctx.h)
+	if (pooled) {
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			const unsigned d = __hip_atomic_fetch_add(pool_ctr + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+			if (d == gridDim.x - 1u) {
+				__hip_atomic_store(pool_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_store(pool_ctr + 1, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+			}
+		}
+	}
 	DIAG_FLUSH();
 }
 

@@ -627,8 +627,8 @@ def test_cross_die_pool_equals_static_split(trx):
     torch.cuda.synchronize()
     for r, so in outs:
         assert torch.equal(r, ref_res) and torch.equal(so.view(torch.int32), ref_soft.view(torch.int32))
-    # more streams than the context has counters (64: one per stream), two launches on each, all outstanding together: the
-    # surplus streams run the static split, nobody shares a counter (round 3 handed counters out per launch, modulo 64)
+    # many streams, two launches on each, all outstanding together: every launch has its own counter pair (1024 per context,
+    # re-armed by the kernel itself; rounds 3 / 4 shared counters modulo 64 / ran out of per-stream slots after 64 streams)
     streams = [torch.cuda.Stream() for _ in range(70)]
     n = 32768 + 16
     outs = []
@@ -710,3 +710,39 @@ def test_fast_detector_campaign_against_oracle(trx, capsys):
               f"{reruns} TOA searches re-run in the reference's operand order ({rate:.3%} of detected); "
               f"max amp error {worst_amp:.2e} relative (bar {FAST_AMP_RTOL:g}), max C/I error {worst_ci:.3f} of its bar")
     assert rate < 0.02
+
+
+def test_two_host_threads_launching_on_one_stream(trx):
+    """the pool counter of round 4 was zeroed by a hipMemsetAsync queued separately from the launch, so two host
+    threads launching large batches on ONE stream could enqueue memset A, memset B, kernel A, kernel B and leave kernel B
+    with an exhausted counter -- the last eighth of its groups never processed, stale rows returned.  The kernel now re-arms
+    its counter pair itself and a launch is a single enqueue: any interleaving of the two threads' calls is correct.  Two
+    threads, 24 pooled launches each on the NULL stream, sentinel-filled outputs, every result equal to the serial run."""
+    import threading
+    from osmo_trx_amd import synth
+    n = 65536 + 48
+    iq, params = synth.make_mixed_bursts(n, "cuda:0", seed=909, chunk=8192)
+    d_p = trx.params_tensor(params)
+    ref_res, ref_soft = trx.detect_demod(iq, d_p, sps=4)
+    torch.cuda.synchronize()
+    outs = {0: [], 1: []}
+    bufs = {t: [(torch.full((n, 32), 0xA5, dtype=torch.uint8, device="cuda:0"),
+                 torch.full((n, 148), float("nan"), dtype=torch.float32, device="cuda:0")) for _ in range(24)] for t in (0, 1)}
+    torch.cuda.synchronize()
+    go = threading.Barrier(2)
+
+    def work(t):
+        go.wait()
+        for res, soft in bufs[t]:
+            outs[t].append(trx.detect_demod(iq, d_p, sps=4, results=res, soft=soft))
+
+    th = [threading.Thread(target=work, args=(t,)) for t in (0, 1)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    torch.cuda.synchronize()
+    for t in (0, 1):
+        assert len(outs[t]) == 24
+        for r, so in outs[t]:
+            assert torch.equal(r, ref_res) and torch.equal(so.view(torch.int32), ref_soft.view(torch.int32))
