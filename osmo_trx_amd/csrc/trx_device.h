@@ -831,10 +831,10 @@ __device__ __forceinline__ int detect_tail_h(const c32 *sig, int sig_len, c32 *c
 	DIAG_MARK(4);
 	// ---- computePeakRatio (:1541-1571): terms in the reference's order; out-of-range terms read the
 	// zero pads (adding +0 is exact), their count is arithmetic
-	if (!WI_SKIP) {
+	const float pwr = WI_SKIP ? 0.0f : norm2(cz[bidx + pc.ratio_off]);   // (read before cz[len - 1] is zeroed below)
+	auto ratio_gate = [&]() -> bool {
 		// lane k (mod 8) squares the k-th term of the reference's loop (peak-2, peak+2, peak-3, ... peak+5; out-of-range
 		// ones read the zero pads), a serial DPP scan adds them left to right: lane 7 holds the reference's avg
-		const float pwr = norm2(cz[bidx + pc.ratio_off]);
 		auto ordered_avg = [&]() {
 			float acc = pwr;
 #pragma unroll
@@ -875,16 +875,22 @@ __device__ __forceinline__ int detect_tail_h(const c32 *sig, int sig_len, c32 *c
 		const float t2 = t_e * t_e;
 		const float gm = FAST ? 1.2e-5f : 8e-6f;                   // (FAST: + the tree sum's 6e-7, with room)
 		if (amp2 < t2 * (1.0f - gm))
-			return 0;
+			return false;
 		if (!(amp2 > t2 * (1.0f + gm))) {
 			if (FAST)
 				avg = ordered_avg();
 			const float rms = (float)((double)sqrtf(avg / (float)num) + 0.00001);
 			const float ratio = sqrtf(amp2) / rms;
 			if (ratio < thresh)
-				return 0;
+				return false;
 		}
-	}
+		return true;
+	};
+	// (Round 5 measured the other order for the 4-SPS kernel -- TOA search first, so that its hook's loads of the demodulator's
+	// low-edge tap rows have the gate's ~250 cycles more to arrive; the wait for those rows is 1.8 % of the kernel -- and did
+	// not keep it: -0.8 %, the extra search on the slots that fail the gate costs more; profiles/r05_ab_runs.txt.)
+	if (!WI_SKIP && !ratio_gate())
+		return 0;
 
 	DIAG_MARK(5);
 	// ---- peakDetect (:1695): refined TOA (multiple of 1/512) and interpolated correlation value

@@ -93,8 +93,9 @@ def test_aligned_shard_ranges_for_every_world_size():
 
 
 def test_bench_self_spawn_refuses_more_ranks_than_gpus():
-    """plain `python bench.py --gpus 2` launches its own ranks; on a box without that many GPUs it says so (before any
-    child starts) instead of running as world 1 and printing n_gpus 1 (round 3)."""
+    """plain `python bench.py --gpus 2` launches its own ranks; on a box without that many GPUs the rank without a device says
+    so and takes the others down, instead of the job running as world 1 and printing n_gpus 1 (round 3).  (Round 5: the
+    launcher itself no longer counts devices -- torch.cuda.device_count() may fall back to a HIP call there)"""
     import pytest
     import torch
     if torch.cuda.device_count() >= 2:
@@ -102,7 +103,8 @@ def test_bench_self_spawn_refuses_more_ranks_than_gpus():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "TRXHIP_ONE_DEVICE")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
-    assert r.returncode != 0 and "--gpus 2 but this node shows" in r.stderr and '"metric"' not in r.stdout
+    assert r.returncode != 0 and '"metric"' not in r.stdout
+    assert "but this node shows" in r.stderr or "bench.py needs a GPU" in r.stderr
 
 
 def test_eight_rank_world_matches_the_eight_gpu_layout(tmp_path):
