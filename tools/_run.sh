@@ -1,4 +1,2 @@
-L=osmo_trx_amd/lib
-bash tools/pmc_insts.sh $L/libtrxhip_ge.so $L/libtrxhip_gl.so $L/libtrxhip_nosel.so > gpurun_out/r05_pmc8.log 2>&1
-bash tools/ab_multi.sh 3 30 $L/libtrxhip_ge.so $L/libtrxhip_gl.so $L/libtrxhip_nosel.so > gpurun_out/r05_ab8.log 2>&1
-cat gpurun_out/r05_pmc8.log gpurun_out/r05_ab8.log
+python -m pytest tests/test_gpu_sharded.py -q -m gpu -x --durations=6 2>&1 | tail -25 > gpurun_out/r05_t8.log
+cat gpurun_out/r05_t8.log
