@@ -94,6 +94,7 @@ enum trxhip_signal_error {
 
 /* Per-burst input: what pullRadioVector() knows before calling detectAnyBurst()
  * (expectedCorrType() Transceiver.cpp:513-601, mTSC, mMaxExpectedDelayAB/NB :757-758). 8 bytes. */
+#define TRXHIP_FLAG_USE_VA       8  /* trxhip_hostpipe_cfg.flags only: see there */
 #define TRXHIP_FLAG_IDLE_DUMMY   4  /* search IDLE slots for the dummy burst, as detectAnyBurst(IDLE) does (detectDummyBurst,
                                      * sigProcLib.cpp:1863-1877, :1945-1947; rc = IDLE on a hit) instead of skipping them as
                                      * pullRadioVector does (Transceiver.cpp:754-755) */
@@ -305,7 +306,11 @@ typedef struct trxhip_hostpipe_cfg {
 	int32_t  sps;
 	int32_t  soft_stride;  /* floats per burst downloaded (148 / 156 / 444); 0 = no float soft output */
 	int32_t  pkt_stride;   /* bytes per burst of TRXD datagrams downloaded (multiple of 4, >= 160); 0 = no TRXD packing */
-	int32_t  flags;        /* TRXHIP_FLAG_*; TRXD packing implies TRXHIP_FLAG_SLICE */
+	int32_t  flags;        /* TRXHIP_FLAG_*; TRXD packing implies TRXHIP_FLAG_SLICE.  TRXHIP_FLAG_USE_VA (host pipe only): the
+	                        * cfg->use_va flow of pullRadioVector (Transceiver.cpp:760-787) -- the slot's bursts are what the radio
+	                        * read 20 samples early; power / rssi come from them as read, detection runs on the copy shifted by 20
+	                        * samples (zeros behind), the soft bits from scaleVector(1 / 16383) + demodAnyBurst_va() on the unshifted
+	                        * burst (trxhip_demod_va_batch_cf32 chained behind the detection records): hard 0 / 1 rows of 148 */
 	float    threshold;    /* TRXHIP_BURST_THRESH */
 	float    full_scale;
 	float    rssi_offset;  /* enters the TRXD rssi byte only; result.rssi stays without it */

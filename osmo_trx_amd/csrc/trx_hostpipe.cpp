@@ -37,7 +37,9 @@ struct trxhip_hostpipe {
 		char *h_out, *d_out;           /* one block each: results, soft rows */
 		int16_t *d_iq;
 		int16_t *d_iq_sel;             /* n_paths > 1: the chosen path of every burst */
-		float *d_avg;                  /* n_paths > 1: path-averaged energy */
+		float *d_avg;                  /* n_paths > 1: path-averaged energy; use_va: energy of the burst as read */
+		int16_t *d_shift;              /* use_va: the bursts shifted by 20 samples (what the detector looks at) */
+		float *d_cf;                   /* use_va: the bursts as complex64 (what the Viterbi receiver reads) */
 		trxhip_burst_params *d_params;
 		trxhip_trxd_meta *d_meta;
 		trxhip_burst_result *d_results;
@@ -74,6 +76,9 @@ int trxhip_hostpipe_create(trxhip_ctx *ctx, const trxhip_hostpipe_cfg *c, trxhip
 		return TRXHIP_EINVAL;
 	if (c->n_paths < 0 || c->n_paths > 8)
 		return TRXHIP_EINVAL;
+	const bool use_va = (c->flags & TRXHIP_FLAG_USE_VA) != 0;
+	if (use_va && (c->sps != 4 || c->burst_len <= 40 || (c->flags & TRXHIP_FLAG_EXACT_DEMOD)))
+		return TRXHIP_EINVAL;                                  /* grgsm_vitac is a 4-SPS receiver */
 	if (c->n_paths > 1) {                                      /* the diversity energy scan must stay inside a path (trx_capi.cpp) */
 		const int window = 20 * c->sps < c->burst_len ? 20 * c->sps : c->burst_len;
 		if (4 * (window - 1) >= c->burst_len)
@@ -109,7 +114,9 @@ int trxhip_hostpipe_create(trxhip_ctx *ctx, const trxhip_hostpipe_cfg *c, trxhip
 		     pin((void **)&sl.h_in, in_bytes) && dev((void **)&sl.d_in, in_bytes) &&
 		     hipHostGetDevicePointer((void **)&sl.dv_in, sl.h_in, 0) == hipSuccess &&
 		     pin((void **)&sl.h_out, out_bytes_h) && dev((void **)&sl.d_out, out_bytes_d) &&
-		     (np == 1 || (dev((void **)&sl.d_iq_sel, nb * c->burst_len * 4) && dev((void **)&sl.d_avg, nb * sizeof(float))));
+		     (np == 1 || (dev((void **)&sl.d_iq_sel, nb * c->burst_len * 4) && dev((void **)&sl.d_avg, nb * sizeof(float)))) &&
+		     (!use_va || (dev((void **)&sl.d_shift, nb * c->burst_len * 4) && dev((void **)&sl.d_cf, nb * c->burst_len * 8) &&
+				  (sl.d_avg || dev((void **)&sl.d_avg, nb * sizeof(float)))));
 		if (!ok)
 			break;
 		sl.h.params = reinterpret_cast<trxhip_burst_params *>(sl.h_in);
@@ -146,7 +153,7 @@ void trxhip_hostpipe_destroy(trxhip_hostpipe *p)
 		if (sl.stream) (void)hipStreamSynchronize(sl.stream);
 		void *hp[] = { sl.h_in, sl.h_out, sl.h.pkt, sl.h.pkt_len };
 		for (void *q : hp) if (q) (void)hipHostFree(q);
-		void *dp[] = { sl.d_in, sl.d_out, sl.d_iq_sel, sl.d_avg };
+		void *dp[] = { sl.d_in, sl.d_out, sl.d_iq_sel, sl.d_avg, sl.d_shift, sl.d_cf };
 		for (void *q : dp) if (q) (void)hipFree(q);
 		if (sl.done) (void)hipEventDestroy(sl.done);
 		if (sl.stream) (void)hipStreamDestroy(sl.stream);
@@ -203,11 +210,35 @@ int trxhip_hostpipe_submit(trxhip_hostpipe *p, int slot, size_t n)
 		rc = trxhip_select_diversity_batch(p->ctx, d_bursts, n, (int)np, c.burst_len, c.sps, sl.d_iq_sel, sl.d_avg, nullptr, st);
 		d_bursts = sl.d_iq_sel;
 	}
-	if (rc == TRXHIP_OK)
-		rc = trxhip_detect_demod_batch(p->ctx, d_bursts, d_params, sl.d_results, sl.d_soft, n, c.burst_len, c.sps,
-					       c.threshold, c.full_scale, p->dev_soft_stride, c.flags, st);
-	if (rc == TRXHIP_OK && np > 1)                                /* :741, :751: rssi from the path average */
-		rc = trxhip_apply_diversity_power(p->ctx, sl.d_results, d_params, sl.d_avg, n, c.full_scale, st);
+	if (c.flags & TRXHIP_FLAG_USE_VA) {
+		/* cfg->use_va (Transceiver.cpp:760-787): detection on the copy shifted by 20 samples -- samples 20 .. len - 20 in
+		 * front, zeros behind (shift_vec, :679, :762) -- no soft bits from it; power of the burst as read; the Viterbi
+		 * receiver on the unshifted, scaled burst for the slots the detector found */
+		const size_t bb = (size_t)c.burst_len * 4, keep = ((size_t)c.burst_len - 40) * 4;
+		if (rc == TRXHIP_OK &&
+		    (hipMemsetAsync(sl.d_shift, 0, n * bb, st) != hipSuccess ||
+		     hipMemcpy2DAsync(sl.d_shift, bb, d_bursts + 40, bb, keep, n, hipMemcpyDeviceToDevice, st) != hipSuccess))
+			rc = TRXHIP_EIO;
+		if (rc == TRXHIP_OK)
+			rc = trxhip_detect_demod_batch(p->ctx, sl.d_shift, d_params, sl.d_results, nullptr, n, c.burst_len, c.sps,
+						       c.threshold, c.full_scale, p->dev_soft_stride,
+						       c.flags & ~(TRXHIP_FLAG_USE_VA | TRXHIP_FLAG_SLICE), st);
+		if (rc == TRXHIP_OK)
+			rc = trxhip_convert_short_float(p->ctx, sl.d_cf, d_bursts, n * (size_t)c.burst_len * 2, st);
+		if (rc == TRXHIP_OK && np == 1)                           /* (with diversity the path average is there already) */
+			rc = trxhip_energy_detect_batch_cf32(p->ctx, sl.d_cf, n, c.burst_len, 20u * (unsigned)c.sps, sl.d_avg, st);
+		if (rc == TRXHIP_OK)
+			rc = trxhip_demod_va_batch_cf32(p->ctx, sl.d_cf, d_params, sl.d_results, sl.d_soft, nullptr, n, c.burst_len,
+							1.0f / (float)((1 << 14) - 1), p->dev_soft_stride, c.flags & TRXHIP_FLAG_SLICE, st);
+		if (rc == TRXHIP_OK)                                      /* energy / rssi of the record: the burst as read (:724-751) */
+			rc = trxhip_apply_diversity_power(p->ctx, sl.d_results, d_params, sl.d_avg, n, c.full_scale, st);
+	} else {
+		if (rc == TRXHIP_OK)
+			rc = trxhip_detect_demod_batch(p->ctx, d_bursts, d_params, sl.d_results, sl.d_soft, n, c.burst_len, c.sps,
+						       c.threshold, c.full_scale, p->dev_soft_stride, c.flags, st);
+		if (rc == TRXHIP_OK && np > 1)                            /* :741, :751: rssi from the path average */
+			rc = trxhip_apply_diversity_power(p->ctx, sl.d_results, d_params, sl.d_avg, n, c.full_scale, st);
+	}
 	const bool records_by_packer = c.pkt_stride && !c.soft_stride;
 	if (rc == TRXHIP_OK && c.pkt_stride)                          /* datagrams and lengths: straight into the pinned buffers */
 		rc = trx_launch_pack_trxd_wire(sl.d_results, d_params, sl.d_soft, p->dev_soft_stride, d_meta, sl.dv_pkt, c.pkt_stride,

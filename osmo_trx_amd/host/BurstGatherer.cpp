@@ -380,7 +380,7 @@ bool BurstGatherer::start()
 		stride = c.pkt_stride;
 		payload = stride;
 	}
-	c.flags = TRXHIP_FLAG_SLICE | (m.cfg.exact_demod ? TRXHIP_FLAG_EXACT_DEMOD : 0);
+	c.flags = TRXHIP_FLAG_SLICE | (m.cfg.exact_demod ? TRXHIP_FLAG_EXACT_DEMOD : 0) | (m.cfg.use_va ? TRXHIP_FLAG_USE_VA : 0);
 	c.threshold = BURST_THRESH;
 	c.full_scale = (float)m.cfg.rxFullScale;
 	c.rssi_offset = (float)m.cfg.rssi_offset;

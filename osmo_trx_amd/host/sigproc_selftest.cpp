@@ -370,7 +370,8 @@ int main(int argc, char **argv)
 		memset(&cfg, 0, sizeof(cfg));
 		cfg.chans = chans; cfg.max_batch = 256; cfg.timeout_us = 200; cfg.fifo_depth = 32; cfg.sps = 4; cfg.burst_len = 625;
 		cfg.rxFullScale = 32767.0; cfg.rssi_offset = -3.5; cfg.egprs = false; cfg.trxd_version = -1; cfg.depth = 4;
-		cfg.exact_demod = atoi(argv[7]) != 0;
+		cfg.exact_demod = atoi(argv[7]) == 1;                       /* 0: fused, 1: bit-exact kernel, 2: cfg->use_va (Viterbi receiver) */
+		cfg.use_va = atoi(argv[7]) == 2;
 		BurstGatherer g(cfg);
 		if (!g.start()) { fprintf(stderr, "BurstGatherer::start failed\n"); return 5; }
 #pragma pack(push, 1)

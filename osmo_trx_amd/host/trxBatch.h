@@ -105,6 +105,10 @@ struct BurstGathererConfig {
 	int devices[TRX_GATHERER_MAX_DEVICES];
 	bool exact_demod;         /* TRXHIP_FLAG_EXACT_DEMOD: the reference's two FIR stages, soft bits bit-identical to generic C
 	                           * (default false: the fused demodulator, include/trxhip.h) */
+	bool use_va;              /* cfg->use_va ("viterbi-eq", Transceiver.cpp:760-787): pushed bursts are what the radio read 20
+	                           * samples early (osmo-trx.cpp:87-100); power from them as read, detection on the shifted copy, soft
+	                           * bits from scaleVector(1/16383) + demodAnyBurst_va() -- all on the GPU, one batch = one stream
+	                           * (TRXHIP_FLAG_USE_VA of the host pipe).  Not with exact_demod (there is no filter demodulator). */
 };
 class BurstGatherer {
 public:

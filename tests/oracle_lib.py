@@ -302,7 +302,7 @@ class UlBurstInd(C.Structure):
                 ("tsc", C.c_uint8), ("ci", C.c_float)]
 
 
-def pull_radio_vector_chain(iq, params, chans, muted=-1, full_scale=32767.0, rssi_offset=0.0):
+def pull_radio_vector_chain(iq, params, chans, muted=-1, full_scale=32767.0, rssi_offset=0.0, use_va=False):
     """Transceiver::pullRadioVector() for a schedule of slots (burst i on channel i % chans, fn = i // chans, tn = i & 7): the
     oracle's DSP per burst (energyDetect -> detectAnyBurst -> demodAnyBurst) inside the restated wrapper with one
     orc_rx_state per channel.  Returns a list of (code, UlBurstInd, rx_clipping, rx_no_burst_detected) in input order."""
@@ -325,7 +325,18 @@ def pull_radio_vector_chain(iq, params, chans, muted=-1, full_scale=32767.0, rss
         rc, nsoft, pw = 0, 0, 0.0
         if typ != OFF:
             pw = float(L.orc_energy_detect(x.ctypes.data, 625, 80))
-            if typ != IDLE:
+            if typ != IDLE and use_va:
+                # cfg->use_va (Transceiver.cpp:760-787): detection on the copy shifted by 20 samples (zeros behind), soft bits
+                # from scaleVector(1 / 16383) + demodAnyBurst_va() on the burst as read
+                xs = np.zeros_like(x)
+                xs[:625 - 40] = x[20:625 - 20]
+                rc = L.orc_detect_any_burst(xs.ctypes.data, 625, tsc, 4.0, 4, typ, max_toa, C.byref(ebp))
+                if rc > 0:
+                    xc = np.ascontiguousarray(x.view(np.complex64).reshape(625))
+                    _, va = demod_any_burst_va(xc, rc, tsc, max_toa)
+                    soft[:156] = va[:156]
+                    nsoft = 156
+            elif typ != IDLE:
                 rc = L.orc_detect_any_burst(x.ctypes.data, 625, tsc, 4.0, 4, typ, max_toa, C.byref(ebp))
                 if rc > 0:
                     nsoft = L.orc_demod_any_burst(x.ctypes.data, 625, rc, 4, C.byref(ebp), soft.ctypes.data)
