@@ -663,6 +663,9 @@ frontend_fused_kernel(const uint4 *__restrict__ in4, size_t n_total, c32 *__rest
 #pragma unroll
 				for (int v = 0; v < CH_J + CH_H - 1; v++)
 					x[v] = ch_lds(&xs[pp][v & 3][t + (v >> 2)]);
+				// (round 5 measured these 16 wave-uniform taps as scalar operands of the packed multiplies, fetched per path through
+				// the scalar cache instead of LDS: 1.30 ms against 1.04 -- the s_load and its lgkmcnt wait sit in front of every
+				// path's sums; profiles/r05_ab_runs.txt)
 				const float2 *g2 = reinterpret_cast<const float2 *>(&taps[pp][0]);
 				ch_v2f acc[CH_J];
 #pragma unroll

@@ -108,6 +108,14 @@ int trxhip_create_from_tables(trxhip_ctx **out, int device, const void *h_blob, 
 	const trx_tables *t = static_cast<const trx_tables *>(h_blob);
 	if (t->magic != TRX_TABLES_MAGIC || t->version != TRX_TABLES_VERSION)
 		return TRXHIP_EINVAL;
+	/* the exact delay filters of the kernels skip taps 0, 17, 18, 19: exactly 0.0f in every filter sigProcLibSetup() can
+	 * generate (the sinc LUT is zero beyond 8 pi, sigProcLib.cpp:990-998, :2164-2172).  A blob that breaks this is not such a
+	 * table set: refused rather than silently evaluated with 16 of its 20 taps.  (Non-finite samples: the
+	 * reference's x * 0 turns an Inf / NaN inside the 20-tap span into NaN where the skipped taps drop it -- complex64 input
+	 * only; int16 input is always finite.) */
+	for (int f = 0; f < TRX_DELAY_FILTS; f++)
+		if (t->delay_filt[f][0] != 0.0f || t->delay_filt[f][17] != 0.0f || t->delay_filt[f][18] != 0.0f || t->delay_filt[f][19] != 0.0f)
+			return TRXHIP_ENOTSUP;
 	int n = 0;
 	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n)
 		return TRXHIP_ENODEV;

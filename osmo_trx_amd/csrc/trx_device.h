@@ -1264,9 +1264,15 @@ __device__ __forceinline__ float edge_post(const c32 *dec, int n_dec, const trx_
 			// boundaries |y| = tan(pi/8) |x| instead of through the arc tangent: the same k except for a symbol within the
 			// arc tangent's own rounding of a boundary, where both neighbours are equally far and the error sum is the same
 			const float ax = fabsf(rot.x), ay = fabsf(rot.y);
-			int k = (ay <= 0.41421356237f * ax) ? 0 : (ax <= 0.41421356237f * ay) ? 2 : 1;
+			const float b1 = 0.41421356237f * ax, b2 = 0.41421356237f * ay;
+			int k = (ay <= b1) ? 0 : (ax <= b2) ? 2 : 1;
 			if (rot.x < 0.0f) k = 4 - k;
 			if (__builtin_signbit(rot.y)) k = -k;
+			// a symbol within 1e-5 of an octant boundary (or on an axis through zero, where the signs of +-0 decide): there the
+			// two forms may pick different neighbours -- equally far to 1e-7, but the error sum's last bits would differ.  Those
+			// (one symbol in ~1e4) are decided exactly as the reference does
+			if (fabsf(ay - b1) <= 1e-5f * ax || fabsf(ax - b2) <= 1e-5f * ay || ax == 0.0f || ay == 0.0f)
+				k = (int)roundf(atan2f(rot.y, rot.x) / tab->edge_step);
 			const trx_c32 id = tab->edge_ideal[k + 4];
 			const c32 e = make_float2(id.re - rot.x, id.im - rot.y);
 			err += norm2(e);

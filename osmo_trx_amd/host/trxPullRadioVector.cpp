@@ -8,7 +8,7 @@
 
 TRX_SHIM_NS_BEGIN
 
-RxChanState::RxChanState() : noise_itr(0), mNoiseLev(0.0f), mMuted(false), ctr_changed(false)
+RxChanState::RxChanState() : noise_itr(0), mNoiseLev(0.0f), mMuted(false), ctr_changed(false), use_rssi_offset(false), rssi_offset(0.0)
 {
 	for (size_t i = 0; i < TRX_NOISE_CNT; i++)
 		noises[i] = 0.0f;                                          /* std::vector<float>(size): value-initialised */
@@ -73,8 +73,9 @@ int trxPullRadioVector(BurstGatherer &g, RxChanState &st, size_t chan, struct tr
 		st.mNoiseLev = st.avgNoise();
 	}
 	/* :750-752, in double as there (rxFullScale double, avg / mNoiseLev float) */
-	bi->rssi = 20.0 * log10(cfg.rxFullScale / avg) + cfg.rssi_offset;
-	bi->noise = 20.0 * log10(cfg.rxFullScale / st.mNoiseLev) + cfg.rssi_offset;
+	const double rssi_offset = st.use_rssi_offset ? st.rssi_offset : cfg.rssi_offset;   /* rssiOffset(chan), :613-618 */
+	bi->rssi = 20.0 * log10(cfg.rxFullScale / avg) + rssi_offset;
+	bi->noise = 20.0 * log10(cfg.rxFullScale / st.mNoiseLev) + rssi_offset;
 	if (is_idle_slot) {                                                /* :754-755 */
 		bi->idle = true;
 		return 0;

@@ -65,6 +65,11 @@ struct RxChanState {
 	bool mMuted;                       /* TRXC "MUTE": idle indications, no power measurement (:719-721) */
 	struct { unsigned rx_empty_burst, rx_clipping, rx_no_burst_detected; } ctrs;
 	bool ctr_changed;                  /* set when a counter moved: the caller dispatches its rate-counter signal (:806-807) and clears it */
+	/* Transceiver::rssiOffset(chan) = mRadioInterface->rssiOffset(chan) + cfg->rssi_offset, per channel unless
+	 * force_rssi_offset is set (Transceiver.cpp:613-618, :750-752): set use_rssi_offset and rssi_offset to that sum for a
+	 * channel whose RX gain differs; otherwise the gatherer-wide BurstGathererConfig::rssi_offset applies */
+	bool use_rssi_offset;
+	double rssi_offset;
 	RxChanState();
 	bool insertNoise(float val);       /* avgVector::insert() */
 	float avgNoise() const;            /* avgVector::avg(): serial float sum over all 20 entries / 20 */
@@ -73,7 +78,7 @@ struct RxChanState {
 /** pullRadioVector(chan, bi).  Blocks until the channel's next burst has come back from the GPU.
  *  0: *bi filled (bi->idle for IDLE slots, misses and muted channels); -ENOENT: the slot is OFF (bi->fn / bi->tn filled,
  *  no power or noise update); -EIO: gatherer stopped or GPU error.  The gatherer must run in float mode
- *  (BurstGathererConfig::trxd_version = -1); rxFullScale and rssi_offset are the gatherer's. */
+ *  (BurstGathererConfig::trxd_version = -1); rxFullScale is the gatherer's, rssi_offset the channel's (RxChanState) or the gatherer's. */
 int trxPullRadioVector(BurstGatherer &g, RxChanState &st, size_t chan, struct trx_ul_burst_ind *bi);
 
 TRX_SHIM_NS_END

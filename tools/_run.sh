@@ -1,9 +1,4 @@
-for D in "" "0,0" "0,0,0,0"; do
-  export TRXHIP_DEVICES=$D; [ -z "$D" ] && unset TRXHIP_DEVICES
-  echo "TRXHIP_DEVICES=$D"
-  python tools/bench_gather.py 16 4096 200 1 256 4 4096
-  python tools/bench_gather.py 16 4096 200 1 256 8 4096
-  python tools/bench_gather.py 16 1024 200 1 256 8 4096
-done > gpurun_out/r05_gather0.log 2>&1
-nproc >> gpurun_out/r05_gather0.log
-cat gpurun_out/r05_gather0.log
+L=osmo_trx_amd/lib
+for r in 1 2; do for l in felds fesgpr; do echo "== $l"; TRXHIP_LIB=$PWD/$L/libtrxhip_$l.so python tools/bench_frontend.py 2>&1 | grep -i "fused\|front"; done; done > gpurun_out/r05_fe1.log 2>&1
+python -m pytest tests/test_gpu_aux_kernels.py -q -m gpu -x 2>&1 | tail -3 >> gpurun_out/r05_fe1.log
+cat gpurun_out/r05_fe1.log
