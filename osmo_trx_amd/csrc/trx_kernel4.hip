@@ -18,7 +18,10 @@
 //         outputs whose decimator window straddles those edges come from truncated-composite tables (or, in unusual
 //         geometries, the exact masked two-stage sum), so the result differs from the reference only by rounding and the
 //         dropped taps: TRXHIP_FUSED_SOFT_ATOL (include/trxhip.h: 1e-5 absolute on full scale 1; bar 1e-4).
-//     Detection (rc, TOA, amp, C/I) is shared and bit-exact in both modes.
+//     Detection: rc, TSC and TOA are identical to the reference's in both modes.  EXACT keeps every sum of the reference (amp and
+//     C/I bit-exact too); FUSED runs the FAST detector (round 5, trx_device.h peak_detect_fast): FMA interpolation rounds whose
+//     every early / late decision is certified by a proven margin or re-run exactly -- amp / C/I within TRXHIP_FAST_AMP_RTOL /
+//     TRXHIP_FAST_CI_ATOL_DB (include/trxhip.h).
 //   * occupancy: 16 waves per CU (4 per SIMD) -- per-wave LDS is cut to 7.7 KB (NARROW buffers, trx_device.h) and the
 //     kernel kept at 128 VGPRs.  A wave is one serial program per burst and a SIMD runs four: what counts is that all
 //     four stay resident to the end of the launch (waves CLAIM bursts, they are not dealt them) and the length of a
