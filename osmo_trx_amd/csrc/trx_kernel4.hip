@@ -108,7 +108,10 @@ __device__ __forceinline__ PhBase ph_bases(const c32 *P, int ph0, int m0)
 #define K4_NTP TRX_FUSED_NTP
 __device__ __forceinline__ void fir24x3(const PhBase &pb, const float4 *c4, v2f (&acc)[3])
 {
-	constexpr int D = 4, NV = K4_NT + 8;                            // samples v = 0 .. 31
+#ifndef K4_FIR_D
+#define K4_FIR_D 4
+#endif
+	constexpr int D = K4_FIR_D, NV = K4_NT + 8;                     // samples v = 0 .. 31; D (<= 7) reads ahead of the FMAs
 	c32 xw[16];
 	float4 cq[2];
 	cq[0] = c4[0];
@@ -760,8 +763,43 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 			if (sx.x + sy.y + sp + sq == 1.2345e-30f || ss == 0x7fffffff) energy += 1.0f;      // keep the results alive
 		}
 #endif
+		// The burst's result record (wave-uniform fields dropped into lanes 0..7 of one register; written by flush() at the top
+		// of the next burst).  Assembled in front of the demodulator when the straight-line one is about to run -- its ~25
+		// scalar and vector instructions then sit between the fetch of the low-edge tap rows (issued when the TOA was known)
+		// and the first use of those rows (TRX_EARLY_RECORD; the wait for the rows is 1.8 % of the kernel) -- else behind it.
+		auto assemble_record = [&]() {
+			const bool det = rc > 0;
+			pend_flags = (uint32_t)(det ? out_tsc : 0) | ((uint32_t)clip << 8) | ((uint32_t)idle << 16) | ((uint32_t)(nbits / 4) << 24);
+			pend_rc = rc;
+			pend_toa = det ? toa : 0.0f;
+			pend_ax = det ? amp.x : 0.0f;
+			pend_ay = det ? amp.y : 0.0f;
+			pend_ci = det ? ci : 0.0f;
+			pend_energy = energy;
+			pend_rssi = rssi;
+			{
+				int word = pend_rc;
+				word = put_lane<1>(word, pend_toa);                     // results of vector arithmetic: still in vector registers
+				word = write_lane<2>(word, __float_as_int(pend_ax));
+				word = write_lane<3>(word, __float_as_int(pend_ay));
+				word = put_lane<4>(word, pend_ci);
+				word = put_lane<5>(word, pend_energy);
+				word = put_lane<6>(word, pend_rssi);
+				word = write_lane<7>(word, (int)pend_flags);
+				pend_word = word;
+			}
+			pend_b = b;
+			pend_any = true;
+		};
+		bool record_done = false;
 		// ---- demodAnyBurst -> demodGmskBurst (:2055-2072) ----
 		if (COMMON && !EXACT && rc == TRXHIP_TSC && fast_nk != (1 << 30) && !fast_done && !ABL(0)) {
+#ifndef TRX_LATE_RECORD
+			nbits = 148;                                                // (what fast_demod() sets)
+			idle = 0;
+			assemble_record();
+			record_done = true;
+#endif
 			fast_demod();
 			fast_done = true;
 		}
@@ -1123,30 +1161,8 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 		}
 
 		DIAG_MARK(11);
-		{
-			const bool det = rc > 0;
-			pend_flags = (uint32_t)(det ? out_tsc : 0) | ((uint32_t)clip << 8) | ((uint32_t)idle << 16) | ((uint32_t)(nbits / 4) << 24);
-			pend_rc = rc;
-			pend_toa = det ? toa : 0.0f;
-			pend_ax = det ? amp.x : 0.0f;
-			pend_ay = det ? amp.y : 0.0f;
-			pend_ci = det ? ci : 0.0f;
-			pend_energy = energy;
-			pend_rssi = rssi;
-			{
-				int word = pend_rc;
-				word = put_lane<1>(word, pend_toa);                     // results of vector arithmetic: still in vector registers
-				word = write_lane<2>(word, __float_as_int(pend_ax));
-				word = write_lane<3>(word, __float_as_int(pend_ay));
-				word = put_lane<4>(word, pend_ci);
-				word = put_lane<5>(word, pend_energy);
-				word = put_lane<6>(word, pend_rssi);
-				word = write_lane<7>(word, (int)pend_flags);
-				pend_word = word;
-			}
-			pend_b = b;
-			pend_any = true;
-		}
+		if (!record_done)
+			assemble_record();
 		DIAG_MARK(12);
 	}
 	flush(lane);

@@ -1,2 +1,4 @@
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
-python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "edge or fuzz" 2>&1 | tail -3
+L=osmo_trx_amd/lib
+bash tools/pmc_insts.sh $L/libtrxhip_late.so $L/libtrxhip_early.so > gpurun_out/r05_pmc9.log 2>&1
+bash tools/ab_multi.sh 3 30 $L/libtrxhip_late.so $L/libtrxhip_early.so $L/libtrxhip_d6.so $L/libtrxhip_d2.so > gpurun_out/r05_ab9.log 2>&1
+cat gpurun_out/r05_pmc9.log gpurun_out/r05_ab9.log
