@@ -348,6 +348,9 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 	c32 pre_c[CF32 ? NLD : 1];
 	uint32_t pre_prm = 0u;
 	auto prefetch = [&](unsigned bb) {
+#ifdef TRX_WHATIF_L2INPUT   /* timing only (tools/): every burst reads one of the first 4096 (cache-resident input): what HBM latency costs */
+		bb &= 4095u;
+#endif
 		pre_prm = reinterpret_cast<const uint32_t *>(params)[2 * (size_t)bb];
 		if (CF32) {
 			const c32 *src = reinterpret_cast<const c32 *>(iq_) + (size_t)bb * L;

@@ -1,4 +1,3 @@
 L=osmo_trx_amd/lib
-bash tools/pmc_insts.sh $L/libtrxhip_late.so $L/libtrxhip_early.so > gpurun_out/r05_pmc9.log 2>&1
-bash tools/ab_multi.sh 3 30 $L/libtrxhip_late.so $L/libtrxhip_early.so $L/libtrxhip_d6.so $L/libtrxhip_d2.so > gpurun_out/r05_ab9.log 2>&1
-cat gpurun_out/r05_pmc9.log gpurun_out/r05_ab9.log
+for l in cur l2in cur l2in; do TRXHIP_LIB=$PWD/$L/libtrxhip_$l.so python3 bench.py --main-only --steps 30 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); s=d['config']['sustained']; print('$l', d['value'], d['roofline']['kernel_ms'], s['mbursts_per_s_all_gpus'], s['sclk_mhz_under_load'])"; done > gpurun_out/r05_ab11.log 2>&1
+cat gpurun_out/r05_ab11.log
