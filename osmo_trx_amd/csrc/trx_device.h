@@ -792,7 +792,9 @@ __device__ __forceinline__ void peak_detect_fast(const c32 *cz, int max_idx, flo
 	int final_ix = E + 512;
 	if (!unsure) {
 		const int ixb = E + pc.offB;
-		const c32 pv = interp_taps_fma(cz + ((ixb >> 9) - 7), sincv + sinc_base_lo(ixb & 511), sincv + sinc_base_hi(ixb & 511));
+		c32 pv = make_float2(0.0f, 0.0f);
+		if (lane < 30 || (lane >= 32 && lane < 48))                      // 15 nodes x {early, late} + 16 final positions: 18 lanes idle
+			pv = interp_taps_fma(cz + ((ixb >> 9) - 7), sincv + sinc_base_lo(ixb & 511), sincv + sinc_base_hi(ixb & 511));
 		const int offB = walk_tree_fast<4>(norm2(pv), km, 8, unsure);
 		E += offB;
 		final_ix = E + 512;
@@ -1041,7 +1043,10 @@ __device__ __forceinline__ int detect_burst_h(const c32 *sig, int sig_len, c32 *
 		pair = true;
 		const int l2 = lane < 40 ? 2 * lane : 78;
 		trx_v2f a0, a1;
-		corr_unit_pair40(unit_slot, sig + (l2 + start - 39), a0, a1);
+		a0 = (trx_v2f){ 0.0f, 0.0f };
+		a1 = a0;
+		if (lane < 40)
+			corr_unit_pair40(unit_slot, sig + (l2 + start - 39), a0, a1);
 		const bool in0 = lane < 40 && l2 < len, in1 = lane < 40 && l2 + 1 < len;
 		// lags >= len are not part of the correlation: zeros (cz[len ..] is the right zero pad)
 		const float4 y = make_float4(in0 ? a0.x : 0.0f, in0 ? a0.y : 0.0f, in1 ? a1.x : 0.0f, in1 ? a1.y : 0.0f);
@@ -1057,9 +1062,11 @@ __device__ __forceinline__ int detect_burst_h(const c32 *sig, int sig_len, c32 *
 	} else if (PADDED && unit_slot >= 0 && len + TRX_CZ_PAD <= WAVE && start + WAVE <= sig_len + 4) {
 		// one round (normal bursts: len <= 49): lane = lag, and the twelve lanes behind the window write the right zero pad in
 		// the SAME store (an LDS store costs three reads); what they correlated -- real samples further on -- is discarded
-		const trx_v2f acc = corr_unit(unit_slot, sig + (lane + start - (N - 1)));
 		const bool in = lane < len;
-		const c32 y = make_float2(in ? acc.x : 0.0f, in ? acc.y : 0.0f);
+		trx_v2f acc = { 0.0f, 0.0f };
+		if (in)                                                         // (idle lanes neither read nor add: LDS time and power)
+			acc = corr_unit(unit_slot, sig + (lane + start - (N - 1)));
+		const c32 y = make_float2(acc.x, acc.y);
 		if (lane < len + TRX_CZ_PAD)
 			cz[lane] = y;
 		const float v = norm2(y);

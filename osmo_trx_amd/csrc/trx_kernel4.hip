@@ -628,9 +628,15 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 					const int len = 16 + max_toa;
 					__builtin_assume(len >= 16 && len <= 49);
 					{
-						const c32 y = decimate16_sym<!EXACT>(P + PH_M0 + (56 + lane) - 4, gdec);
-						dec[56 + lane] = y;
-						unit_bad |= (__ballot(unit_unsafe(y) && lane < 15 + len) != 0ull) ? 1 : 0;
+						// only the 15 + len lanes whose samples the window reads are active: the others would move 16 samples
+						// each through the LDS and multiply them for nothing -- same instruction count, less LDS time and
+						// less power (the kernel runs at its power limit, DESIGN.md 4.1 "Round 5")
+						c32 y = make_float2(0.0f, 0.0f);
+						if (lane < 15 + len) {
+							y = decimate16_sym<!EXACT>(P + PH_M0 + (56 + lane) - 4, gdec);
+							dec[56 + lane] = y;
+						}
+						unit_bad |= (__ballot(lane < 15 + len && unit_unsafe(y)) != 0ull) ? 1 : 0;
 						wave_sync();
 					}
 					DIAG_MARK(2);
@@ -657,9 +663,11 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 #pragma unroll
 					for (int r = 0; r < 2; r++) {
 						const int i = lane + r * WAVE;                          // < 128 <= TRX_DEC_NARROW
-						const c32 y = decimate16_sym<!EXACT>(P + PH_M0 + i - 4, gdec);
-						dec[i] = y;
-						bad |= unit_unsafe(y) && i < 39 + len;
+						if (i < 39 + len) {                                     // (the lanes behind the window stay idle)
+							const c32 y = decimate16_sym<!EXACT>(P + PH_M0 + i - 4, gdec);
+							dec[i] = y;
+							bad |= unit_unsafe(y);
+						}
 					}
 					unit_bad |= (__ballot(bad) != 0ull) ? 1 : 0;
 					wave_sync();
@@ -1043,7 +1051,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 					if (ic > i_max - 2) ic = i_max - 2;
 					const PhBase pb = ph_bases(P, c & 3, ic + (c >> 2));
 					v2f acc[3] = { { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f } };
-					if (!ABL(5))
+					if (!ABL(5) && lane < 52)                                   // 52 lanes x 3 outputs = 156; the rest would compute discarded values
 						fir24x3(pb, c4, acc);
 					DIAG_MARK(10);
 					// the 1-SPS symbols go through dec[] (free once detection is done; the 8-PSK tail wants them there
