@@ -630,9 +630,7 @@ __device__ __forceinline__ void peak_detect_spec(const c32 *cz, int max_idx, con
 	if (!tie) {
 		// ---- round B: levels 5..8 (incr = 1/64 .. 1/512) on lanes 0..29, the 16 possible final
 		// positions (earlyIndex + 1) on lanes 32..47
-		c32 pv = make_float2(0.0f, 0.0f);
-		if (lane < 30 || (lane >= 32 && lane < 48))      // 15 nodes x {early, late} + 16 final positions: the other 18 lanes stay idle (power)
-			pv = interp_point(cz, E + pc.offB, sincv);
+		const c32 pv = interp_point(cz, E + pc.offB, sincv);
 		const float nv = norm2(pv);
 		const int offB = walk_tree<4>(nv, 8, tie);
 		E += offB;

@@ -905,7 +905,6 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 #pragma unroll
 					for (int j = 0; j < R; j++)
 						ya[j] = (v2f){ 0.0f, 0.0f };
-					if (lc == lane) {       // lanes whose twelve outputs lie outside the burst stay idle (they used to compute discarded values: power)
 #pragma unroll
 					for (int j = K0; j < K0 + R - 1 + D; j++) {
 						const c32 t = lds_c32(pb.p[j & 3] + (j >> 2));
@@ -935,7 +934,6 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 						if ((k & 1) && k + 1 < K1)
 							hq = hp2[(k + 1) >> 1];
 						__builtin_amdgcn_sched_barrier(0);
-					}
 					}
 #pragma unroll
 					for (int j = 0; j < R; j++)
