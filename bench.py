@@ -598,7 +598,8 @@ def main():
             "roofline": {
                 # `bound` names the roofline the fraction is priced against (the measurement contract: HBM bytes); what limits
                 # the kernel in practice is in `compute` -- the vector ALU's issue rate, not HBM
-                "bound": "hbm", "bound_note": "valu-issue in practice (see compute): `bound` names the roofline `frac` is priced against",
+                "bound": "hbm", "bound_note": "valu-issue in practice, at the chip's power limit (see compute, and config.sustained.sclk_mhz_under_load "
+                                              "of 2400 MHz): `bound` names the roofline `frac` is priced against",
                 "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,
                 "compute": compute,
