@@ -623,16 +623,23 @@ frontend_fused_kernel(const uint4 *__restrict__ in4, size_t n_total, c32 *__rest
 	const size_t tile_hi = (tile_lo + per_wg < n_tiles) ? tile_lo + per_wg : n_tiles;
 	uint4 pre[4];
 	auto prefetch = [&](size_t tile) {
+		// staged step j (0 <= j < n_stage) is wideband step t0 + j.  Everything that depends on the tile is wave-uniform: the
+		// range [jlo, jhi) of steps inside the stream and a base pointer; a thread adds its 32-bit j.  (Round 5: the 64-bit
+		// per-thread step numbers this replaces were spilled to scratch, and every reload waited for vmcnt(0) -- for the
+		// previous tile's output stores -- in the middle of the tile loop.)
 		const long long t0 = (long long)tile * tile_in - 30;               // first staged wideband step
+		const long long lo = t0 < 0 ? -t0 : 0, hi = (long long)n_total - t0;
+		const int jlo = (int)(lo < n_stage ? lo : n_stage), jhi = (int)(hi < 0 ? 0 : (hi < n_stage ? hi : n_stage));
+		const uint4 *const base = in4 + t0;                                 // (dereferenced for jlo <= j < jhi only)
+		const int hoff = (int)((CH_H - 1) + t0);                            // tile 0: steps -15 .. -1 come from the carried history
 #pragma unroll
 		for (int i = 0; i < 4; i++) {
 			const int j = i * CH_TPB + t;
-			const long long ts = t0 + j;
 			uint4 v = make_uint4(0u, 0u, 0u, 0u);
-			if (j < n_stage) {
-				if (ts >= 0) { if ((size_t)ts < n_total) v = in4[ts]; }
-				else if (ts >= -(CH_H - 1) && wide_hist) v = wide_hist[(CH_H - 1) + ts];   // carried history: steps -15 .. -1
-			}
+			if (j >= jlo && j < jhi)
+				v = base[j];
+			else if (j < jlo && hoff + j >= 0 && wide_hist)
+				v = wide_hist[hoff + j];
 			pre[i] = v;
 		}
 	};
@@ -733,9 +740,10 @@ frontend_fused_kernel(const uint4 *__restrict__ in4, size_t n_total, c32 *__rest
 				// all four channels of an output position per pass: four independent sum chains over the same taps and offsets,
 				// 16 LDS reads in flight per block of four taps
 				const c32 *xa = cs + n_t;
-				c32 *ya = out + o0 + t;
-				size_t oo = o0 + t;
-				for (int it = 0; it < iters && oo < n_out; it++, oo += S, xa += nstep, ya += S) {
+				c32 *const ob = out + o0;                                   // wave-uniform base; the thread adds a 32-bit offset
+				unsigned yo = (unsigned)t;                                  // (a per-thread 64-bit pointer here was spilled and reloaded --
+				size_t oo = o0 + t;                                         // behind a vmcnt(0) wait -- once per tile)
+				for (int it = 0; it < iters && oo < n_out; it++, oo += S, xa += nstep, yo += (unsigned)S) {
 					ch_v2f acc[CH_M];
 #pragma unroll
 					for (int c = 0; c < CH_M; c++)
@@ -759,7 +767,7 @@ frontend_fused_kernel(const uint4 *__restrict__ in4, size_t n_total, c32 *__rest
 					}
 #pragma unroll
 					for (int c = 0; c < CH_M; c++)
-						ya[c * out_stride] = make_float2(acc[c].x, acc[c].y);
+						(ob + (size_t)c * out_stride)[yo] = make_float2(acc[c].x, acc[c].y);
 				}
 			}
 		}
