@@ -618,6 +618,19 @@ frontend_fused_kernel(const uint4 *__restrict__ in4, size_t n_total, c32 *__rest
 	const int n_t = (int)(qt / (unsigned)p), path_t = (int)(qt % (unsigned)p);
 	const int nstep = q * m;
 
+	// The residues S - 256 .. S - 1 of every resampler step (all channels) are swept item by item.  Which output, which filter
+	// path and which input sample an item is depends on the item alone, not on the tile: worked out once, here, and parked in
+	// LDS as two packed words -- per tile the four integer divisions (~ 160 instructions on the waves that hold items, which
+	// the other waves of the workgroup then wait for at the next barrier) become one 8-byte read.
+	const int n_res = (S - CH_TPB) * iters * CH_M;
+	int2 *const res_item = reinterpret_cast<int2 *>(rtaps + 16 * pst);
+	for (int idx = t; idx < n_res; idx += CH_TPB) {
+		const int nres0 = S - CH_TPB;
+		const int c = idx / (nres0 * iters), r = idx % (nres0 * iters);
+		const int oi = CH_TPB + r % nres0 + S * (r / nres0);
+		const unsigned qi = (unsigned)q * (unsigned)oi;
+		res_item[idx] = make_int2((c << 16) | (int)(qi / (unsigned)p), (oi << 16) | (int)(qi % (unsigned)p));
+	}
 	const size_t per_wg = (n_tiles + gridDim.x - 1) / gridDim.x;
 	const size_t tile_lo = (size_t)blockIdx.x * per_wg;
 	const size_t tile_hi = (tile_lo + per_wg < n_tiles) ? tile_lo + per_wg : n_tiles;
@@ -632,6 +645,21 @@ frontend_fused_kernel(const uint4 *__restrict__ in4, size_t n_total, c32 *__rest
 		const int jlo = (int)(lo < n_stage ? lo : n_stage), jhi = (int)(hi < 0 ? 0 : (hi < n_stage ? hi : n_stage));
 		const uint4 *const base = in4 + t0;                                 // (dereferenced for jlo <= j < jhi only)
 		const int hoff = (int)((CH_H - 1) + t0);                            // tile 0: steps -15 .. -1 come from the carried history
+		if (jlo == 0 && jhi == n_stage) {
+			// a tile inside the stream (all but the first and the last): four unconditional loads.  A branch of its own, and
+			// wave-uniform -- with the edge cases as the other arm of a per-lane if, both arms ran one after the other in every
+			// wave, both wrote pre[i], and the compiler put an s_waitcnt vmcnt(0) between them: loads three and four of every
+			// tile waited for loads one and two to come back from HBM.
+			unsigned tt = (unsigned)t;                                       // opaque per tile: the four clamped offsets are three instructions
+			asm volatile("" : "+v"(tt));                                    // each to recompute, and 8 registers (spilled) to keep across tiles
+			const unsigned jmax = (unsigned)n_stage - 1u;
+#pragma unroll
+			for (int i = 0; i < 4; i++) {
+				const unsigned j = (unsigned)(i * CH_TPB) + tt;
+				pre[i] = base[j < jmax ? j : jmax];                            // (j >= n_stage is never staged)
+			}
+			return;
+		}
 #pragma unroll
 		for (int i = 0; i < 4; i++) {
 			const int j = i * CH_TPB + t;
@@ -771,24 +799,19 @@ frontend_fused_kernel(const uint4 *__restrict__ in4, size_t n_total, c32 *__rest
 				}
 			}
 		}
-		const int nres = S - CH_TPB;                                       // residues of every step, all channels
-		for (int idx = t; idx < nres * iters * CH_M; idx += CH_TPB) {
-			const int c = idx / (nres * iters), r = idx % (nres * iters);
-			const int oi = CH_TPB + r % nres + S * (r / nres);
+		for (int idx = t; idx < n_res; idx += CH_TPB) {                    // residues of every step, all channels
+			const int2 e = res_item[idx];
+			const int c = e.x >> 16, n = e.x & 0xffff, oi = e.y >> 16, path = e.y & 0xffff;
 			if (o0 + oi >= n_out)
 				continue;
-			const unsigned qi = (unsigned)q * (unsigned)oi;
-			const int n = (int)(qi / (unsigned)p), path = (int)(qi % (unsigned)p);
 			const c32 *xp = cs + c * FE_CS + n;
-			float yr = 0.0f, yi = 0.0f;
+			ch_v2f acc = { 0.0f, 0.0f };                                    // product, then sum, k ascending, on both components at once:
 #pragma unroll
-			for (int k = 0; k < 16; k++) {
-				const c32 xv = xp[k];
+			for (int k = 0; k < 16; k++) {                                  // the two roundings per tap of yr += x.x * h, yi += x.y * h
 				const float h = rtaps[k * pst + path];
-				yr += xv.x * h;
-				yi += xv.y * h;
+				acc = acc + ch_lds(xp + k) * (ch_v2f){ h, h };
 			}
-			out[c * out_stride + o0 + oi] = make_float2(yr, yi);
+			out[c * out_stride + o0 + oi] = make_float2(acc.x, acc.y);
 		}
 		if (chan_hist_out && tile + 1 == n_tiles && t < CH_M * 15) {        // the call's last 15 channel samples
 			const long long j = (long long)n_total - (long long)tile * tile_in + (t % 15);   // time n_total - 15 + i -> cs index
@@ -809,7 +832,10 @@ extern "C" int trx_launch_frontend_fused(const int16_t *d_wide, float *d_out, si
 		return 1;
 	const size_t n_tiles = (n_out + (size_t)p * tm - 1) / ((size_t)p * tm);
 	size_t gx = n_tiles < 1024 ? n_tiles : 1024;                         // 4 workgroups of 34 KB LDS per CU, each a run of tiles
-	const size_t lds = (size_t)16 * (p + 1) * sizeof(float);
+	const size_t n_res = (size_t)(p * m - CH_TPB) * (tm / m) * CH_M;    // residue items per tile (80 at 65 / 48)
+	if (n_res > 1024)
+		return 1;
+	const size_t lds = (size_t)16 * (p + 1) * sizeof(float) + n_res * sizeof(int2);   // resampler taps + the residue items
 	hipLaunchKernelGGL(frontend_fused_kernel, dim3((unsigned)gx), dim3(CH_TPB), lds, stream, reinterpret_cast<const uint4 *>(d_wide),
 			   n_total, reinterpret_cast<c32 *>(d_out), n_out, out_stride, p, q, tm, m, n_tiles, parts, d_tab,
 			   reinterpret_cast<const uint4 *>(d_wide_hist_io), reinterpret_cast<const c32 *>(d_chan_hist_in),
