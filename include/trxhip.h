@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TRXHIP_ABI_VERSION 4
+#define TRXHIP_ABI_VERSION 5
 
 /* error codes */
 #define TRXHIP_OK          0
@@ -339,6 +339,22 @@ int  trxhip_hostpipe_submit(trxhip_hostpipe *p, int slot, size_t n_bursts);
 int  trxhip_hostpipe_wait(trxhip_hostpipe *p, int slot);
 /* 0 = finished (or never submitted), 1 = still running, < 0 error */
 int  trxhip_hostpipe_query(trxhip_hostpipe *p, int slot);
+/* ---- bursts by reference (round 5): no CPU copy of the samples at all ----
+ * The reference cuts every burst out of the radio's receive ring with one CPU copy (radioInterface.cpp:272-291,
+ * unRadioifyVector into a new radioVector); writing the burst into slot.iq is that copy.  When the ring itself is
+ * registered with the pipe, a slot can instead carry one host POINTER per burst: submit_by_ref() uploads only
+ * [params][meta], and a device kernel fetches the n bursts from the ring over the link (burst_len x 4 bytes from
+ * each pointer, x n_paths with diversity) into the slot's device buffer; everything behind is trxhip_hostpipe_submit().
+ * Contract: every src[i] is 4-byte aligned and lies, with its whole burst, inside one registered range (TRXHIP_EINVAL
+ * otherwise, nothing enqueued); the samples stay unchanged until wait() on the slot has returned.
+ * register_host: pins [base, base + bytes) and maps it into the device's address space (hipHostRegister; a range some
+ * other pipe of the process has registered already is shared); at most 8 ranges per pipe; unregister_host (or destroy)
+ * releases what this pipe pinned -- no slot that refers to the range may be in flight. */
+int  trxhip_hostpipe_register_host(trxhip_hostpipe *p, const void *base, size_t bytes);
+int  trxhip_hostpipe_unregister_host(trxhip_hostpipe *p, const void *base);
+/* the slot's pointer array: max_bursts entries of pinned host memory, valid until trxhip_hostpipe_destroy() */
+int  trxhip_hostpipe_slot_sources(trxhip_hostpipe *p, int slot, const int16_t ***out_src);
+int  trxhip_hostpipe_submit_by_ref(trxhip_hostpipe *p, int slot, size_t n_bursts);
 /* Pageable buffers: n bursts are cut into slot-sized chunks, staged, processed with all slots in flight and copied
  * out.  h_meta / h_soft / h_pkt / h_pkt_len may be NULL (must be NULL when the pipe was created without them). */
 int  trxhip_hostpipe_run(trxhip_hostpipe *p, const int16_t *h_iq, const trxhip_burst_params *h_params,

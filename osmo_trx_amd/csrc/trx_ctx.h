@@ -35,6 +35,9 @@ extern "C" int trx_launch_pack_trxd_wire(const trxhip_burst_result *d_results, c
 					 int pkt_stride, uint16_t *d_pkt_len, size_t n_bursts, float rssi_offset, hipStream_t stream,
 					 trxhip_burst_result *d_results_copy);
 
+/* bursts by reference (trx_aux_kernels.hip): n bursts of `dwords` 4-byte words each from the device-side addresses d_src[] */
+extern "C" int trx_launch_gather_bursts(const unsigned long long *d_src, void *d_dst, size_t n, unsigned dwords, hipStream_t stream);
+
 static inline int with_device(const trxhip_ctx *ctx)
 {
 	return hipSetDevice(ctx->device) == hipSuccess ? 0 : TRXHIP_EIO;

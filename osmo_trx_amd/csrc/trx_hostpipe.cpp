@@ -26,6 +26,13 @@ struct trxhip_hostpipe {
 	int dev_soft_stride;               /* stride of the device-side soft rows (>= what the packer needs) */
 	size_t in_iq_off, in_meta_off;     /* [params][meta][bursts] inside the input blocks */
 	size_t out_soft_off;               /* [results][soft rows] inside the output blocks */
+	struct Region {                    /* host ranges registered for bursts by reference */
+		const char *base;
+		size_t bytes;
+		const char *dev_base;          /* the range's address on this pipe's device */
+		bool owned;                    /* pinned by this pipe (hipHostRegister): released by it */
+	} region[8];
+	int n_region;
 	struct Slot {
 		hipStream_t stream;
 		hipEvent_t done;
@@ -47,6 +54,8 @@ struct trxhip_hostpipe {
 		uint8_t *dv_pkt;               /* device-side addresses of the pinned h.pkt / h.pkt_len */
 		uint16_t *dv_pkt_len;
 		trxhip_burst_result *dv_results; /* ... of h.results (TRXD-only pipes: the packer delivers the records too) */
+		const int16_t **h_src;         /* by reference: the caller's host pointers (pinned, max_bursts) ... */
+		unsigned long long *h_src_dev, *dv_src_dev;   /* ... and their device-side addresses, read in place by the gather kernel */
 	} slot[16];
 };
 
@@ -114,6 +123,8 @@ int trxhip_hostpipe_create(trxhip_ctx *ctx, const trxhip_hostpipe_cfg *c, trxhip
 		     pin((void **)&sl.h_in, in_bytes) && dev((void **)&sl.d_in, in_bytes) &&
 		     hipHostGetDevicePointer((void **)&sl.dv_in, sl.h_in, 0) == hipSuccess &&
 		     pin((void **)&sl.h_out, out_bytes_h) && dev((void **)&sl.d_out, out_bytes_d) &&
+		     pin((void **)&sl.h_src, nb * sizeof(void *)) && pin((void **)&sl.h_src_dev, nb * sizeof(unsigned long long)) &&
+		     hipHostGetDevicePointer((void **)&sl.dv_src_dev, sl.h_src_dev, 0) == hipSuccess &&
 		     (np == 1 || (dev((void **)&sl.d_iq_sel, nb * c->burst_len * 4) && dev((void **)&sl.d_avg, nb * sizeof(float)))) &&
 		     (!use_va || (dev((void **)&sl.d_shift, nb * c->burst_len * 4) && dev((void **)&sl.d_cf, nb * c->burst_len * 8) &&
 				  (sl.d_avg || dev((void **)&sl.d_avg, nb * sizeof(float)))));
@@ -151,13 +162,16 @@ void trxhip_hostpipe_destroy(trxhip_hostpipe *p)
 	for (int s = 0; s < 16; s++) {
 		trxhip_hostpipe::Slot &sl = p->slot[s];
 		if (sl.stream) (void)hipStreamSynchronize(sl.stream);
-		void *hp[] = { sl.h_in, sl.h_out, sl.h.pkt, sl.h.pkt_len };
+		void *hp[] = { sl.h_in, sl.h_out, sl.h.pkt, sl.h.pkt_len, (void *)sl.h_src, sl.h_src_dev };
 		for (void *q : hp) if (q) (void)hipHostFree(q);
 		void *dp[] = { sl.d_in, sl.d_out, sl.d_iq_sel, sl.d_avg, sl.d_shift, sl.d_cf };
 		for (void *q : dp) if (q) (void)hipFree(q);
 		if (sl.done) (void)hipEventDestroy(sl.done);
 		if (sl.stream) (void)hipStreamDestroy(sl.stream);
 	}
+	for (int r = 0; r < p->n_region; r++)
+		if (p->region[r].owned)
+			(void)hipHostUnregister(const_cast<char *>(p->region[r].base));
 	delete p;
 }
 
@@ -179,30 +193,53 @@ int trxhip_hostpipe_set_levels(trxhip_hostpipe *p, float threshold, float full_s
 	return TRXHIP_OK;
 }
 
-int trxhip_hostpipe_submit(trxhip_hostpipe *p, int slot, size_t n)
+static int submit_slot(trxhip_hostpipe *p, int slot, size_t n, bool by_ref)
 {
 	if (!p || slot < 0 || slot >= p->cfg.depth || n > p->cfg.max_bursts)
 		return TRXHIP_EINVAL;
 	trxhip_hostpipe::Slot &sl = p->slot[slot];
 	if (sl.busy)
 		return TRXHIP_EINVAL;                                  /* wait() first */
+	const trxhip_hostpipe_cfg &c = p->cfg;
+	const size_t np = c.n_paths > 1 ? (size_t)c.n_paths : 1;
+	if (by_ref) {
+		/* host pointer -> device-side address, range by range (the last hit first: a radio has one ring); nothing is enqueued
+		 * unless every burst lies inside a registered range */
+		const size_t burst_bytes = np * (size_t)c.burst_len * 4;
+		int r = 0;
+		for (size_t i = 0; i < n; i++) {
+			const char *q = reinterpret_cast<const char *>(sl.h_src[i]);
+			bool in = false;
+			for (int k = 0; k < p->n_region && !in; k++) {
+				const trxhip_hostpipe::Region &g = p->region[(r + k) % p->n_region];
+				if (q >= g.base && (size_t)(q - g.base) <= g.bytes && g.bytes - (size_t)(q - g.base) >= burst_bytes) {
+					r = (r + k) % p->n_region;
+					in = true;
+				}
+			}
+			if (!in || (reinterpret_cast<uintptr_t>(q) & 3u))
+				return TRXHIP_EINVAL;
+			sl.h_src_dev[i] = (unsigned long long)reinterpret_cast<uintptr_t>(p->region[r].dev_base + (q - p->region[r].base));
+		}
+	}
 	sl.n = n;
 	sl.failed = false;
 	if (n == 0)
 		return TRXHIP_OK;
-	const trxhip_hostpipe_cfg &c = p->cfg;
 	if (with_device(p->ctx))
 		return TRXHIP_EIO;
 	hipStream_t st = sl.stream;
-	const size_t np = c.n_paths > 1 ? (size_t)c.n_paths : 1;
 	/* one upload: [params][meta][the n bursts] -- or none: a small batch is read by the kernels where it lies (pinned memory
 	 * is device-visible; the detector fetches every sample once, one burst ahead, so the link's latency is covered the way
 	 * HBM's is and the copy engine's start-up cost -- more than such a transfer itself -- is not paid) */
 	static const size_t zc_max = getenv("TRXHIP_HOSTPIPE_ZC") ? (size_t)atol(getenv("TRXHIP_HOSTPIPE_ZC")) : 1024;   /* bursts x paths */
-	const bool in_place = n * np <= zc_max;
+	const bool in_place = !by_ref && n * np <= zc_max;
 	const char *const in = in_place ? sl.dv_in : sl.d_in;
-	bool ok = in_place || hipMemcpyAsync(sl.d_in, sl.h_in, p->in_iq_off + n * np * c.burst_len * 4, hipMemcpyHostToDevice, st) == hipSuccess;
+	bool ok = in_place ||
+		  hipMemcpyAsync(sl.d_in, sl.h_in, p->in_iq_off + (by_ref ? 0 : n * np * c.burst_len * 4), hipMemcpyHostToDevice, st) == hipSuccess;
 	int rc = ok ? TRXHIP_OK : TRXHIP_EIO;
+	if (rc == TRXHIP_OK && by_ref)                               /* the n bursts, fetched through their pointers by the device */
+		rc = trx_launch_gather_bursts(sl.dv_src_dev, sl.d_iq, n, (unsigned)(np * (size_t)c.burst_len), st);
 	const int16_t *d_bursts = reinterpret_cast<const int16_t *>(in + p->in_iq_off);
 	const trxhip_burst_params *const d_params = reinterpret_cast<const trxhip_burst_params *>(in);
 	const trxhip_trxd_meta *const d_meta = reinterpret_cast<const trxhip_trxd_meta *>(in + p->in_meta_off);
@@ -253,6 +290,68 @@ int trxhip_hostpipe_submit(trxhip_hostpipe *p, int slot, size_t n)
 	sl.busy = true;                                            /* even on failure: wait() drains what was enqueued */
 	sl.failed = !ok;
 	return ok ? TRXHIP_OK : (rc != TRXHIP_OK ? rc : TRXHIP_EIO);
+}
+
+int trxhip_hostpipe_submit(trxhip_hostpipe *p, int slot, size_t n) { return submit_slot(p, slot, n, false); }
+int trxhip_hostpipe_submit_by_ref(trxhip_hostpipe *p, int slot, size_t n) { return submit_slot(p, slot, n, true); }
+
+int trxhip_hostpipe_slot_sources(trxhip_hostpipe *p, int slot, const int16_t ***out)
+{
+	if (!p || !out || slot < 0 || slot >= p->cfg.depth)
+		return TRXHIP_EINVAL;
+	*out = p->slot[slot].h_src;
+	return TRXHIP_OK;
+}
+
+int trxhip_hostpipe_register_host(trxhip_hostpipe *p, const void *base, size_t bytes)
+{
+	if (!p || !base || bytes == 0)
+		return TRXHIP_EINVAL;
+	if (p->n_region >= 8)
+		return TRXHIP_ENOMEM;
+	for (int r = 0; r < p->n_region; r++)
+		if (p->region[r].base == base)
+			return TRXHIP_EINVAL;
+	if (with_device(p->ctx))
+		return TRXHIP_EIO;
+	/* portable + mapped: every device of the process may read it.  Already registered (another pipe of a multi-device
+	 * gatherer, or the caller itself): shared, not owned */
+	const hipError_t e = hipHostRegister(const_cast<void *>(base), bytes, hipHostRegisterPortable | hipHostRegisterMapped);
+	if (e != hipSuccess)
+		(void)hipGetLastError();
+	if (e != hipSuccess && e != hipErrorHostMemoryAlreadyRegistered)
+		return TRXHIP_EIO;
+	void *dv = nullptr;
+	if (hipHostGetDevicePointer(&dv, const_cast<void *>(base), 0) != hipSuccess) {
+		(void)hipGetLastError();
+		if (e == hipSuccess)
+			(void)hipHostUnregister(const_cast<void *>(base));
+		return TRXHIP_EIO;
+	}
+	trxhip_hostpipe::Region &g = p->region[p->n_region++];
+	g.base = static_cast<const char *>(base);
+	g.bytes = bytes;
+	g.dev_base = static_cast<const char *>(dv);
+	g.owned = e == hipSuccess;
+	return TRXHIP_OK;
+}
+
+int trxhip_hostpipe_unregister_host(trxhip_hostpipe *p, const void *base)
+{
+	if (!p || !base)
+		return TRXHIP_EINVAL;
+	for (int r = 0; r < p->n_region; r++)
+		if (p->region[r].base == base) {
+			for (int s = 0; s < p->cfg.depth; s++)
+				if (p->slot[s].busy)
+					return TRXHIP_EINVAL;                      /* wait() first: a slot in flight may refer to the range */
+			(void)with_device(p->ctx);
+			if (p->region[r].owned)
+				(void)hipHostUnregister(const_cast<void *>(base));
+			p->region[r] = p->region[--p->n_region];
+			return TRXHIP_OK;
+		}
+	return TRXHIP_EINVAL;
 }
 
 int trxhip_hostpipe_wait(trxhip_hostpipe *p, int slot)

@@ -118,7 +118,8 @@ struct Chan {
 	std::mutex mu;
 	std::condition_variable cv;
 	std::vector<uint8_t> ring;                  /* fifo_depth x (sizeof(Entry) + payload) */
-	alignas(64) std::atomic<size_t> tail{0};    /* entries delivered so far (completion thread) */
+	alignas(64) std::atomic<size_t> tail{0};    /* entries delivered so far (the completion thread whose turn it is) */
+	std::atomic<uint64_t> deliver_seq{0};       /* sequence number of the batch that may write this ring next (several completers) */
 	std::atomic<int> waiting{0};                /* the consumer sleeps on cv (checked by the completion thread after publishing) */
 	alignas(64) size_t head = 0;                /* entries pulled so far (consumer's own) */
 	alignas(64) std::atomic<size_t> outstanding{0};     /* pushed and not yet pulled: the reference's FIFO occupancy */
@@ -131,7 +132,10 @@ struct Batch {
 	alignas(64) std::atomic<int64_t> first_ns{0};       /* arrival of the first burst (0 = none yet) */
 	trxhip_hostpipe_slot h;
 	uint32_t count = 0;                         /* final size once closed */
+	bool refused = false;                       /* submit returned an error: every burst of the batch is delivered with -EIO */
+	uint64_t seq = 0;                           /* position in submission order, taken when a completion thread picks the batch up */
 	uint32_t epoch = 1;                         /* bumped per reuse: what Slot::ready must equal */
+	const int16_t **src = nullptr;              /* by_reference: the slot's pointer array (trxhip_hostpipe_slot_sources) */
 	std::vector<Slot> slot;
 };
 }  // namespace
@@ -146,18 +150,23 @@ struct BurstGatherer::Impl {
 		std::atomic<uint64_t> n_batches{0};
 	};
 	std::vector<Dev> dev;
+	std::vector<std::pair<const void *, size_t>> ranges;   /* registerBuffer(): applied to every pipe at start() */
 	std::mutex life_mu;                         /* start() / stop() against each other */
-	std::atomic<int> users{0};                  /* threads inside pushSlot() / pull() */
+	/* threads inside pushSlot() / pull(), counted on 64 cache lines: a consumer counts itself on its channel's line, a producer
+	 * on its first channel's -- one shared word here was two contended read-modify-writes per call for every producer and
+	 * consumer of the process, and bounded the whole stage at ~ 10 M calls/s (round 5, profiles/r05_gather.txt) */
+	struct alignas(64) UserLine { std::atomic<int> n{0}; };
+	UserLine users[64];
 	std::atomic<bool> reconfig{false};          /* start() is replacing pipes, batches and rings: entrants leave at once */
 	struct User {                               /* entry ticket of pushSlot() / pull() */
-		Impl &m;
+		std::atomic<int> &n;
 		bool ok;
-		explicit User(Impl &mm) : m(mm)
+		User(Impl &m, size_t line) : n(m.users[line & 63].n)
 		{
-			m.users.fetch_add(1, std::memory_order_seq_cst);
+			n.fetch_add(1, std::memory_order_seq_cst);
 			ok = !m.reconfig.load(std::memory_order_seq_cst);
 		}
-		~User() { m.users.fetch_sub(1, std::memory_order_seq_cst); }
+		~User() { n.fetch_sub(1, std::memory_order_seq_cst); }
 	};
 	trxhip_hostpipe *pipe_of(int b) const { return dev[(size_t)b % dev.size()].pipe; }
 	int slot_of(int b) const { return b / (int)dev.size(); }
@@ -179,7 +188,9 @@ struct BurstGatherer::Impl {
 	std::deque<int> free_q, closed_q, flight_q;
 	std::atomic<bool> stopping{false}, running{false};
 	bool submitter_done = false;                /* under mu: nothing more will enter flight_q */
-	std::thread submitter, completer;
+	std::thread submitter;
+	std::vector<std::thread> completers;        /* one per device entry (or cfg.n_completers): see complete_loop() */
+	uint64_t next_seq = 0;                      /* under mu */
 	std::atomic<uint64_t> n_batches{0}, n_dropped{0}, n_rejected{0};
 
 	/* make parked batch s the open one (caller holds mu, filling < 0 or being replaced): the ONLY place a batch is re-armed */
@@ -225,7 +236,10 @@ struct BurstGatherer::Impl {
 				for (uint32_t i = 0; i < b.count; i++)                       /* a producer may still be inside its memcpy */
 					while (b.slot[i].ready.load(std::memory_order_acquire) != b.epoch)
 						std::this_thread::yield();
-				(void)trxhip_hostpipe_submit(pipe_of(s), slot_of(s), b.count);   /* a failure surfaces in wait() */
+				/* a failure surfaces in wait() -- except a refused by-reference batch (a burst outside the registered ranges:
+				 * nothing was enqueued), which is remembered here */
+				b.refused = (cfg.by_reference ? trxhip_hostpipe_submit_by_ref(pipe_of(s), slot_of(s), b.count)
+							      : trxhip_hostpipe_submit(pipe_of(s), slot_of(s), b.count)) != TRXHIP_OK;
 				dev[(size_t)s % dev.size()].n_batches++;
 				lk.lock();
 				n_batches++;
@@ -263,8 +277,10 @@ struct BurstGatherer::Impl {
 			const int s = flight_q.front();
 			flight_q.pop_front();
 			Batch &b = batch[s];
+			b.seq = next_seq++;                                    /* flight_q is in submission order: so are the tickets */
+			const uint64_t seq = b.seq;
 			lk.unlock();
-			const bool ok = trxhip_hostpipe_wait(pipe_of(s), slot_of(s)) == TRXHIP_OK;
+			const bool ok = trxhip_hostpipe_wait(pipe_of(s), slot_of(s)) == TRXHIP_OK && !b.refused;
 			/* counting sort of the batch by channel (stable: arrival order within a channel is kept), then one lock and
 			 * one wake-up per channel */
 			const size_t nch = chan.size();
@@ -278,9 +294,16 @@ struct BurstGatherer::Impl {
 			for (uint32_t i = 0; i < b.count; i++)
 				order[fill[b.slot[i].r.chan]++] = i;
 			for (size_t c = 0; c < nch; c++) {
-				if (first[c] == first[c + 1])
-					continue;
 				Chan &ch = chan[c];
+				/* Several completion threads: each has waited for its own batch and sorted it on its own; the rings are
+				 * written in ticket order, channel by channel -- the thread of batch k + 1 follows one channel behind the
+				 * thread of batch k.  (One thread: the ticket is always the ring's turn.) */
+				for (unsigned spin = 0; ch.deliver_seq.load(std::memory_order_acquire) != seq; spin++)
+					if (spin > 64) std::this_thread::yield();
+				if (first[c] == first[c + 1]) {
+					ch.deliver_seq.store(seq + 1, std::memory_order_release);
+					continue;
+				}
 				size_t tail = ch.tail.load(std::memory_order_relaxed);
 				{
 					for (uint32_t k = first[c]; k < first[c + 1]; k++) {
@@ -305,6 +328,7 @@ struct BurstGatherer::Impl {
 					}
 				}
 				ch.tail.store(tail, std::memory_order_seq_cst);          /* publish; then look for a sleeping consumer */
+				ch.deliver_seq.store(seq + 1, std::memory_order_release);
 				if (ch.waiting.load(std::memory_order_seq_cst)) {
 					std::lock_guard<std::mutex> g(ch.mu);
 					ch.cv.notify_one();
@@ -392,8 +416,9 @@ bool BurstGatherer::start()
 	 * count themselves in `users`; with `reconfig` raised new entrants leave at once, the ones already inside finish (a
 	 * stopped gatherer blocks nobody: pull() on an empty FIFO returns -EIO, pushSlot() returns 0). */
 	m.reconfig.store(true, std::memory_order_seq_cst);
-	while (m.users.load(std::memory_order_seq_cst) != 0)
-		std::this_thread::yield();
+	for (const Impl::UserLine &u : m.users)
+		while (u.n.load(std::memory_order_seq_cst) != 0)
+			std::this_thread::yield();
 	struct Lower { std::atomic<bool> &f; ~Lower() { f.store(false, std::memory_order_seq_cst); } } lower{m.reconfig};
 
 	m.release_devices();                                           /* restart: the previous run's contexts, staging slots, streams */
@@ -411,6 +436,12 @@ bool BurstGatherer::start()
 			m.release_devices();
 			return false;
 		}
+		if (m.cfg.by_reference)
+			for (const auto &r : m.ranges)
+				if (trxhip_hostpipe_register_host(d.pipe, r.first, r.second) != TRXHIP_OK) {
+					m.release_devices();
+					return false;
+				}
 	}
 	m.stride = stride;
 	m.payload = payload;
@@ -421,6 +452,8 @@ bool BurstGatherer::start()
 	m.free_q.clear(); m.closed_q.clear(); m.flight_q.clear();
 	for (int s = 0; s < n_batch; s++) {
 		trxhip_hostpipe_slot_buffers(m.pipe_of(s), m.slot_of(s), &m.batch[s].h);
+		if (m.cfg.by_reference && trxhip_hostpipe_slot_sources(m.pipe_of(s), m.slot_of(s), &m.batch[s].src) != TRXHIP_OK)
+			return false;
 		m.batch[s].slot = std::vector<Slot>(m.cfg.max_batch);
 		for (size_t k = 0; k < m.cfg.max_batch; k++)
 			m.batch[s].slot[k].ready.store(0, std::memory_order_relaxed);
@@ -437,6 +470,7 @@ bool BurstGatherer::start()
 		ch.ring.assign(m.cfg.fifo_depth * m.entry_bytes, 0);
 		ch.head = 0;
 		ch.tail.store(0, std::memory_order_relaxed);
+		ch.deliver_seq.store(0, std::memory_order_relaxed);
 		ch.outstanding.store(0, std::memory_order_relaxed);
 	}
 	m.stopping = false;
@@ -444,7 +478,13 @@ bool BurstGatherer::start()
 	m.publish_locked(0);
 	m.running = true;
 	m.submitter = std::thread([&m] { m.submit_loop(); });
-	m.completer = std::thread([&m] { m.complete_loop(); });
+	m.next_seq = 0;
+	size_t n_compl = m.cfg.n_completers > 0 ? (size_t)m.cfg.n_completers : m.dev.size();
+	if (const char *e = getenv("TRXHIP_COMPLETERS")) if (atoi(e) > 0) n_compl = (size_t)atoi(e);
+	if (n_compl > 16) n_compl = 16;
+	m.completers.clear();
+	for (size_t k = 0; k < n_compl; k++)
+		m.completers.emplace_back([&m] { m.complete_loop(); });
 	return true;
 }
 
@@ -467,7 +507,9 @@ void BurstGatherer::stop()
 		m.submitter_done = true;
 		m.cv_done.notify_all();
 	}
-	m.completer.join();                                            /* delivers every batch that was submitted */
+	for (std::thread &t : m.completers)
+		t.join();                                                  /* they deliver every batch that was submitted */
+	m.completers.clear();
 	{
 		/* gathered but never submitted: discarded (pull() on an empty FIFO of a stopped gatherer returns -EIO) */
 		std::lock_guard<std::mutex> g(m.mu);
@@ -492,7 +534,7 @@ bool BurstGatherer::push(size_t c, const BurstRequest &rq)
 size_t BurstGatherer::pushSlot(const size_t *chans, const BurstRequest *rqs, size_t n, bool *accepted)
 {
 	Impl &m = *impl_;
-	Impl::User user(m);
+	Impl::User user(m, (chans && n) ? chans[0] : 0);
 	if (!user.ok || !chans || !rqs || n > 65535 || m.stopping || !m.running) {     /* (ok_idx[] holds 16-bit positions) */
 		if (accepted)
 			for (size_t k = 0; k < n; k++) accepted[k] = false;
@@ -572,9 +614,13 @@ size_t BurstGatherer::pushSlot(const size_t *chans, const BurstRequest *rqs, siz
 			r.type = (uint8_t)rq.type;
 			r.tn = rq.tn;
 			r.fn = rq.fn;
-			/* the burst goes straight into the pinned slot the DMA engine reads from */
-			const size_t burst_i16 = m.cfg.burst_len * 2 * (m.cfg.n_paths > 1 ? (size_t)m.cfg.n_paths : 1);
-			memcpy(b.h.iq + (size_t)idx * burst_i16, rq.iq, burst_i16 * sizeof(int16_t));
+			if (m.cfg.by_reference) {
+				b.src[idx] = rq.iq;                                     /* the device fetches it from the registered ring */
+			} else {
+				/* the burst goes straight into the pinned slot the DMA engine reads from */
+				const size_t burst_i16 = m.cfg.burst_len * 2 * (m.cfg.n_paths > 1 ? (size_t)m.cfg.n_paths : 1);
+				memcpy(b.h.iq + (size_t)idx * burst_i16, rq.iq, burst_i16 * sizeof(int16_t));
+			}
 			trxhip_burst_params &p = b.h.params[idx];
 			p.type = (uint8_t)rq.type;
 			p.tsc = (uint8_t)rq.tsc;
@@ -602,7 +648,7 @@ size_t BurstGatherer::pushSlot(const size_t *chans, const BurstRequest *rqs, siz
 int BurstGatherer::pull(size_t c, BurstIndication *bi, uint8_t *pkt, size_t *pkt_len)
 {
 	Impl &m = *impl_;
-	Impl::User user(m);
+	Impl::User user(m, c + 32);                                        /* (a channel's consumer and its producer on different lines) */
 	if (!user.ok || c >= m.chan.size() || !bi)
 		return -EIO;
 	Chan &ch = m.chan[c];
@@ -649,6 +695,16 @@ bool BurstGatherer::setTrxdVersion(size_t c, int version)
 	if (c >= m.chan.size())
 		return false;
 	m.chan[c].trxd_version.store(version, std::memory_order_relaxed);
+	return true;
+}
+
+bool BurstGatherer::registerBuffer(const void *base, size_t bytes)
+{
+	Impl &m = *impl_;
+	std::lock_guard<std::mutex> life(m.life_mu);
+	if (m.running || !m.cfg.by_reference || !base || bytes == 0 || m.ranges.size() >= 8)
+		return false;
+	m.ranges.emplace_back(base, bytes);
 	return true;
 }
 

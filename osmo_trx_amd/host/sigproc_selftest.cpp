@@ -255,13 +255,15 @@ int main(int argc, char **argv)
 		return 0;
 	}
 
-	// gather <iq.s16> <params.bin> <n> <chans> <max_batch> <timeout_us> <trxd_version|-1> <out.bin> [repeat [producers [fifo_depth]]]
+	// gather <iq.s16> <params.bin> <n> <chans> <max_batch> <timeout_us> <trxd_version|-1> <out.bin> [repeat [producers [fifo_depth [by_ref]]]]
+	// by_ref = 1: BurstGathererConfig::by_reference -- the loaded capture is registered as the "receive ring" and the producers
+	// push addresses into it (no CPU copy of the samples; the GPU fetches the gathered bursts over the link).
 	// `producers` threads (default: one per channel; the reference has one RxLower thread per radio device feeding all its
 	// channels) push the n bursts (burst i belongs to channel i % chans, fn = i / chans; channel c is fed by producer
 	// c % producers), `chans` consumer threads pull them back (pullRadioVector's role).  out.bin: per burst, in input order,
 	// {int32 code, int32 rc, float toa, float ci, float rssi, uint32 fn, uint32 tn|idle<<8|nbits<<16, uint32 pkt_len}
 	// followed by 456 bytes: the TRXD datagram (trxd_version >= 0) or the first 114 soft floats (-1).
-	if (!strcmp(argv[1], "gather") && argc >= 10 && argc <= 13) {
+	if (!strcmp(argv[1], "gather") && argc >= 10 && argc <= 14) {
 		std::vector<char> iq = slurp(argv[2]), pr = slurp(argv[3]);
 		const size_t n = atol(argv[4]), chans = atol(argv[5]);
 		const int repeat = argc >= 11 ? atoi(argv[10]) : 1;
@@ -280,7 +282,9 @@ int main(int argc, char **argv)
 		cfg.egprs = false;
 		cfg.trxd_version = atoi(argv[8]);
 		cfg.depth = 4;
+		cfg.by_reference = argc >= 14 && atoi(argv[13]) != 0;
 		BurstGatherer g(cfg);
+		if (cfg.by_reference && !g.registerBuffer(iq.data(), iq.size())) { fprintf(stderr, "BurstGatherer::registerBuffer failed\n"); return 5; }
 		if (!g.start()) { fprintf(stderr, "BurstGatherer::start failed\n"); return 5; }
 		struct Rec { int32_t code, rc; float toa, ci, rssi; uint32_t fn, misc, pkt_len; uint8_t body[456]; };
 		std::vector<Rec> rec(n);
@@ -343,9 +347,9 @@ int main(int argc, char **argv)
 		}
 		for (auto &t : th) t.join();
 		const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-		printf("gather bursts %zu seconds %.6f mbursts_per_s %.3f batches %llu push_retries %llu producers %zu consumers %zu fifo_depth %zu\n",
+		printf("gather bursts %zu seconds %.6f mbursts_per_s %.3f batches %llu push_retries %llu producers %zu consumers %zu fifo_depth %zu by_ref %d\n",
 		       n * repeat, dt, n * repeat / dt * 1e-6, (unsigned long long)g.batches(), (unsigned long long)retries.load(), producers,
-		       chans, fifo_depth);
+		       chans, fifo_depth, (int)cfg.by_reference);
 		printf("devices %zu batches_per_device", g.devices());      /* TRXHIP_DEVICES=0,0: two contexts on one GPU */
 		for (size_t k = 0; k < g.devices(); k++) printf(" %llu", (unsigned long long)g.batchesOn(k));
 		printf("\n");

@@ -109,6 +109,18 @@ struct BurstGathererConfig {
 	                           * samples early (osmo-trx.cpp:87-100); power from them as read, detection on the shifted copy, soft
 	                           * bits from scaleVector(1/16383) + demodAnyBurst_va() -- all on the GPU, one batch = one stream
 	                           * (TRXHIP_FLAG_USE_VA of the host pipe).  Not with exact_demod (there is no filter demodulator). */
+	int n_completers;         /* completion threads (0: one per device entry).  Each waits for a batch of its own, sorts it by
+	                           * channel and writes the channels' rings when its batch's turn comes (tickets in submission
+	                           * order): deliveries stay in push order per channel, two threads overlap the copy of batch k + 1
+	                           * with that of batch k.  TRXHIP_COMPLETERS in the environment overrides. */
+	bool by_reference;        /* round 5: push() records BurstRequest::iq instead of copying the burst.  The reference cuts each
+	                           * burst out of the receive ring with one CPU copy (radioInterface.cpp:272-291); here the ring is
+	                           * registered once (registerBuffer(), before start()) and the GPU fetches the gathered bursts
+	                           * from it over the link (trxhip_hostpipe_submit_by_ref): the producer's cost per burst is a few
+	                           * stores.  Contract: iq is 4-byte aligned, the whole burst lies inside a registered range, and
+	                           * the samples stay unchanged until the burst's indication has been pulled (a channel never has
+	                           * more than fifo_depth bursts outstanding: a ring of fifo_depth + 1 burst periods per channel
+	                           * satisfies it).  A burst outside every registered range fails its batch: -EIO from pull(). */
 };
 class BurstGatherer {
 public:
@@ -121,6 +133,9 @@ public:
 	/* TRXD header version of one channel (the reference negotiates it per channel: mVersionTRXD[chan],
 	 * Transceiver.cpp:1238-1250); applies to bursts pushed afterwards.  false in float mode (trxd_version < 0). */
 	bool setTrxdVersion(size_t chan, int version);
+	/* by_reference: a host range bursts will be pushed from (the radio's receive ring); pinned and mapped into every device
+	 * of the list at start(), released at stop() / destruction.  Before start() only; at most 8 ranges. */
+	bool registerBuffer(const void *base, size_t bytes);
 	/* producer: false = dropped (channel FIFO full, radioInterface.cpp:277-280) or rejected (an EDGE slot on a gatherer
 	 * configured without egprs: the 444-bit rows do not exist) */
 	bool push(size_t chan, const BurstRequest &req);

@@ -76,6 +76,10 @@ SYMBOLS = {
     "trxhip_hostpipe_wait": (_I, [_VP, _I]),
     "trxhip_hostpipe_query": (_I, [_VP, _I]),
     "trxhip_hostpipe_run": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _SZ]),
+    "trxhip_hostpipe_register_host": (_I, [_VP, _VP, _SZ]),
+    "trxhip_hostpipe_unregister_host": (_I, [_VP, _VP]),
+    "trxhip_hostpipe_slot_sources": (_I, [_VP, _I, C.POINTER(_VP)]),
+    "trxhip_hostpipe_submit_by_ref": (_I, [_VP, _I, _SZ]),
     "trxhip_convolve_real_batch": (_I, [_VP, _VP, _I, _VP, _I, _VP, _I, _I, _I, _SZ, _VP]),
     "trxhip_convolve_complex_batch": (_I, [_VP, _VP, _I, _VP, _I, _VP, _I, _I, _I, _SZ, _VP]),
     "trxhip_convert_short_float": (_I, [_VP, _VP, _VP, _SZ, _VP]),
@@ -104,7 +108,7 @@ def load_library():
     except OSError as e:  # pragma: no cover
         raise TrxHipError(f"cannot load {path}: {e}") from e
     for name, (res, args) in SYMBOLS.items():
-        if name == "trxhip_fast_stats" and os.environ.get("TRXHIP_LIB") and not hasattr(L, name):
+        if (name == "trxhip_fast_stats" or name.startswith("trxhip_hostpipe_")) and os.environ.get("TRXHIP_LIB") and not hasattr(L, name):
             continue          # tools/ab_multi.sh against an older measurement build of the library (product: always bound)
         f = getattr(L, name)  # AttributeError if the export is missing
         f.restype = res
@@ -481,6 +485,25 @@ class HostPipe:
 
     def submit(self, i, n):
         _check(self.trx.L.trxhip_hostpipe_submit(self.h, i, n), "trxhip_hostpipe_submit")
+
+    # ---- bursts by reference: the samples stay where they are (a registered host range), the slot carries pointers ----
+    def register_host(self, array):
+        """Pin a numpy array (the radio's receive ring) and map it into the device: bursts inside it can be submitted by
+        address.  The caller keeps the array alive until unregister_host() / close()."""
+        _check(self.trx.L.trxhip_hostpipe_register_host(self.h, _VP(array.ctypes.data), array.nbytes), "trxhip_hostpipe_register_host")
+
+    def unregister_host(self, array):
+        _check(self.trx.L.trxhip_hostpipe_unregister_host(self.h, _VP(array.ctypes.data)), "trxhip_hostpipe_unregister_host")
+
+    def sources(self, i):
+        """uint64 view of slot i's pointer array (max_bursts host addresses)."""
+        q = _VP()
+        _check(self.trx.L.trxhip_hostpipe_slot_sources(self.h, i, C.byref(q)), "trxhip_hostpipe_slot_sources")
+        buf = (C.c_ubyte * (self.cfg.max_bursts * 8)).from_address(q.value)
+        return np.frombuffer(buf, dtype=np.uint64)
+
+    def submit_by_ref(self, i, n):
+        _check(self.trx.L.trxhip_hostpipe_submit_by_ref(self.h, i, n), "trxhip_hostpipe_submit_by_ref")
 
     def wait(self, i):
         _check(self.trx.L.trxhip_hostpipe_wait(self.h, i), "trxhip_hostpipe_wait")

@@ -19,6 +19,8 @@ struct trxhip_hostpipe {
 	std::vector<trxhip_hostpipe_slot> slot;
 	std::vector<std::atomic<int64_t>> done_ns;
 	std::vector<void *> allocs;
+	std::vector<const int16_t **> src;                       /* by reference: one pointer array per slot */
+	std::vector<std::pair<const char *, size_t>> ranges;
 };
 
 static std::atomic<int> g_live_pipes{0};
@@ -69,6 +71,7 @@ extern "C" int trxhip_hostpipe_create(trxhip_ctx *ctx, const trxhip_hostpipe_cfg
 		h.pkt = cfg->pkt_stride ? (uint8_t *)grab((size_t)cfg->max_bursts * cfg->pkt_stride) : nullptr;
 		h.pkt_len = (uint16_t *)grab(cfg->max_bursts * sizeof(uint16_t));
 		p->done_ns[s].store(0);
+		p->src.push_back((const int16_t **)grab(cfg->max_bursts * sizeof(void *)));
 	}
 	g_live_pipes++;
 	*out = p;
@@ -121,6 +124,40 @@ extern "C" int trxhip_hostpipe_submit(trxhip_hostpipe *p, int slot, size_t n)
 	}
 	p->done_ns[slot].store(now_ns() + 20000 + (int64_t)(rng() % 280000), std::memory_order_release);
 	return TRXHIP_OK;
+}
+
+/* bursts by reference: the "device" copies each burst from its registered range into the slot, then the plain submit */
+extern "C" int trxhip_hostpipe_register_host(trxhip_hostpipe *p, const void *base, size_t bytes)
+{
+	if (!p || !base || !bytes || p->ranges.size() >= 8) return TRXHIP_EINVAL;
+	p->ranges.emplace_back((const char *)base, bytes);
+	return TRXHIP_OK;
+}
+extern "C" int trxhip_hostpipe_unregister_host(trxhip_hostpipe *p, const void *base)
+{
+	for (size_t k = 0; p && k < p->ranges.size(); k++)
+		if (p->ranges[k].first == base) { p->ranges.erase(p->ranges.begin() + k); return TRXHIP_OK; }
+	return TRXHIP_EINVAL;
+}
+extern "C" int trxhip_hostpipe_slot_sources(trxhip_hostpipe *p, int slot, const int16_t ***out)
+{
+	if (!p || !out || slot < 0 || slot >= p->cfg.depth) return TRXHIP_EINVAL;
+	*out = p->src[slot];
+	return TRXHIP_OK;
+}
+extern "C" int trxhip_hostpipe_submit_by_ref(trxhip_hostpipe *p, int slot, size_t n)
+{
+	const size_t bytes = (size_t)p->cfg.burst_len * 4;
+	for (size_t i = 0; i < n; i++) {
+		const char *q = (const char *)p->src[slot][i];
+		bool in = false;
+		for (auto &r : p->ranges)
+			in = in || (q >= r.first && q + bytes <= r.first + r.second);
+		if (!in) return TRXHIP_EINVAL;
+	}
+	for (size_t i = 0; i < n; i++)
+		memcpy(p->slot[slot].iq + i * p->cfg.burst_len * 2, p->src[slot][i], bytes);
+	return trxhip_hostpipe_submit(p, slot, n);
 }
 
 extern "C" int trxhip_hostpipe_wait(trxhip_hostpipe *p, int slot)

@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported(lib):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/trxhip.h but not exported"
     assert sorted(trxhip.SYMBOLS) == names
-    assert lib.trxhip_abi_version() == 4
+    assert lib.trxhip_abi_version() == 5
 
 
 # device blob layout (osmo_trx_amd/csrc/trx_tables.h)

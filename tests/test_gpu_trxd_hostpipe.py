@@ -164,6 +164,90 @@ def test_hostpipe_output_modes_and_input_paths(trx, max_bursts, soft_stride, pkt
     pipe.close()
 
 
+@pytest.mark.parametrize("n_paths", [1, 2])
+def test_hostpipe_bursts_by_reference_equal_the_staged_path(trx, n_paths):
+    """trxhip_hostpipe_submit_by_ref(): the bursts stay in a registered host range (the radio's receive ring) -- scattered, in
+    another order than they are submitted, 4-byte but not 16-byte aligned -- and the slot carries their addresses; the device
+    fetches them over the link.  Results, soft rows and datagrams equal the staged submit bit for bit (with diversity: the
+    paths of a burst back to back behind its address).  An address outside every registered range, a burst that crosses
+    the end of its range and a misaligned address are refused with TRXHIP_EINVAL before anything is enqueued."""
+    from osmo_trx_amd.trxhip import HostPipe, TrxHipError
+    n, max_bursts = 1500, 2048
+    iq, params, meta = mixed_workload(n * n_paths)
+    iq = iq.numpy().reshape(n, n_paths, 625, 2)
+    params, meta = params[:n], meta[:n]
+    if n_paths > 1:                                                   # the diversity pipe takes no EDGE / RACH-specific layout: all types fine
+        iq = np.ascontiguousarray(iq)
+    pipe = HostPipe(trx, max_bursts, depth=2, soft_stride=148, pkt_stride=160, rssi_offset=0.5, n_paths=n_paths)
+    v = pipe.slot(0)
+    v["iq"][:n] = iq if n_paths > 1 else iq[:, 0]
+    v["params"][:n] = params
+    v["meta"][:n] = meta
+    pipe.submit(0, n)
+    pipe.wait(0)
+    want = {k: v[k][:n].copy() for k in ("results", "soft", "pkt", "pkt_len")}
+    # the "ring": burst i lives at a permuted position, 3 int16 pairs (12 bytes) of slack in front of every burst
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(n)
+    per = n_paths * 625 * 2 + 6
+    ring = np.zeros(n * per + 64, dtype=np.int16)
+    for i in range(n):
+        o = perm[i] * per + 6
+        ring[o:o + per - 6] = iq[i].reshape(-1)
+    pipe.register_host(ring)
+    w = pipe.slot(1)
+    w["params"][:n] = params
+    w["meta"][:n] = meta
+    w["iq"][:] = 0                                                    # nothing is staged
+    src = pipe.sources(1)
+    src[:n] = ring.ctypes.data + 2 * (perm * per + 6)
+    pipe.submit_by_ref(1, n)
+    pipe.wait(1)
+    for k in want:
+        assert np.array_equal(w[k][:n], want[k]), k
+    # refusals: outside the range, crossing its end, misaligned -- and the slot stays usable
+    other = np.zeros(4096, dtype=np.int16)
+    for bad in (other.ctypes.data, ring.ctypes.data + ring.nbytes - 100, ring.ctypes.data + 2):
+        src[5] = bad
+        with pytest.raises(TrxHipError):
+            pipe.submit_by_ref(1, n)
+    src[5] = ring.ctypes.data + 2 * (perm[5] * per + 6)
+    pipe.submit_by_ref(1, n)
+    pipe.wait(1)
+    assert np.array_equal(w["results"][:n], want["results"])
+    pipe.unregister_host(ring)
+    with pytest.raises(TrxHipError):
+        pipe.submit_by_ref(1, 8)
+    pipe.close()
+
+
+def test_burst_gatherer_by_reference_equals_copying_gatherer(trx, tmp_path):
+    """BurstGathererConfig::by_reference: the capture is registered as the receive ring, 16 producers push addresses, the GPU
+    fetches every gathered batch from the ring.  Every delivered record and datagram / soft row equals the copying gatherer's
+    (same schedule, same batches or not: the per-burst results do not depend on the batch), on one and on two device entries."""
+    from osmo_trx_amd import build as trx_build
+    trx_build.build_all()
+    n, chans = 8192, 16
+    iq, params, meta = mixed_workload(n)
+    (tmp_path / "iq.s16").write_bytes(iq.numpy().tobytes())
+    (tmp_path / "p.bin").write_bytes(params.tobytes())
+    env0 = {k: v for k, v in os.environ.items() if k != "TRXHIP_DEVICES"}
+    for exe in exes():
+        for version in (-1, 1):
+            ref = None
+            for by_ref, devs in ((0, None), (1, None), (1, "0,0")):
+                out = tmp_path / "g.bin"
+                env = dict(env0) if devs is None else dict(env0, TRXHIP_DEVICES=devs)
+                txt = subprocess.run([exe, "gather", str(tmp_path / "iq.s16"), str(tmp_path / "p.bin"), str(n), str(chans), "256", "200",
+                                      str(version), str(out), "2", "4", "32", str(by_ref)], stdout=subprocess.PIPE, text=True, check=True,
+                                     env=env).stdout
+                assert f"by_ref {by_ref}" in txt, txt
+                got = out.read_bytes()
+                if ref is None:
+                    ref = got
+                assert got == ref, (exe, version, by_ref, devs)
+
+
 def test_hostpipe_argument_checks(trx):
     from osmo_trx_amd.trxhip import HostPipe, TrxHipError
     with pytest.raises(TrxHipError):
@@ -266,7 +350,8 @@ def test_multi_device_gatherer_two_contexts_equal_one(trx, tmp_path):
                 want = 1 if devs is None else devs.count(",") + 1
                 assert int(line[1]) == want, txt
                 per_dev = [int(x) for x in line[3:]]
-                assert len(per_dev) == want and min(per_dev) > 0 and max(per_dev) - min(per_dev) <= 1, txt
+                # (one completion thread per entry: a staging batch re-opens when its own entry has finished -- shares, not strict turns)
+                assert len(per_dev) == want and min(per_dev) > 0 and max(per_dev) - min(per_dev) <= 2 + sum(per_dev) // 50, txt
                 got = out.read_bytes()
                 if ref is None:
                     ref = got
