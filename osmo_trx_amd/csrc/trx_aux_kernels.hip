@@ -1358,7 +1358,8 @@ extern "C" int trx_launch_scale_vector(float *d_x, size_t len, float sr, float s
 // the link.  One wave per burst, `dwords` 4-byte words each (625 at 4 SPS: ten rounds of 256 contiguous bytes); five loads of a
 // lane are issued before the first store so that a wave keeps 1.25 KB in flight -- 256 CUs x 8 waves hold 2.6 MB on the link,
 // an order of magnitude above its bandwidth-delay product.  Plain loads: with the non-temporal hint the same kernel fetched
-// 37.7 GB/s instead of 44.7, 16-byte loads from the aligned body of every burst 41.4 (profiles/r05_gather.txt; the copy engine
+// 37.7 GB/s instead of 44.7, 16-byte loads from the aligned body of every burst 41.4 / 42.8 (with / without the hint;
+// profiles/r05_gather.txt; the copy engine
 // moves the staged form of the same batch at 55 GB/s -- a cache line per request against the engine's long bursts).
 // Nothing of this data is read twice: HBM sees one write.
 __global__ void __launch_bounds__(256)
@@ -1386,52 +1387,10 @@ gather_bursts_kernel(const unsigned long long *__restrict__ src, uint32_t *__res
 		d[i] = s[i];
 }
 
-// measurement variant (TRXHIP_GATHER_VARIANT=2): 16-byte loads from the 16-byte-aligned body of every burst
-__global__ void __launch_bounds__(256)
-gather_bursts_x4_kernel(const unsigned long long *__restrict__ src, uint32_t *__restrict__ dst, size_t n, unsigned dwords)
-{
-	const unsigned lane = threadIdx.x & 63u;
-	const size_t b = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-	if (b >= n)
-		return;
-	const unsigned long long a = src[b];
-	const unsigned a_lo = __builtin_amdgcn_readfirstlane((unsigned)a), a_hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-	const uint32_t *__restrict__ s = reinterpret_cast<const uint32_t *>(((unsigned long long)a_hi << 32) | a_lo);
-	uint32_t *__restrict__ d = dst + b * dwords;
-	const unsigned head = ((16u - (a_lo & 15u)) & 15u) >> 2;             // dwords in front of the first 16-byte boundary
-	const unsigned nvec = (dwords - head) >> 2, tail0 = head + 4u * nvec;
-	const uint4 *__restrict__ sv = reinterpret_cast<const uint4 *>(s + head);
-	uint32_t *__restrict__ dv = d + head;
-	uint4 v[3];
-#pragma unroll
-	for (int k = 0; k < 3; k++)
-		if (lane + 64u * k < nvec)
-			v[k] = sv[lane + 64u * k];
-	if (lane < head)
-		d[lane] = s[lane];
-	if (lane < dwords - tail0)
-		d[tail0 + lane] = s[tail0 + lane];
-#pragma unroll
-	for (int k = 0; k < 3; k++)
-		if (lane + 64u * k < nvec) {
-			uint32_t *q = dv + 4u * (lane + 64u * k);
-			q[0] = v[k].x; q[1] = v[k].y; q[2] = v[k].z; q[3] = v[k].w;
-		}
-	for (unsigned i = lane + 192u; i < nvec; i += 64u) {
-		const uint4 w = sv[i];
-		uint32_t *q = dv + 4u * i;
-		q[0] = w.x; q[1] = w.y; q[2] = w.z; q[3] = w.w;
-	}
-}
-
 extern "C" int trx_launch_gather_bursts(const unsigned long long *d_src, void *d_dst, size_t n, unsigned dwords, hipStream_t stream)
 {
 	if (n == 0)
 		return 0;
-	static const int variant = getenv("TRXHIP_GATHER_VARIANT") ? atoi(getenv("TRXHIP_GATHER_VARIANT")) : 0;
-	if (variant == 2)
-		hipLaunchKernelGGL(gather_bursts_x4_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, d_src, reinterpret_cast<uint32_t *>(d_dst), n, dwords);
-	else
-		hipLaunchKernelGGL(gather_bursts_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, d_src, reinterpret_cast<uint32_t *>(d_dst), n, dwords);
+	hipLaunchKernelGGL(gather_bursts_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, d_src, reinterpret_cast<uint32_t *>(d_dst), n, dwords);
 	return hipGetLastError() == hipSuccess ? 0 : TRXHIP_EIO;
 }

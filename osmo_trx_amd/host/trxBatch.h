@@ -76,7 +76,8 @@ int trxdPackBurstInd(uint8_t *buf, const BurstIndication *bi, unsigned version);
  * on the RxUpper<chan> thread (Transceiver.cpp:665-815, blocking FIFO read :683).  Between them the gatherer copies
  * each burst straight into the pinned staging buffer of the batch being filled, launches the batch when it holds
  * `max_batch` bursts or its first burst has waited `timeout_us`, and hands the results back per channel in
- * arrival order. */
+ * arrival order.  (by_reference: it records the burst's address in a registered receive ring instead, and the device
+ * fetches the batch from there.) */
 #define TRX_GATHERER_MAX_DEVICES 16
 struct BurstGathererConfig {
 	size_t chans;             /* number of ARFCN channels (FIFOs) */
