@@ -349,7 +349,8 @@ int  trxhip_hostpipe_query(trxhip_hostpipe *p, int slot);
  * otherwise, nothing enqueued); the samples stay unchanged until wait() on the slot has returned.
  * register_host: pins [base, base + bytes) and maps it into the device's address space (hipHostRegister; a range some
  * other pipe of the process has registered already is shared); at most 8 ranges per pipe; unregister_host (or destroy)
- * releases what this pipe pinned -- no slot that refers to the range may be in flight. */
+ * releases what this pipe pinned -- before the memory is freed, and with no slot that refers to the range in flight.
+ * register / unregister are not synchronised against submits of the same pipe on other threads. */
 int  trxhip_hostpipe_register_host(trxhip_hostpipe *p, const void *base, size_t bytes);
 int  trxhip_hostpipe_unregister_host(trxhip_hostpipe *p, const void *base);
 /* the slot's pointer array: max_bursts entries of pinned host memory, valid until trxhip_hostpipe_destroy() */

@@ -491,9 +491,11 @@ class HostPipe:
         """Pin a numpy array (the radio's receive ring) and map it into the device: bursts inside it can be submitted by
         address.  The caller keeps the array alive until unregister_host() / close()."""
         _check(self.trx.L.trxhip_hostpipe_register_host(self.h, _VP(array.ctypes.data), array.nbytes), "trxhip_hostpipe_register_host")
+        self._registered = getattr(self, "_registered", []) + [array]     # pinned pages must not be freed under the device
 
     def unregister_host(self, array):
         _check(self.trx.L.trxhip_hostpipe_unregister_host(self.h, _VP(array.ctypes.data)), "trxhip_hostpipe_unregister_host")
+        self._registered = [a for a in getattr(self, "_registered", []) if a is not array]
 
     def sources(self, i):
         """uint64 view of slot i's pointer array (max_bursts host addresses)."""
@@ -536,6 +538,7 @@ class HostPipe:
             self._slots = None
             self.trx.L.trxhip_hostpipe_destroy(self.h)
             self.h = None
+            self._registered = []
 
     def __del__(self):
         try:
