@@ -349,6 +349,11 @@ __device__ __forceinline__ float norm2(c32 v) { return v.y * v.y + v.x * v.x; }
 #define TRX_UNIT_NEG_DUMMY  0x1212ull
 #define TRX_UNIT_NEG_SCH    0x41f73b2d69b9df04ull     /* 64 taps (trx_sch.hip); residue up to 7e-14: 2^17 * 7e-14 = 9.2e-9 < 2^-26 */
 
+// One s_waitcnt for a block's eight LDS reads instead of the compiler's one per use: a wait is an issue slot of the wave like
+// any instruction, and eight of them in front of eight multiply-adds doubled the block (round 5: - 1 % wave cycles together with
+// the grouped reads of fir24x3; the same for the decimator's 16 reads and for the burst's ten global loads measured nothing)
+#define TRX_FAST_ONE_WAIT() __builtin_amdgcn_s_waitcnt(0xc07f)   /* lgkmcnt(0) */
+
 // acc += x * u for the unit tap u of parity ODD and sign NEG:  even: +-(x0, x1);  odd: h = (e, s): (-s*x1, s*x0)
 template <bool ODD, bool NEG>
 __device__ __forceinline__ trx_v2f unit_mac(trx_v2f acc, trx_v2f x)
@@ -382,6 +387,7 @@ struct UnitCorr {
 #pragma unroll
 			for (int u = 0; u < 8; u++)
 				x[u] = lds_c32(p + k0 + u);
+			TRX_FAST_ONE_WAIT();
 #pragma unroll
 			for (int u = 0; u < 8; u++)
 				acc = unit_mac_k(acc, (trx_v2f){ x[u].x, x[u].y }, NEGMASK, k0 + u);
@@ -409,6 +415,7 @@ struct UnitCorrPair40 {
 #pragma unroll
 			for (int u = 0; u < 4; u++)
 				x[u] = *(lds_ptr4)(p + 2 * (m0 + u));
+			TRX_FAST_ONE_WAIT();
 #pragma unroll
 			for (int u = 0; u < 4; u++) {
 				const int m = m0 + u;                                // samples 2m (a) and 2m + 1 (b) of the lane's window
@@ -700,6 +707,7 @@ __device__ __forceinline__ c32 interp_taps_fma(const c32 *c, const float *sa, co
 			x[u] = cp[8 * h + u];
 			w[u] = h ? sb[512 * u] : sa[512 * (7 - u)];
 		}
+		TRX_FAST_ONE_WAIT();
 #pragma unroll
 		for (int u = 0; u < 8; u += 2) {
 			p0 = pk_fma_w(x[u], w[u], p0);
@@ -725,6 +733,7 @@ __device__ __forceinline__ c32 interp_taps_w_fma(const c32 *c, const float4 *wq)
 #pragma unroll
 		for (int u = 0; u < 8; u++)
 			x[u] = cp[8 * h + u];
+		TRX_FAST_ONE_WAIT();
 #pragma unroll
 		for (int u = 0; u < 8; u += 2) {
 			const float4 q = (u & 4) ? qb : qa;
