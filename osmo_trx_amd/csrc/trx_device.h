@@ -375,23 +375,31 @@ __device__ __forceinline__ trx_v2f unit_mac_k(trx_v2f acc, trx_v2f x, unsigned l
 	return unit_mac<true, true>(acc, x);
 }
 
-// N taps in blocks of 8 reads followed by 8 adds (the register footprint of the multiplying loop it replaces)
+// N taps through a window of 8 samples in registers (the register footprint of the multiplying loop it replaces).  A
+// v_pk_add_f32 that depends on the v_pk_add_f32 in front of it costs a wait state (the compiler pads with s_nop 0), and the sum
+// is ONE chain by definition (the reference's order): the read of sample k + 8 is issued straight behind the add of sample k and
+// takes the pad's slot -- an instruction that has to be issued anyway.  One s_waitcnt per block: the block's samples have all
+// arrived before its first add, so the reads in between need none.  Only the last block keeps its pads.
 template <unsigned long long NEGMASK, int N>
 struct UnitCorr {
 	static __device__ __forceinline__ trx_v2f run(trx_v2f acc, const c32 *p)
 	{
 		static_assert(N % 8 == 0, "blocks of 8 taps");
+		c32 x[8];
+#pragma unroll
+		for (int u = 0; u < 8; u++)
+			x[u] = lds_c32(p + u);
 #pragma unroll
 		for (int k0 = 0; k0 < N; k0 += 8) {
-			c32 x[8];
-#pragma unroll
-			for (int u = 0; u < 8; u++)
-				x[u] = lds_c32(p + k0 + u);
 			TRX_FAST_ONE_WAIT();
-#pragma unroll
-			for (int u = 0; u < 8; u++)
-				acc = unit_mac_k(acc, (trx_v2f){ x[u].x, x[u].y }, NEGMASK, k0 + u);
 			__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+			for (int u = 0; u < 8; u++) {
+				acc = unit_mac_k(acc, (trx_v2f){ x[u].x, x[u].y }, NEGMASK, k0 + u);
+				if (k0 + 8 < N)
+					x[u] = lds_c32(p + k0 + 8 + u);
+				__builtin_amdgcn_sched_barrier(0);
+			}
 		}
 		return acc;
 	}
@@ -420,6 +428,8 @@ struct UnitCorrPair40 {
 			for (int u = 0; u < 4; u++) {
 				const int m = m0 + u;                                // samples 2m (a) and 2m + 1 (b) of the lane's window
 				const trx_v2f a = { x[u].x, x[u].y }, b = { x[u].z, x[u].w };
+				// (alternating the two lags' chains -- a1 a0 a1 a0 -- does not save the pads: a packed add between two dependent
+				// packed adds does not count as their wait state, the compiler pads every second instruction either way)
 				if (m >= 1)
 					a1 = unit_mac_k(a1, a, NEGMASK, 2 * m - 1);
 				a0 = unit_mac_k(a0, a, NEGMASK, 2 * m);
