@@ -616,15 +616,20 @@ frontend_fused_kernel(const uint4 *__restrict__ in4, size_t n_total, c32 *__rest
 	const int S = p * m, iters = tm / m;
 	const bool owner = t < S;
 	const unsigned qt = (unsigned)q * (unsigned)t;
-	const int n_t = (int)(qt / (unsigned)p), path_t = (int)(qt % (unsigned)p);
+	const int n_t0 = (int)(qt / (unsigned)p), path_t0 = (int)(qt % (unsigned)p);
 	const int nstep = q * m;
 
 	// The residues S - 256 .. S - 1 of every resampler step (all channels) are swept item by item.  Which output, which filter
 	// path and which input sample an item is depends on the item alone, not on the tile: worked out once, here, and parked in
 	// LDS as two packed words -- per tile the four integer divisions (~ 160 instructions on the waves that hold items, which
 	// the other waves of the workgroup then wait for at the next barrier) become one 8-byte read.
+	// (first sample, filter path) of this thread's output positions: a function of the thread alone, but kept in two registers
+	// across the tile loop it was what the allocator spilled at 128 -- and a scratch reload in front of the resampler loop waits
+	// for vmcnt(0), i.e. for the next tile's prefetch that has just been issued.  Parked in LDS, one ds_read_b32 per tile.
+	int *const thr_item = reinterpret_cast<int *>(rtaps + 16 * pst);
+	thr_item[t] = (n_t0 << 16) | path_t0;
 	const int n_res = (S - CH_TPB) * iters * CH_M;
-	int2 *const res_item = reinterpret_cast<int2 *>(rtaps + 16 * pst);
+	int2 *const res_item = reinterpret_cast<int2 *>(rtaps + 16 * pst + CH_TPB);
 	for (int idx = t; idx < n_res; idx += CH_TPB) {
 		const int nres0 = S - CH_TPB;
 		const int c = idx / (nres0 * iters), r = idx % (nres0 * iters);
@@ -761,6 +766,11 @@ frontend_fused_kernel(const uint4 *__restrict__ in4, size_t n_total, c32 *__rest
 			// than this loop does.  Two CHANNELS of an output position per pass: the same taps and offsets, 32 LDS reads in
 			// flight and two independent sum chains instead of one (the waves of this kernel wait two thirds of their time:
 			// profiles/r04_ab_runs.txt); each output's sum still runs k = 0..15, product then add.
+			typedef const volatile int __attribute__((address_space(3))) *lds_int;
+			int tl = t;                                                     // (opaque: the address is one instruction to form per tile -- hoisted
+			asm volatile("" : "+v"(tl));                                    // out of the tile loop it was the next value to be spilled)
+			const int ti = *(lds_int)(thr_item + tl);
+			const int n_t = ti >> 16, path_t = ti & 0xffff;
 			ch_v2f h2[8];
 #pragma unroll
 			for (int k = 0; k < 8; k++)
@@ -773,10 +783,10 @@ frontend_fused_kernel(const uint4 *__restrict__ in4, size_t n_total, c32 *__rest
 				unsigned yo = (unsigned)t;                                  // (a per-thread 64-bit pointer here was spilled and reloaded --
 				size_t oo = o0 + t;                                         // behind a vmcnt(0) wait -- once per tile)
 				for (int it = 0; it < iters && oo < n_out; it++, oo += S, xa += nstep, yo += (unsigned)S) {
-					ch_v2f acc[CH_M];
+					ch_v2f acc[CH_M], pr[CH_M];
 #pragma unroll
 					for (int c = 0; c < CH_M; c++)
-						acc[c] = (ch_v2f){ 0.0f, 0.0f };
+						acc[c] = pr[c] = (ch_v2f){ 0.0f, 0.0f };
 #pragma unroll
 					for (int k0 = 0; k0 < 16; k0 += 4) {
 						ch_v2f x[CH_M][4];
@@ -785,22 +795,37 @@ frontend_fused_kernel(const uint4 *__restrict__ in4, size_t n_total, c32 *__rest
 #pragma unroll
 							for (int c = 0; c < CH_M; c++)
 								x[c][k] = ch_lds(xa + c * FE_CS + k0 + k);
+						// A tap at a time, software-pipelined: the four channels' products of tap k (the LAST-read channel first -- its
+						// s_waitcnt covers the other three, LDS returns in order) alternate with the four sums of tap k - 1.  Written as
+						// product + sum per channel the compiler ran all sixteen through one product register: wait, multiply, s_nop
+						// (the pad of a dependent packed pair), add -- four issue slots per tap and channel where two do the
+						// arithmetic; a packed instruction between the two does not count as their pad, so products and sums of the
+						// SAME tap in two groups of four still paid one s_nop per tap (round 5).
 #pragma unroll
 						for (int k = 0; k < 4; k++) {
 							const int kk = k0 + k;
 #pragma unroll
-							for (int c = 0; c < CH_M; c++)
-								acc[c] = acc[c] + ((kk & 1) ? ch_mul_tap<1>(x[c][k], h2[kk >> 1]) : ch_mul_tap<0>(x[c][k], h2[kk >> 1]));   // product, then sum
+							for (int c = CH_M - 1; c >= 0; c--) {
+								const ch_v2f pn = (kk & 1) ? ch_mul_tap<1>(x[c][k], h2[kk >> 1]) : ch_mul_tap<0>(x[c][k], h2[kk >> 1]);
+								if (kk > 0)
+									acc[c] = acc[c] + pr[c];                           // product, then sum: tap kk - 1
+								pr[c] = pn;
+								__builtin_amdgcn_sched_barrier(0);
+							}
 						}
-						__builtin_amdgcn_sched_barrier(0);
 					}
+#pragma unroll
+					for (int c = CH_M - 1; c >= 0; c--)
+						acc[c] = acc[c] + pr[c];                                       // tap 15
 #pragma unroll
 					for (int c = 0; c < CH_M; c++)
 						(ob + (size_t)c * out_stride)[yo] = make_float2(acc[c].x, acc[c].y);
 				}
 			}
 		}
-		for (int idx = t; idx < n_res; idx += CH_TPB) {                    // residues of every step, all channels
+		int tr = t;                                                         // (opaque, as above: the item's address is formed per tile)
+		asm volatile("" : "+v"(tr));
+		for (int idx = tr; idx < n_res; idx += CH_TPB) {                   // residues of every step, all channels
 			const int2 e = res_item[idx];
 			const int c = e.x >> 16, n = e.x & 0xffff, oi = e.y >> 16, path = e.y & 0xffff;
 			if (o0 + oi >= n_out)
@@ -836,7 +861,7 @@ extern "C" int trx_launch_frontend_fused(const int16_t *d_wide, float *d_out, si
 	const size_t n_res = (size_t)(p * m - CH_TPB) * (tm / m) * CH_M;    // residue items per tile (80 at 65 / 48)
 	if (n_res > 1024)
 		return 1;
-	const size_t lds = (size_t)16 * (p + 1) * sizeof(float) + n_res * sizeof(int2);   // resampler taps + the residue items
+	const size_t lds = (size_t)16 * (p + 1) * sizeof(float) + CH_TPB * sizeof(int) + n_res * sizeof(int2);   // resampler taps + the threads' items + the residue items
 	hipLaunchKernelGGL(frontend_fused_kernel, dim3((unsigned)gx), dim3(CH_TPB), lds, stream, reinterpret_cast<const uint4 *>(d_wide),
 			   n_total, reinterpret_cast<c32 *>(d_out), n_out, out_stride, p, q, tm, m, n_tiles, parts, d_tab,
 			   reinterpret_cast<const uint4 *>(d_wide_hist_io), reinterpret_cast<const c32 *>(d_chan_hist_in),
