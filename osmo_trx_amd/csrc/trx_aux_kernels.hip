@@ -700,28 +700,48 @@ frontend_fused_kernel(const uint4 *__restrict__ in4, size_t n_total, c32 *__rest
 			c32 yp[CH_J][CH_M];
 #pragma unroll
 			for (int pp = 0; pp < CH_M; pp++) {
+				// The window is requested LAST sample first: the first product needs x[0], the newest request, and its s_waitcnt
+				// covers the whole window (LDS returns in order) -- one wait per path where the ascending order had one per tap.
 				ch_v2f x[CH_J + CH_H - 1];
 #pragma unroll
-				for (int v = 0; v < CH_J + CH_H - 1; v++)
+				for (int v = CH_J + CH_H - 2; v >= 0; v--)
 					x[v] = ch_lds(&xs[pp][v & 3][t + (v >> 2)]);
 				// (round 5 measured these 16 wave-uniform taps as scalar operands of the packed multiplies, fetched per path through
 				// the scalar cache instead of LDS: 1.30 ms against 1.04 -- the s_load and its lgkmcnt wait sit in front of every
 				// path's sums; profiles/r05_ab_runs.txt)
-				const float2 *g2 = reinterpret_cast<const float2 *>(&taps[pp][0]);
-				ch_v2f acc[CH_J];
+				// A pair of taps is one broadcast 8-byte read, requested one pair AHEAD of its use (the compiler had sunk each read
+				// to its first use: request, s_waitcnt lgkmcnt(0), multiply -- a full LDS round trip in front of every tap pair).
+				// Products of tap k alternate with the sums of tap k - 1: a dependent packed pair costs a pad, and a packed
+				// instruction in between does not count as one (see the resampler loop below).
+				typedef const volatile ch_v2f __attribute__((address_space(3))) *lds_tap;
+				const lds_tap g2 = (lds_tap)(&taps[pp][0]);
+				ch_v2f acc[CH_J], pr[CH_J];
 #pragma unroll
 				for (int j = 0; j < CH_J; j++)
-					acc[j] = (ch_v2f){ 0.0f, 0.0f };
+					acc[j] = pr[j] = (ch_v2f){ 0.0f, 0.0f };
+				ch_v2f gcur = g2[0];
 #pragma unroll
-				for (int k = 0; k < CH_H; k++) {
-					const float2 gq = g2[k >> 1];
-					const ch_v2f gp = (ch_v2f){ gq.x, gq.y };
+				for (int kp = 0; kp < CH_H / 2; kp++) {
+					ch_v2f gnext = gcur;
+					if (kp + 1 < CH_H / 2)
+						gnext = g2[kp + 1];
 #pragma unroll
-					for (int j = 0; j < CH_J; j++)
-						acc[j] = acc[j] + ((k & 1) ? ch_mul_tap<1>(x[j + k], gp) : ch_mul_tap<0>(x[j + k], gp));
-					if (k & 1)
-						__builtin_amdgcn_sched_barrier(0);
+					for (int kk = 0; kk < 2; kk++) {
+						const int k = 2 * kp + kk;
+#pragma unroll
+						for (int j = 0; j < CH_J; j++) {
+							const ch_v2f pn = kk ? ch_mul_tap<1>(x[j + k], gcur) : ch_mul_tap<0>(x[j + k], gcur);
+							if (k > 0)
+								acc[j] = acc[j] + pr[j];                               // product, then sum: tap k - 1
+							pr[j] = pn;
+							__builtin_amdgcn_sched_barrier(0);
+						}
+					}
+					gcur = gnext;
 				}
+#pragma unroll
+				for (int j = 0; j < CH_J; j++)
+					acc[j] = acc[j] + pr[j];                                           // tap 15
 #pragma unroll
 				for (int j = 0; j < CH_J; j++) {
 					asm volatile("" : "+v"(acc[j]));
