@@ -137,6 +137,13 @@ const char *trxhip_strerror(int err);
  * never depend on it (tests/test_gpu_parity.py); a measurement switch.  TRXHIP_NO_POOL in the environment makes 0 the
  * default of contexts created afterwards. */
 int  trxhip_set_work_pool(trxhip_ctx *ctx, int enabled);
+/* Kernel split of trxhip_detect_demod_batch() for the call pullRadioVector() makes (int16 bursts of 625 samples at 4 SPS, fused
+ * demodulator, TRXHIP_FLAG_SLICE alone, soft_stride 148): 1 (default) = the normal-burst kernel (csrc/trx_kernel_nb.hip: TSC
+ * slots with max_toa <= 32 and nothing else) runs over the batch and the general kernel over the list of bursts it left --
+ * slots of other types, wide windows, the rare bursts outside its straight-line paths; 0 = the general kernel alone, as in
+ * rounds 1-5.  Results are bit-identical either way (tests/test_gpu_nb_kernel.py); a measurement switch.  TRXHIP_NO_NB_KERNEL in
+ * the environment makes 0 the default of contexts created afterwards. */
+int  trxhip_set_nb_kernel(trxhip_ctx *ctx, int enabled);
 /* Counters of the fused kernels' FAST detector on the context's device since the last reset (synchronises the device):
  * out4[0] = bursts whose TOA search found an uncertified early / late decision on its path and was re-run in the
  * reference's operand order; out4[1..3] reserved.  Diagnostics (tests and tools report the re-run rate). */

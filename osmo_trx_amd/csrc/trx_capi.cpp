@@ -17,6 +17,9 @@ extern "C" int trx_launch_pull(unsigned *d_pool_ctr, const void *d_iq, int cf32,
 			       trxhip_burst_result *d_results, float *d_soft, const trx_tables *d_tab, const float *d_ebp_in,
 			       size_t n_bursts, int L, int sps, float thresh, float full_scale,
 			       int soft_stride, int slice, int n_cu, hipStream_t stream);
+extern "C" int trx_launch_pull4_nb(unsigned *d_pool_ctr, const void *d_iq, const trxhip_burst_params *d_params,
+				   trxhip_burst_result *d_results, float *d_soft, const trx_tables *d_tab, size_t n_bursts,
+				   float thresh, float full_scale, int n_cu, unsigned *d_redo, hipStream_t stream);
 extern "C" int trx_unit_masks_match(const trx_tables *t);       /* trx_kernel4.hip: compiled-in sign masks vs the tables */
 extern "C" int trx_launch_pack_trxd(const trxhip_burst_result *d_results, const float *d_soft, int soft_stride,
 				    uint8_t *d_pkt, size_t n_bursts, float rssi_offset, hipStream_t stream);
@@ -108,6 +111,10 @@ int trxhip_create_from_tables(trxhip_ctx **out, int device, const void *h_blob, 
 	const trx_tables *t = static_cast<const trx_tables *>(h_blob);
 	if (t->magic != TRX_TABLES_MAGIC || t->version != TRX_TABLES_VERSION)
 		return TRXHIP_EINVAL;
+	/* the composite-tap window is a build-time choice of generator AND kernels (TRX_FUSED_U0 / TRX_FUSED_NT): a blob made by a
+	 * build with another window would be read with shifted taps */
+	if (t->fused_u0 != TRX_FUSED_U0 || t->fused_nt != TRX_FUSED_NT)
+		return TRXHIP_EINVAL;
 	/* the exact delay filters of the kernels skip taps 0, 17, 18, 19: exactly 0.0f in every filter sigProcLibSetup() can
 	 * generate (the sinc LUT is zero beyond 8 pi, sigProcLib.cpp:990-998, :2164-2172).  A blob that breaks this is not such a
 	 * table set: refused rather than silently evaluated with 16 of its 20 taps.  (Non-finite samples: the
@@ -136,6 +143,14 @@ int trxhip_create_from_tables(trxhip_ctx **out, int device, const void *h_blob, 
 	ctx->d_pool = nullptr;
 	ctx->pool_next.store(0u);
 	ctx->pool_enabled = getenv("TRXHIP_NO_POOL") ? 0 : 1;          /* measurement switch, read once per context */
+	ctx->nb_enabled = getenv("TRXHIP_NO_NB_KERNEL") ? 0 : 1;       /* the same for the normal-burst kernel (A/B against the general one) */
+	ctx->redo_next = 0;
+	for (int i = 0; i < TRX_REDO_SLOTS; i++) {
+		ctx->redo[i].d = nullptr;
+		ctx->redo[i].cap = 0;
+		ctx->redo[i].ev = nullptr;
+		ctx->redo[i].busy = 0;
+	}
 	ctx->no_sym = 0;                                           /* the straight-line decimator reads taps 0..7 and mirrors them */
 	for (int k = 0; k < 8; k++)
 		if (memcmp(&t->dec_taps[k], &t->dec_taps[15 - k], sizeof(float)) != 0)
@@ -193,8 +208,21 @@ void trxhip_destroy(trxhip_ctx *ctx)
 	if (hipSetDevice(ctx->device) == hipSuccess) {
 		if (ctx->d_tables) (void)hipFree(ctx->d_tables);
 		if (ctx->d_pool) (void)hipFree(ctx->d_pool);
+		for (int i = 0; i < TRX_REDO_SLOTS; i++) {
+			if (ctx->redo[i].busy) (void)hipEventSynchronize(ctx->redo[i].ev);
+			if (ctx->redo[i].ev) (void)hipEventDestroy(ctx->redo[i].ev);
+			if (ctx->redo[i].d) (void)hipFree(ctx->redo[i].d);
+		}
 	}
 	delete ctx;
+}
+
+int trxhip_set_nb_kernel(trxhip_ctx *ctx, int enabled)
+{
+	if (!ctx)
+		return TRXHIP_EINVAL;
+	ctx->nb_enabled = enabled ? 1 : 0;
+	return TRXHIP_OK;
 }
 
 int trxhip_set_work_pool(trxhip_ctx *ctx, int enabled)
@@ -256,10 +284,54 @@ static int pull_common(trxhip_ctx *ctx, const void *d_iq, int cf32, const trxhip
 		flags |= TRXHIP_IFLAG_NO_SYM;
 	if (ctx->no_fast)
 		flags |= TRXHIP_IFLAG_NO_FAST;
+	/* A launch that is being captured into a HIP graph keeps whatever it is handed for as long as the graph lives, and replays
+	 * may overlap later launches: it gets neither a pool counter pair (static split) nor a leftover list (general kernel only) --
+	 * both are recycled between launches. */
+	hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+	const bool capturing = stream && hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cap) == hipSuccess &&
+			       cap != hipStreamCaptureStatusNone;
 	/* a counter pair for this launch (zero: the previous user's last workgroup re-armed it; trx_ctx.h) */
 	unsigned *pool = nullptr;
-	if (ctx->d_pool && ctx->pool_enabled && n_bursts >= (size_t)ctx->n_cu * 128)
+	if (ctx->d_pool && ctx->pool_enabled && !capturing && n_bursts >= (size_t)ctx->n_cu * 128)
 		pool = ctx->d_pool + (size_t)(ctx->pool_next.fetch_add(1u, std::memory_order_relaxed) % TRX_POOL_SLOTS) * 16;
+	/* The call pullRadioVector() makes for its traffic slots (int16 bursts of 625 samples at 4 SPS, fused demodulator, sliced rows
+	 * of 148 soft bits): the normal-burst kernel over the batch, then the general kernel over whatever it left on its list. */
+	if (ctx->nb_enabled && !capturing && !cf32 && !d_ebp_in && sps == 4 && burst_len == 625 && d_soft && soft_stride == 148 &&
+	    flags == TRXHIP_FLAG_SLICE) {
+		std::lock_guard<std::mutex> lk(ctx->redo_mu);
+		trxhip_ctx::redo_slot &sl = ctx->redo[ctx->redo_next++ % TRX_REDO_SLOTS];
+		bool ok = true;
+		if (sl.busy) {
+			ok = hipEventSynchronize(sl.ev) == hipSuccess;
+			sl.busy = 0;
+		}
+		if (ok && !sl.ev)
+			ok = hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming) == hipSuccess;
+		if (ok && sl.cap < n_bursts) {
+			if (sl.d) (void)hipFree(sl.d);
+			sl.d = nullptr;
+			sl.cap = 0;
+			const size_t cap_new = n_bursts < 65536 ? 65536 : n_bursts;
+			ok = hipMalloc(reinterpret_cast<void **>(&sl.d), (TRX_REDO_HDR_WORDS + cap_new) * sizeof(unsigned)) == hipSuccess &&
+			     hipMemset(sl.d, 0, TRX_REDO_HDR_WORDS * sizeof(unsigned)) == hipSuccess;
+			if (ok)
+				sl.cap = cap_new;
+			else if (sl.d) {
+				(void)hipFree(sl.d);
+				sl.d = nullptr;
+			}
+		}
+		if (ok) {
+			const int rc = trx_launch_pull4_nb(pool, d_iq, d_params, d_results, d_soft, ctx->d_tables, n_bursts, threshold, full_scale,
+							   ctx->n_cu, sl.d, static_cast<hipStream_t>(stream));
+			if (rc == 0 && hipEventRecord(sl.ev, static_cast<hipStream_t>(stream)) == hipSuccess)
+				sl.busy = 1;
+			else if (rc == 0)
+				(void)hipStreamSynchronize(static_cast<hipStream_t>(stream));   /* no event: the slot is free once the stream has drained */
+			return rc;
+		}
+		/* (no list buffer: fall through to the general kernel) */
+	}
 	return trx_launch_pull(pool, d_iq, cf32, d_params, d_results, d_soft, ctx->d_tables, d_ebp_in, n_bursts, burst_len, sps,
 			       threshold, full_scale, soft_stride, flags, ctx->n_cu, static_cast<hipStream_t>(stream));
 }

@@ -25,8 +25,18 @@ struct trxhip_ctx {
 	unsigned *d_pool;
 	int pool_enabled;                  /* trxhip_set_work_pool(); default 1, 0 when TRXHIP_NO_POOL is set at creation */
 	std::atomic<unsigned> pool_next;
+	/* The normal-burst kernel (trx_kernel_nb.hip) and the list of bursts it leaves to the general kernel: TRX_REDO_SLOTS device
+	 * buffers of TRX_REDO_HDR + capacity words, handed out round-robin per launch under redo_mu.  A slot's header is zero
+	 * between launches (the general kernel's last workgroup re-arms it); its event marks the end of the launch pair that used
+	 * it last -- a slot is only handed out again (or re-allocated larger) once that event has completed. */
+	int nb_enabled;                    /* trxhip_set_nb_kernel(); default 1, 0 when TRXHIP_NO_NB_KERNEL is set at creation */
+	std::mutex redo_mu;
+	struct redo_slot { unsigned *d; size_t cap; hipEvent_t ev; int busy; } redo[4];
+	unsigned redo_next;
 };
 #define TRX_POOL_SLOTS 1024
+#define TRX_REDO_SLOTS 4
+#define TRX_REDO_HDR_WORDS 16           /* = TRX_REDO_HDR of the kernels */
 
 /* the TRXD wire packer's launcher (trx_aux_kernels.hip); d_results_copy (may be NULL): every result record is also written
  * there -- the host pipe points it at pinned memory and saves the download */

@@ -29,9 +29,8 @@
 #include <atomic>
 #include "trx_device.h"
 
-#define PH_A   180                 // entries per phase array (= 4 mod 16: conflict-free loader writes)
-#define PH_M0  12                  // position of m = 0 inside a phase array (48 samples of zero pad in front)
-#define K4_XS  (4 * PH_A)
+#include "trx_k4_common.h"
+
 #define K4_CZ_LEN (TRX_CZ_PAD + TRX_CORR_NARROW + TRX_CZ_PAD)
 #define K4_SLICE (K4_XS + TRX_DEC_NARROW + K4_CZ_LEN)
 #define K4_DROWS (TRX_DELAY_FILTS + 1)                         // + identity row (no fractional filter)
@@ -44,7 +43,6 @@
 #define K4_NO_BURST 0xffffffffu
 #define K4_LDS_TAIL (16 + 4 * K4_POOL_RING)  // work counter + pool ring behind the per-wave slices
 
-typedef float v2f __attribute__((ext_vector_type(2)));
 
 #ifdef TRX_DIAG
 extern "C" int trxhip_diag_read(unsigned long long *out, int reset)
@@ -74,21 +72,6 @@ __device__ __forceinline__ int cdiv(int a, int b) { return -fdiv(-a, b); }
 __device__ __forceinline__ int fdiv4(int a) { return a >> 2; }
 __device__ __forceinline__ int cdiv4(int a) { return (a + 3) >> 2; }
 
-// four per-lane base pointers for a run of consecutive samples s0, s0+1, ... : sample s0+t lives at
-// pb[t & 3][t >> 2].  ph0 = s0 & 3, m0 = s0 >> 2 (arithmetic).
-struct PhBase { const c32 *p[4]; };
-__device__ __forceinline__ PhBase ph_bases(const c32 *P, int ph0, int m0)
-{
-	// p[k] = P + ((ph0 + k) & 3) * PH_A + PH_M0 + m0 + ((ph0 + k) >> 2), incrementally: one multiply-add for p[0],
-	// then + k * PH_A, and one row back / one sample on where the phase wraps
-	PhBase b;
-	const c32 *p0 = P + (ph0 * PH_A + PH_M0 + m0);
-	b.p[0] = p0;
-#pragma unroll
-	for (int k = 1; k < 4; k++)
-		b.p[k] = p0 + (k * PH_A + ((ph0 + k) >> 2) * (1 - 4 * PH_A));
-	return b;
-}
 
 // waves per workgroup (one persistent workgroup per CU): 16 = 4 per SIMD for int16 input, both demodulators (<= 128
 // VGPRs; 36.6 KB of tables + 16 x 7.7 KB slices + the work counter = 159.7 KB of the 160 KB LDS, which is why the per-wave
@@ -99,107 +82,29 @@ __device__ __forceinline__ PhBase ph_bases(const c32 *P, int ph0, int m0)
 // the end of the launch (work claiming, below) another 13 % in round 2.
 #define K4_WPB(CF_, EX_) (((CF_) && (EX_)) ? 12 : 16)
 
-// The fused demodulator's main filter: three ADJACENT outputs per lane over the composite taps u = K4_U0 .. K4_U0 + K4_NT - 1
-// (6 .. 29, 24 of 35: trx_tables.h).  pb addresses the lane's first sample (tap K4_U0 of its first output), c4 its tap row from K4_U0 on -- a per-lane
-// LDS address, wave-uniform for the ordinary lanes.  Taps outer, a ring of 16 samples loaded D ahead of use; one
-// sched_barrier per tap keeps the order and the register footprint.
-#define K4_U0 TRX_FUSED_U0
-#define K4_NT TRX_FUSED_NT
-#define K4_NTP TRX_FUSED_NTP
-__device__ __forceinline__ void fir24x3(const PhBase &pb, const float4 *c4, v2f (&acc)[3])
-{
-	constexpr int D = 4, NV = K4_NT + 8;                            // samples v = 0 .. 31; the ring runs D = 4 samples ahead of the FMAs
-	c32 xw[16];
-	float4 cq[2];
-	cq[0] = c4[0];
-#pragma unroll
-	for (int v = 0; v < 8 + D; v++)
-		xw[v] = lds_c32(pb.p[v & 3] + (v >> 2));
-#pragma unroll
-	for (int u = 0; u < K4_NT; u++) {
-		if ((u & 3) == 0 && u + 4 < K4_NT)
-			cq[((u >> 2) + 1) & 1] = c4[(u >> 2) + 1];
-		// the ring is refilled four samples at a time, in front of every group of four taps: the compiler then needs ONE
-		// s_waitcnt per group (for the previous group's reads) where a read per tap needed one per tap -- a wait is an issue
-		// slot like any other (round 5: 24 -> 6 in this filter, - 0.9 % wave cycles)
-		if ((u & 3) == 0) {
-#pragma unroll
-			for (int k = 0; k < 4; k++)
-				if (u + 8 + D + k < NV)
-					xw[(u + 8 + D + k) & 15] = lds_c32(pb.p[(u + 8 + D + k) & 3] + ((u + 8 + D + k) >> 2));
-		}
-		const float4 ca = cq[(u >> 2) & 1];
-		const v2f hp = (u & 2) ? (v2f){ ca.z, ca.w } : (v2f){ ca.x, ca.y };
-#pragma unroll
-		for (int j = 0; j < 3; j++) {
-			const v2f xv = { xw[(u + 4 * j) & 15].x, xw[(u + 4 * j) & 15].y };
-			acc[j] = (u & 1) ? pk_fma_tap<1>(xv, hp, acc[j]) : pk_fma_tap<0>(xv, hp, acc[j]);
-		}
-		__builtin_amdgcn_sched_barrier(0);
-	}
-}
-
-// One output of the /4 decimator (downsampleBurst, :1587-1601) on the polyphase layout: y = sum_k x[4i-15+k] * g[k], product
-// then sum, k ascending (the reference's order).  All 16 samples are fetched before the first multiply -- the compiler's own
-// schedule interleaves reads and waits with 2-5 reads in flight and exposes the LDS latency six times -- and the taps come as
-// g[0..7] only (two 16-byte broadcast reads): the filter is bitwise symmetric, g[k] == g[15-k] (checked when the context
-// is created; TRX_IFLAG_NO_SYM otherwise keeps callers on the generic path).
-//   FROM_P0: start the sum at the first product instead of adding it to +0 (one instruction less; differs from the reference
-//   only in the sign of a zero result when every product is -0: the fused kernels take it, the bit-exact ones do not)
-template <bool FROM_P0 = false>
-__device__ __forceinline__ c32 decimate16_sym(const c32 *pd, const float *gdec)
-{
-	const float4 *g4 = reinterpret_cast<const float4 *>(gdec);
-	c32 xs[16];
-#pragma unroll
-	for (int k = 0; k < 16; k++)
-		xs[k] = lds_c32(pd + ((k + 1) & 3) * PH_A + ((k + 1) >> 2));
-	const float4 gA = g4[0], gB = g4[1];
-	__builtin_amdgcn_sched_barrier(0);
-	// product k + 1 is issued between sum k - 1 and sum k: a v_pk_add_f32 straight behind the v_pk_add_f32 it depends on costs
-	// a wait state each time (the compiler's order -- sixteen products, then sixteen sums -- paid fifteen s_nop)
-	auto prod = [&](int k) {
-		const int kk = k < 8 ? k : 15 - k;
-		const float4 gq = (kk >> 2) ? gB : gA;
-		const v2f gp = (kk & 2) ? (v2f){ gq.z, gq.w } : (v2f){ gq.x, gq.y };
-		const v2f xv = { xs[k].x, xs[k].y };
-		v2f r;
-		if (kk & 1)
-			asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(xv), "v"(gp));
-		else
-			asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(r) : "v"(xv), "v"(gp));
-		return r;
-	};
-	v2f p_cur = prod(0), p_next = prod(1);
-	v2f ya;
-	if (FROM_P0) {
-		ya = p_cur;
-	} else {
-		ya = (v2f){ 0.0f, 0.0f };
-		asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(ya) : "v"(p_cur));
-	}
-#pragma unroll
-	for (int k = 1; k < 16; k++) {
-		p_cur = p_next;
-		if (k + 1 < 16)
-			p_next = prod(k + 1);
-		asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(ya) : "v"(p_cur));
-	}
-	return make_float2(ya.x, ya.y);
-}
 
 // COMMON = the call pullRadioVector() makes (Transceiver.cpp:665-815) and bench.py times: 625-sample int16 bursts, detection
 // + demodulation, vectorSlicer applied, rows of 148 soft bits, no diagnostic flags.  Those launch parameters are then
 // compile-time constants (the launcher checks them) and the scalar tests, selects and generic store loops they feed
 // disappear from the burst loop; every other call takes the general instantiation of the same source.
-template <bool CF32, bool EXACT, bool COMMON>
+// LIST: the launch works through a LIST of burst indices in device memory -- redo[0] = their number, entries from
+// redo[TRX_REDO_HDR] -- that the normal-burst kernel (trx_kernel_nb.hip) left behind: slots of other types, wide windows, the
+// rare bursts its straight-line paths do not cover.  The count is only known on the device: the grid is the persistent one,
+// a launch over an empty list returns before it stages anything.  List positions are dealt statically (wave w of workgroup g
+// takes positions 16 g + w + k * 16 * gridDim.x) so that the index of the burst after next can be fetched a burst ahead.
+#define TRX_REDO_HDR 16                   /* [0] count, [1] workgroups done (this kernel), entries from [16] */
+template <bool CF32, bool EXACT, bool COMMON, bool LIST = false>
 __global__ void __launch_bounds__(K4_WPB(CF32, EXACT) * WAVE)
 burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__restrict__ params,
 		   trxhip_burst_result *__restrict__ results, float *__restrict__ soft_arg,
 		   const trx_tables *__restrict__ tab, const float4 *__restrict__ ebp_arg,
-		   unsigned n_bursts, int L_arg, float thresh, float full_scale, int soft_stride_arg, int slice_arg,
-		   unsigned *__restrict__ pool_ctr)
+		   unsigned n_bursts_arg, int L_arg, float thresh, float full_scale, int soft_stride_arg, int slice_arg,
+		   unsigned *__restrict__ pool_ctr, unsigned *__restrict__ redo)
 {
+	const unsigned n_bursts = LIST ? (unsigned)uni((int)__hip_atomic_load(redo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : n_bursts_arg;
+	if (LIST && n_bursts == 0u)
+		return;
+	const unsigned *const rlist = LIST ? redo + TRX_REDO_HDR : nullptr;
 	static_assert(!(COMMON && CF32 && EXACT), "complex64 input: the common instantiation exists for the fused demodulator only (16 waves per CU)");
 	static_assert(K4_TABLES_BYTES % 16 == 0 && (K4_SLICE * 8) % 16 == 0 && (K4_XS * 8) % 16 == 0 &&
 		      ((TRX_DEC_NARROW + TRX_CZ_PAD) * 8) % 16 == 0, "dec[] and cz[] are read / written 16 bytes at a time");
@@ -305,7 +210,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 	// drawn group by group from ONE device-wide atomic counter by whichever workgroup gets there: the wave that takes the
 	// first burst of a group draws the NEXT group (k + 1) and publishes it through the LDS ring pool_g[], so that the global
 	// atomic's latency is paid once per 16 bursts by one wave, a burst-time before anybody needs the answer.
-	const bool pooled = pool_ctr != nullptr;
+	const bool pooled = !LIST && pool_ctr != nullptr;
 	const unsigned n_static_groups = pooled ? ((n_groups - (n_groups >> 3)) / n_wg) * n_wg : n_groups;
 	const unsigned n_pool_groups = n_groups - n_static_groups;
 	const unsigned my_groups = (blockIdx.x < n_static_groups) ? (n_static_groups - blockIdx.x + n_wg - 1) / n_wg : 0u;
@@ -372,7 +277,20 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 			}
 		}
 	};
-	unsigned b_first = burst_of((unsigned)wave);                   // (static: pooled launches give every workgroup >= 7 groups)
+	// LIST: position in the list of the wave's current burst, and the index of the burst after next (fetched a burst ahead)
+	unsigned lpos = blockIdx.x * 16u + (unsigned)wave;
+	const unsigned lstride = n_wg * 16u;
+	uint32_t pre_id = K4_NO_BURST;
+	unsigned b_first;
+	if (LIST) {
+		b_first = K4_NO_BURST;
+		if (lpos < n_bursts)
+			b_first = (unsigned)uni((int)rlist[lpos]);
+		if (lpos + lstride < n_bursts)
+			pre_id = rlist[lpos + lstride];
+	} else {
+		b_first = burst_of((unsigned)wave);                         // (static: pooled launches give every workgroup >= 7 groups)
+	}
 	if (b_first != K4_NO_BURST)
 		prefetch(b_first);
 
@@ -448,7 +366,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 		// costs ~50 VGPRs and spills.
 		int lane;
 		asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
-		const int ticket = claim_issue(wg_next);                   // this wave's next item; taken at prefetch time below
+		const int ticket = LIST ? 0 : claim_issue(wg_next);        // this wave's next item; taken at prefetch time below
 		const unsigned prm0 = (unsigned)uni((int)pre_prm);
 		DIAG_MARK(13);
 		const int type = prm0 & 0xff;
@@ -572,11 +490,18 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 		flush(lane);                                               // the previous burst's output (its dec[] is still intact)
 		pend_mode = 0;
 		DIAG_MARK(16);
-		j_next = (unsigned)claim_take(ticket);
-		DIAG_MARK(17);
-		b_next = burst_of(j_next);
-		if (pooled && (j_next & 15u) == 0u && j_next + 16u >= items)
-			pool_draw(j_next, b_next == K4_NO_BURST && j_next >= items, lane);
+		if (LIST) {
+			lpos += lstride;
+			b_next = (lpos < n_bursts) ? (unsigned)uni((int)pre_id) : K4_NO_BURST;
+			if (lpos + lstride < n_bursts)
+				pre_id = rlist[lpos + lstride];
+		} else {
+			j_next = (unsigned)claim_take(ticket);
+			DIAG_MARK(17);
+			b_next = burst_of(j_next);
+			if (pooled && (j_next & 15u) == 0u && j_next + 16u >= items)
+				pool_draw(j_next, b_next == K4_NO_BURST && j_next >= items, lane);
+		}
 		if (b_next != K4_NO_BURST)
 			prefetch(b_next);
 		DIAG_MARK(15);
@@ -1193,6 +1118,17 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 			}
 		}
 	}
+	// LIST: the last workgroup to finish empties the list for the next launch that is handed it
+	if (LIST) {
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			const unsigned d = __hip_atomic_fetch_add(redo + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+			if (d == gridDim.x - 1u) {
+				__hip_atomic_store(redo, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_store(redo + 1, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+			}
+		}
+	}
 	DIAG_FLUSH();
 }
 
@@ -1219,6 +1155,38 @@ extern "C" int trx_unit_masks_match(const trx_tables *t)
 		if (!((t->unit_ok >> s) & 1u) || t->unit_neg[s] != want[s])
 			return 0;
 	return 1;
+}
+
+#include "trx_kernel_nb.hip"
+
+// The normal-burst kernel over the whole batch, then the general kernel (fused demodulator, common launch parameters) over the
+// list of bursts the first one left behind (d_redo: TRX_REDO_HDR words of header + one word per burst, header zero on entry
+// and zero again when the second kernel has finished).  Preconditions (the caller checks them): int16 input of 625 samples,
+// fused demodulator, sliced rows of 148 soft bits, tables with the unit / symmetric / FAST structure.
+extern "C" int trx_launch_pull4_nb(unsigned *d_pool_ctr, const void *d_iq, const trxhip_burst_params *d_params,
+				   trxhip_burst_result *d_results, float *d_soft, const trx_tables *d_tab, size_t n_bursts,
+				   float thresh, float full_scale, int n_cu, unsigned *d_redo, hipStream_t stream)
+{
+	if (n_bursts == 0)
+		return 0;
+	const size_t need = (n_bursts + 15) / 16;
+	size_t grid = (size_t)n_cu;
+	if (grid > need) grid = need;
+	unsigned *const pool = (d_pool_ctr && grid == (size_t)n_cu && need >= 8 * grid) ? d_pool_ctr : nullptr;
+	{
+		auto k = nb_pull4_kernel;
+		TRX_ARM_DYNAMIC_LDS(k);
+		hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NB_WPB * WAVE), NB_LDS_BYTES, stream, reinterpret_cast<const uint32_t *>(d_iq),
+				   d_params, d_results, d_soft, d_tab, (unsigned)n_bursts, thresh, full_scale, pool, d_redo);
+	}
+	{
+		auto k = burst_pull4_kernel<false, false, true, true>;
+		TRX_ARM_DYNAMIC_LDS(k);
+		const size_t lds = K4_TABLES_BYTES + (size_t)K4_WPB(false, false) * K4_SLICE * sizeof(c32) + K4_LDS_TAIL;
+		hipLaunchKernelGGL(k, dim3((unsigned)n_cu), dim3(K4_WPB(false, false) * WAVE), lds, stream, d_iq, d_params, d_results, d_soft, d_tab,
+				   (const float4 *)nullptr, 0u, 625, thresh, full_scale, 148, TRXHIP_FLAG_SLICE, (unsigned *)nullptr, d_redo);
+	}
+	return hipGetLastError() == hipSuccess ? 0 : TRXHIP_EIO;
 }
 
 extern "C" int trx_launch_pull4(unsigned *d_pool_ctr, const void *d_iq, int cf32, const trxhip_burst_params *d_params,
@@ -1259,7 +1227,7 @@ extern "C" int trx_launch_pull4(unsigned *d_pool_ctr, const void *d_iq, int cf32
 		}                                                                                               \
 		hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(wpb * WAVE), lds, stream, d_iq, d_params, d_results, \
 				   d_soft, d_tab, reinterpret_cast<const float4 *>(d_ebp_in), (unsigned)n_bursts, L, thresh, \
-				   full_scale, soft_stride, flags, pool);                                       \
+				   full_scale, soft_stride, flags, pool, (unsigned *)nullptr);                  \
 	} while (0)
 	/* the cross-die pool needs every workgroup to own >= 7 static groups and the grid to be the persistent one */
 	unsigned *const pool = (d_pool_ctr && grid == (size_t)n_cu && need >= 8 * grid) ? d_pool_ctr : nullptr;   /* (TRXHIP_NO_POOL: trx_capi.cpp) */

@@ -1,0 +1,388 @@
+// trx_kernel_nb.hip -- the NORMAL-BURST kernel: 625-sample int16 bursts at 4 SPS whose slot expects a GMSK normal burst
+// (analyzeTrafficBurst, sigProcLib.cpp:1887-1904 -> detectGeneralBurst :1732-1771 -> detectBurst :1649-1709; demodGmskBurst
+// :2055-2072 -> demodCommon :2030-2048; vectorSlicer :546-556), fused demodulator + FAST detector, 148 sliced soft bits --
+// the call pullRadioVector() makes for a traffic slot and bench.py times.  (Included by trx_kernel4.hip: one translation
+// unit, one copy of the device-side counters.)
+//
+// Same arithmetic as the COMMON instantiation of burst_pull4_kernel (trx_kernel4.hip) -- results are bit-identical to it --
+// but nothing else is in here: no access / EDGE / dummy / wide-window / exact-demodulator code, no run-time flags.  A burst
+// this kernel cannot finish is APPENDED TO A LIST and left to the general kernel, which is launched behind it over that list:
+//   * the slot is not a normal-burst slot (type != TSC, tsc > 7) or its window is wider than one round (max_toa > 32);
+//   * a decimated sample fails the addition-only correlation's guard (unit_unsafe(): about one burst in 3000);
+//   * the peak-ratio gate is too close to call for the estimate (about one in 1e5);
+//   * the detected TOA is outside the straight-line demodulator's geometry (toa < -0.25 or > 9 symbols).
+// What is different from the general kernel, beside what is absent:
+//   * soft bits never go through LDS: the three outputs of a lane (symbols 4 + 3 lane + j; symbols 0..3 come from the
+//     low-edge lanes) are rotated, scaled and sliced in registers -- the (-j)^i rotation is a quad permutation of ONE
+//     per-lane multiplier, applied by the DPP operand of the multiply -- and stored as one 12-byte store per lane (a
+//     contiguous 576-byte run per burst), one burst late like the general kernel's (the stores must be older than the
+//     prefetch loads: vmcnt retires in order);
+//   * a workgroup's static share is one CONTIGUOUS range of bursts (burst = base + item: one scalar add).
+#include "trx_k4_common.h"
+
+#define NB_D_LEN    128                                           /* decimated window (64 used) / parking space of the low-edge tap rows (1 KB) */
+#define NB_CZ_LEN   (TRX_CZ_PAD + TRX_CORR_NARROW + TRX_CZ_PAD)
+#define NB_SLICE    (K4_XS + NB_D_LEN + NB_CZ_LEN)                /* complex samples per wave */
+#define NB_COMP_ROWS (TRX_DELAY_FILTS + 1)
+#define NB_TABLES_FLOATS (TRX_SINCV_LDS + 16 * WAVE + NB_COMP_ROWS * 36 + 16 + 8 * 8 + 5 * WAVE)
+#define NB_TABLES_BYTES (NB_TABLES_FLOATS * 4)
+#define NB_WPB 16
+#define NB_POOL_RING 64
+#define NB_POOL_UNSET (-1)
+#define NB_POOL_END (-2)
+#define NB_NO_BURST 0xffffffffu
+#define NB_LDS_TAIL (16 + 4 * NB_POOL_RING)
+#define NB_LDS_BYTES (NB_TABLES_BYTES + NB_WPB * NB_SLICE * 8 + NB_LDS_TAIL)
+#define NB_MAX_TOA 32                                             /* window of 16 + max_toa <= 48 lags: 15 + 48 = 63 decimated samples, one per lane */
+
+
+
+typedef float v3f __attribute__((ext_vector_type(3)));
+
+__global__ void __launch_bounds__(NB_WPB * WAVE)
+nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__restrict__ params,
+		trxhip_burst_result *__restrict__ results, float *__restrict__ soft, const trx_tables *__restrict__ tab,
+		unsigned n_bursts, float thresh, float full_scale, unsigned *__restrict__ pool_ctr, unsigned *__restrict__ redo)
+{
+	static_assert(NB_TABLES_BYTES % 16 == 0 && (NB_SLICE * 8) % 16 == 0 && (K4_XS * 8) % 16 == 0 && (NB_D_LEN * 8) % 16 == 0, "16-byte LDS accesses");
+	static_assert(NB_LDS_BYTES <= 160 * 1024, "LDS");
+	constexpr int NLD = 10;
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	const int lane0 = threadIdx.x & (WAVE - 1);
+	const int wave = uni((int)(threadIdx.x >> 6));
+
+	// ---- LDS carve: [tables][per-wave slices][work counter, pool ring]
+	float *const sincv = reinterpret_cast<float *>(smem);           // [4128] swizzled sinc LUT (at LDS offset 0)
+	float *const wa4f = sincv + TRX_SINCV_LDS;                     // [4][64] float4: round A's interpolation weights by lane
+	const float4 *const wa4 = reinterpret_cast<const float4 *>(wa4f);
+	float *const comp = wa4f + 16 * WAVE;                          // [65][36] composite delay-o-decimate filters (shifted by TRX_FUSED_SH)
+	float *const gdec = comp + NB_COMP_ROWS * 36;                  // [16] decimator taps
+	float *const lhdr = gdec + 16;                                 // [8][8] headers of the eight training sequences
+	int *const pkcl = reinterpret_cast<int *>(lhdr + 8 * 8);       // [5][64] PeakConst fields by lane
+	c32 *const wbase = reinterpret_cast<c32 *>(smem + NB_TABLES_BYTES) + (size_t)wave * NB_SLICE;
+	int *const wg_next = reinterpret_cast<int *>(reinterpret_cast<c32 *>(smem + NB_TABLES_BYTES) + (size_t)NB_WPB * NB_SLICE);
+	int *const pool_g = wg_next + 4;
+	c32 *const P = wbase;                                          // polyphase burst: P[r*PH_A + PH_M0 + m] = x[4m + r]
+	c32 *const D = wbase + K4_XS;                                  // D[i] = decimated sample 56 + i
+	c32 *const cz = D + NB_D_LEN + TRX_CZ_PAD;                     // zero-padded correlation
+
+	// ---- one-time staging of the tables; zero this wave's slice (pads stay zero)
+	for (int i = threadIdx.x; i < TRX_SINCV_LDS; i += blockDim.x)
+		sincv[i] = (i < TRX_SINCV_LEN) ? tab->sincv[i] : 0.0f;
+	for (int i = threadIdx.x; i < 16 * WAVE; i += blockDim.x) {
+		const int l = i & (WAVE - 1), u = i >> 6;
+		const PeakConst pcl = peak_const(l);
+		const int q = (u < 8) ? pcl.loA + 512 * (7 - u) : pcl.hiA + 512 * (u - 8);
+		wa4f[((u >> 2) * WAVE + l) * 4 + (u & 3)] = (q < TRX_SINCV_LEN) ? tab->sincv[q] : 0.0f;
+	}
+	for (int i = threadIdx.x; i < NB_COMP_ROWS * 36; i += blockDim.x) {
+		const int f = i / 36, j = i % 36;
+		comp[i] = (j >= TRX_FUSED_SH) ? tab->comp_filt[f][j - TRX_FUSED_SH] : 0.0f;
+	}
+	if (threadIdx.x < 16)
+		gdec[threadIdx.x] = tab->dec_taps[threadIdx.x];
+	if (threadIdx.x < 64)
+		lhdr[threadIdx.x] = reinterpret_cast<const float *>(&tab->seq[TRX_SEQ_TSC0 + (threadIdx.x >> 3)].gain)[threadIdx.x & 7];
+	if (threadIdx.x < WAVE) {
+		const PeakConst pc0 = peak_const(threadIdx.x);
+		pkcl[0 * WAVE + threadIdx.x] = pc0.flA;
+		pkcl[1 * WAVE + threadIdx.x] = pc0.loA;
+		pkcl[2 * WAVE + threadIdx.x] = pc0.hiA;
+		pkcl[3 * WAVE + threadIdx.x] = pc0.offB;
+		pkcl[4 * WAVE + threadIdx.x] = pc0.ratio_off;
+	}
+	for (int i = lane0; i < NB_SLICE; i += WAVE)
+		wbase[i] = make_float2(0.0f, 0.0f);
+	if (threadIdx.x == 0)
+		*wg_next = NB_WPB;
+	if (threadIdx.x < NB_POOL_RING)
+		pool_g[threadIdx.x] = NB_POOL_UNSET;
+	__syncthreads();
+
+	const float fs_db = 6.02059991f * __log2f(full_scale);          // 20*log10(full_scale)
+	// ---- work distribution: groups of 16 consecutive bursts.  Static part: workgroup w owns ONE contiguous range of groups
+	// (7/8 of the batch when the cross-die pool is on, everything otherwise); the rest is drawn group by group from a
+	// device-wide counter (see burst_pull4_kernel).  Waves claim items one at a time from the workgroup's LDS counter.
+	const unsigned n_wg = gridDim.x;
+	const unsigned n_groups = (n_bursts + 15u) >> 4;
+	const bool pooled = pool_ctr != nullptr;
+	const unsigned n_static_groups = pooled ? ((n_groups - (n_groups >> 3)) / n_wg) * n_wg : n_groups;
+	const unsigned n_pool_groups = n_groups - n_static_groups;
+	const unsigned gq = n_static_groups / n_wg, gr = n_static_groups % n_wg;
+	const unsigned my_groups = gq + (blockIdx.x < gr ? 1u : 0u);
+	const unsigned base16 = (blockIdx.x * gq + (blockIdx.x < gr ? blockIdx.x : gr)) << 4;   // first burst of this workgroup's range
+	unsigned items = my_groups << 4;
+	if (base16 + items > n_bursts)
+		items = (base16 < n_bursts) ? n_bursts - base16 : 0u;       // the batch's last group may be short
+	auto burst_of = [&](unsigned jj) -> unsigned {
+		if (jj < items)
+			return base16 + jj;
+		if (!pooled)
+			return NB_NO_BURST;
+		const unsigned k = (jj - items) >> 4;
+		volatile int *slot = pool_g + (k & (NB_POOL_RING - 1));
+		int g;
+		while ((g = *slot) == NB_POOL_UNSET)
+			__builtin_amdgcn_s_sleep(2);
+		g = uni(g);
+		if (g < 0)
+			return NB_NO_BURST;
+		const unsigned bb = ((n_static_groups + (unsigned)g) << 4) + (jj & 15u);
+		return bb < n_bursts ? bb : NB_NO_BURST;
+	};
+	auto pool_draw = [&](unsigned jj, bool ended, int lane) {
+		const unsigned k = (jj + 16u - items) >> 4;
+		int g = NB_POOL_END;
+		if (!ended) {
+			unsigned p = 0;
+			if (lane == 0)
+				p = __hip_atomic_fetch_add(pool_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			p = (unsigned)uni((int)p);
+			g = (p < n_pool_groups) ? (int)p : NB_POOL_END;
+		}
+		if (lane == 0) {
+			pool_g[(k + NB_POOL_RING / 2) & (NB_POOL_RING - 1)] = NB_POOL_UNSET;
+			pool_g[k & (NB_POOL_RING - 1)] = g;
+		}
+	};
+
+	// ---- software prefetch of the next burst: ten dwords per lane + the slot's parameters
+	uint32_t pre_i[NLD];
+	uint32_t pre_prm = 0u;
+	auto prefetch = [&](unsigned bb, int lane) {
+		pre_prm = reinterpret_cast<const uint32_t *>(params)[2 * (size_t)bb];
+		const uint32_t *src = iq + (size_t)bb * 625;
+#pragma unroll
+		for (int r = 0; r < NLD; r++) {
+			const int i = r * WAVE + lane;
+			pre_i[r] = (r < NLD - 1 || i < 625) ? src[i] : 0u;
+		}
+	};
+	// items j < 16 * my_groups of the static range exist for every workgroup of a launch the launcher sizes (>= 1 group each)
+	const unsigned b_first = burst_of((unsigned)wave);
+	if (b_first != NB_NO_BURST)
+		prefetch(b_first, lane0);
+
+	// ---- deferred output (registers): o = the lane's three sliced soft bits, recw = the result record (lanes 0..7)
+	v3f o = { 0.0f, 0.0f, 0.0f };
+	int recw = 0;
+	bool pend_any = false;
+	unsigned pend_b = 0;
+
+	DIAG_DECL;
+	WI_LOCAL;
+	unsigned j_next = 0, b_next = NB_NO_BURST;
+	for (unsigned b = b_first; b != NB_NO_BURST; b = b_next) {
+		int lane;                                                  // re-materialised per burst (see burst_pull4_kernel)
+		asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+		const int ticket = claim_issue(wg_next);
+		const unsigned prm0 = (unsigned)uni((int)pre_prm);
+
+		// ---- phase 0: registers -> fp32 polyphase LDS; clip scan and energyDetect partial sums on the fly
+		c32 *const pload = P + (lane & 3) * PH_A + PH_M0 + (lane >> 2);
+		float amax = 0.0f, epart = 0.0f;
+#pragma unroll
+		for (int r = 0; r < NLD; r++) {
+			const int i = r * WAVE + lane;
+			if (r < NLD - 1 || i < 625) {
+				const c32 v = make_float2((float)(int16_t)(pre_i[r] & 0xffffu), (float)(int16_t)(pre_i[r] >> 16));
+				pload[16 * r] = v;
+				asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(v.x), "v"(v.y));
+				if (r < 5)
+					epart = fmaf(v.x, v.x, fmaf(v.y, v.y, epart));
+			}
+		}
+		// ---- the previous burst's output: 148 soft bits (lanes 0..47: symbols 4 + 3 lane + j as one 12-byte store, lanes
+		// 52..55: symbols 0..3) and the result record (lanes 0..7)
+		if (pend_any) {
+			float *const so = soft + (size_t)pend_b * 148;
+			int *const rp = reinterpret_cast<int *>(results + pend_b);
+			const float oe = o.x;
+			asm volatile("s_bfm_b64 exec, 48, 0\n\t"
+				     "global_store_dwordx3 %0, %1, %2 offset:16\n\t"
+				     "s_bfm_b64 exec, 4, 52\n\t"
+				     "global_store_dword %3, %4, %2\n\t"
+				     "s_bfm_b64 exec, 8, 0\n\t"
+				     "global_store_dword %5, %6, %7\n\t"
+				     "s_mov_b64 exec, -1\n\t"
+				     "s_nop 0"
+				     :: "v"(lane * 12), "v"(o), "s"(so), "v"(((-lane) & 3) * 4), "v"(oe), "v"(lane * 4), "v"(recw), "s"(rp)
+				     : "memory");
+		}
+		pend_any = false;
+		j_next = (unsigned)claim_take(ticket);
+		b_next = burst_of(j_next);
+		if (pooled && (j_next & 15u) == 0u && j_next + 16u >= items)
+			pool_draw(j_next, b_next == NB_NO_BURST && j_next >= items, lane);
+		if (b_next != NB_NO_BURST)
+			prefetch(b_next, lane);
+
+		// ---- is this a slot the kernel handles?
+		const unsigned max_toa = prm0 >> 16;
+		const int tsc = (prm0 >> 8) & 0xff;
+		bool leave = ((prm0 & 0xf8ffu) != (unsigned)TRXHIP_TSC) || (max_toa > NB_MAX_TOA);
+		int rc = 0;
+		float toa = 0.0f, ci = 0.0f, energy = 0.0f, rssi = 0.0f;
+		c32 amp = make_float2(0.0f, 0.0f);
+		int clip = 0;
+		int fast_nk = 1 << 30;
+		float4 fast_rows = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		if (!leave) {
+			// maxAmplitude() > 30000 (:1711-1722, :1746); energyDetect (:1573-1585) and RSSI (Transceiver.cpp:741,751)
+			clip = __ballot(amax > TRX_CLIP_THRESH) != 0ull;
+			energy = wave_sum_quad0(epart) * 0.0125f;
+			rssi = fs_db - 3.01029996f * __log2f(energy);
+			wave_sync();
+
+			// ---- detectGeneralBurst window of a normal burst (:1887-1904: target 82, head 10, tail 6 + max_toa -> start 71,
+			// len 16 + max_toa): decimated samples 56 .. 70 + len, one per lane
+			const int len = 16 + (int)max_toa;
+			__builtin_assume(len >= 16 && len <= 16 + NB_MAX_TOA);
+			c32 y = make_float2(0.0f, 0.0f);
+			if (lane < 15 + len) {
+				y = decimate16_sym<true>(P + PH_M0 + (56 + lane) - 4, gdec);
+				D[lane] = y;
+			}
+			const bool unit_bad = __ballot(unit_unsafe(y)) != 0ull;
+			wave_sync();
+			if (unit_bad) {
+				leave = true;
+			} else {
+				// ---- correlation (lane = lag; the twelve lanes behind the window store the right zero pad) and arg-max
+				trx_v2f acc = { 0.0f, 0.0f };
+				if (lane < len)
+					acc = corr_unit(tsc, D + lane);
+				const c32 yc = make_float2(acc.x, acc.y);
+				if (lane < len + TRX_CZ_PAD)
+					cz[lane] = yc;
+				const float v = norm2(yc);
+				const float m = wave_max(v);
+				int hit = 0;
+				int toa512 = 0;
+				if (m > 0.0f) {
+					const unsigned long long eqm = __ballot(v == m);
+					const int bidx = __ffsll((unsigned long long)eqm) - 1;
+					const float *const hdr = lhdr + 8 * tsc;
+					PeakConst pkc;
+					pkc.flA = pkcl[0 * WAVE + lane]; pkc.loA = pkcl[1 * WAVE + lane]; pkc.hiA = pkcl[2 * WAVE + lane];
+					pkc.offB = pkcl[3 * WAVE + lane]; pkc.ratio_off = pkcl[4 * WAVE + lane];
+					auto on_toa = [&](int t512) {
+						// TOA in 1/512 symbol -> the demodulator's shift and delay filter; fetch of the low-edge tap rows
+						toa512 = t512;
+						const int nk = -(t512 - (int)(hdr[5] * 512.0f) - 10 * 512);
+						if ((unsigned)(-(nk >> 7)) > 36u)
+							return;
+						fast_nk = nk;
+						const int fr = nk & 127;
+						const int fidx = (fr >= 2) ? (fr >> 1) : TRX_DELAY_FILTS;
+						fast_rows = reinterpret_cast<const float4 *>(&tab->edge8[fidx][0][0])[lane];   // (lanes >= 48: the next row's, unused)
+					};
+					hit = detect_tail_h<true>(D - 56, 156, cz, hdr, 16, thresh, 71, len, bidx, sincv, pkc, lane, &toa, &amp, &ci, on_toa, wa4, 0 DIAG_PASS WI_PASS);
+					wave_sync();
+				}
+				rc = hit ? TRXHIP_TSC : (clip ? -TRXHIP_SIGERR_CLIP : 0);                 // :1764, :1953-1954
+				toa -= 10.0f;                                                              // :1768
+				if (hit && fast_nk == (1 << 30))
+					leave = true;                                                          // TOA outside the straight-line geometry
+			}
+		}
+		if (leave) {
+			if (lane == 0) {
+				const unsigned idx = __hip_atomic_fetch_add(redo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				redo[TRX_REDO_HDR + idx] = b;
+			}
+			continue;
+		}
+
+		// ---- result record (wave-uniform fields dropped into lanes 0..7 of one register)
+		{
+			const bool det = rc > 0;
+			const uint32_t flags = (uint32_t)(det ? tsc : 0) | ((uint32_t)clip << 8) | ((uint32_t)(det ? 0 : 1) << 16) | ((uint32_t)(det ? 37 : 0) << 24);
+			int word = rc;
+			word = put_lane<1>(word, det ? toa : 0.0f);
+			word = write_lane<2>(word, __float_as_int(det ? amp.x : 0.0f));
+			word = write_lane<3>(word, __float_as_int(det ? amp.y : 0.0f));
+			word = put_lane<4>(word, det ? ci : 0.0f);
+			word = put_lane<5>(word, energy);
+			word = put_lane<6>(word, rssi);
+			word = write_lane<7>(word, (int)flags);
+			recw = word;
+			pend_b = b;
+			pend_any = true;
+		}
+		o = (v3f){ 0.0f, 0.0f, 0.0f };
+		if (rc > 0) {
+			// ---- demodGmskBurst (:2055-2072), fused: delay o decimate as one filter at the symbol instants, usual geometry
+			const int nk = fast_nk;
+			const int w = nk >> 7;                                      // integer shift, -36 .. 0
+			const int fr = nk & 127;
+			const int fidx = (fr >= 2) ? (fr >> 1) : TRX_DELAY_FILTS;   // delay filter row (64 = none)
+			const float ian = __builtin_amdgcn_rcpf(norm2(amp));
+			const float sx = amp.x * ian, sy = -amp.y * ian;            // 1 / amp (Complex.h:75,144-150), 1-ulp reciprocal
+			// park the low-edge rows: lane l < 48 holds floats 4l .. 4l+3 of the burst's 8 x 24 block
+			float *const stage = reinterpret_cast<float *>(D);
+			*reinterpret_cast<float4 *>(stage + 4 * lane) = fast_rows;
+			wave_sync();
+			// lanes 0..47: outputs 4 + 3l .. 6 + 3l with the burst's composite row; lanes 52..55: output e = (-lane) & 3, main
+			// part of its truncated row; lanes 56..59: the same outputs' taps u < 8 (window 8 samples = 2 outputs earlier)
+			const int e = (-lane) & 3;
+			const bool sp = (lane >= 52) && (lane < 60);
+			const float *const tp = sp ? stage + (e + (lane >= 56 ? 4 : 0)) * K4_NTP : comp + fidx * 36 + (K4_U0 + TRX_FUSED_SH);
+			int ic = (lane < 48) ? 4 + 3 * lane : 148;
+			if (sp) ic = (lane < 56) ? e : e - 2;
+			const int c = -24 - w + K4_U0;                              // tap u = K4_U0 of output i reads sample 4i + c
+			const PhBase pb = ph_bases(P, c & 3, ic + (c >> 2));
+			v2f acc[3] = { { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f } };
+			fir24x3(pb, reinterpret_cast<const float4 *>(tp), acc);
+			// rotation (-j)^i, scale 1 / amp and vectorSlicer in registers.  Symbol i wants real((-j)^i s z): with VP = the
+			// lane's entry of [sx, sy, -sx, -sy] (by lane & 3) it is z.x * VP[k] + z.y * VP[k - 1], k = i & 3 = (j - lane) & 3:
+			// a quad permutation of VP, which the DPP operand of v_mul / v_fmac applies for free
+			float vp = (lane & 1) ? sy : sx;
+			vp = (lane & 2) ? -vp : vp;
+			float d0, d1, d2;
+			float a0x = acc[0].x, a0y = acc[0].y;
+			asm volatile("s_nop 1\n\t"
+				     "v_add_f32_dpp %3, %3, %3 row_shl:4 row_mask:0x8 bank_mask:0xf\n\t"      // low-edge outputs (lanes 52..55 += 56..59; row 3 only)
+				     "v_add_f32_dpp %4, %4, %4 row_shl:4 row_mask:0x8 bank_mask:0xf\n\t"
+				     "v_mul_f32_dpp %1, %9, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+				     "v_mul_f32_dpp %2, %9, %7 quad_perm:[2,1,0,3] row_mask:0xf bank_mask:0xf\n\t"
+				     "v_mul_f32_dpp %0, %9, %3 quad_perm:[0,3,2,1] row_mask:0xf bank_mask:0xf\n\t"
+				     "v_fmac_f32_dpp %1, %9, %6 quad_perm:[0,3,2,1] row_mask:0xf bank_mask:0xf\n\t"
+				     "v_fmac_f32_dpp %2, %9, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+				     "v_fmac_f32_dpp %0, %9, %4 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n\t"
+				     : "=&v"(d0), "=&v"(d1), "=&v"(d2), "+v"(a0x), "+v"(a0y)
+				     : "v"(acc[1].x), "v"(acc[1].y), "v"(acc[2].x), "v"(acc[2].y), "v"(vp));
+			o.x = __builtin_amdgcn_fmed3f(fmaf(0.5f, d0, 0.5f), 0.0f, 1.0f);     // vectorSlicer: 0.5 * (x + 1), clamped (:546-556)
+			o.y = __builtin_amdgcn_fmed3f(fmaf(0.5f, d1, 0.5f), 0.0f, 1.0f);
+			o.z = __builtin_amdgcn_fmed3f(fmaf(0.5f, d2, 0.5f), 0.0f, 1.0f);
+		}
+	}
+	// ---- the last burst's output
+	if (pend_any) {
+		int lane;
+		asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+		float *const so = soft + (size_t)pend_b * 148;
+		int *const rp = reinterpret_cast<int *>(results + pend_b);
+		const float oe = o.x;
+		asm volatile("s_bfm_b64 exec, 48, 0\n\t"
+			     "global_store_dwordx3 %0, %1, %2 offset:16\n\t"
+			     "s_bfm_b64 exec, 4, 52\n\t"
+			     "global_store_dword %3, %4, %2\n\t"
+			     "s_bfm_b64 exec, 8, 0\n\t"
+			     "global_store_dword %5, %6, %7\n\t"
+			     "s_mov_b64 exec, -1\n\t"
+			     "s_nop 0"
+			     :: "v"(lane * 12), "v"(o), "s"(so), "v"(((-lane) & 3) * 4), "v"(oe), "v"(lane * 4), "v"(recw), "s"(rp)
+			     : "memory");
+	}
+	if (pooled) {
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			const unsigned d = __hip_atomic_fetch_add(pool_ctr + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+			if (d == gridDim.x - 1u) {
+				__hip_atomic_store(pool_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_store(pool_ctr + 1, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+			}
+		}
+	}
+}

@@ -67,6 +67,8 @@ public:
 		std::memset(t_, 0, sizeof(*t_));
 		t_->magic = TRX_TABLES_MAGIC;
 		t_->version = TRX_TABLES_VERSION;
+		t_->fused_u0 = TRX_FUSED_U0;
+		t_->fused_nt = TRX_FUSED_NT;
 		sinc_table();
 		rotation_tables();
 		pulse_1sps();

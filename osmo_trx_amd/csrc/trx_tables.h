@@ -88,7 +88,8 @@ struct trx_tables {
 	//   edge8[f][4 + i][k]     = edge_lo[f][14 - 4i][k - (8 - U0)]       its taps u < U0 (zero elsewhere), for a lane whose window starts 8
 	//                                                                     samples early (lanes 56..59); taps u >= 32 are 0
 	// (TRX_FUSED_U0 / TRX_FUSED_NT, below: the window of composite taps the fused demodulator runs; 8 / 24 in the text above)
-	float    edge8_pad[2];                              // (edge8 at a multiple of 16 bytes)
+	uint32_t fused_u0, fused_nt;                        // TRX_FUSED_U0 / TRX_FUSED_NT the composite rows (comp_filt's LDS shift, edge8) were generated
+	                                                    // for: a kernel built for another window refuses the blob (and edge8 stays at a multiple of 16 bytes)
 	float    edge8[TRX_DELAY_FILTS + 1][8][TRX_FUSED_NTP];
 	// high-side partial outputs (a burst delayed by a negative whole shift w <= -2 ends at delayed sample n_hi = L - 1 + w:
 	// output i only sees decimator taps t <= tm = n_hi + 15 - 4i, 0..14).  Composite of delay filter f with the decimator
@@ -100,7 +101,7 @@ static_assert(TRX_FUSED_U0 >= 0 && TRX_FUSED_U0 <= 8 && TRX_FUSED_U0 + TRX_FUSED
 	      "fused demodulator tap window");
 
 #define TRX_TABLES_MAGIC   0x54585254u
-#define TRX_TABLES_VERSION 7u
+#define TRX_TABLES_VERSION 8u   /* 8: edge8 rows for taps U0 = 6 .. 29 (round 5), window recorded in fused_u0 / fused_nt */
 
 // XOR swizzle of the sincv index: conflict-free LDS gathers both for lanes whose positions differ
 // by multiples of 16/512 (coarse bisection levels) and by 1/512 steps (fine levels).

@@ -49,6 +49,7 @@ SYMBOLS = {
     "trxhip_destroy": (None, [_VP]),
     "trxhip_strerror": (C.c_char_p, [_I]),
     "trxhip_set_work_pool": (_I, [_VP, _I]),
+    "trxhip_set_nb_kernel": (_I, [_VP, _I]),
     "trxhip_fast_stats": (_I, [_VP, C.POINTER(C.c_uint64), _I]),
     "trxhip_tables_size": (_SZ, []),
     "trxhip_tables_generate_host": (_I, [_VP, _SZ]),
@@ -190,6 +191,10 @@ class TrxHip:
     def set_work_pool(self, enabled):
         """Cross-die work pool of the 4-SPS kernel on / off (results never depend on it; a measurement switch)."""
         _check(self.L.trxhip_set_work_pool(self.h, 1 if enabled else 0), "trxhip_set_work_pool")
+
+    def set_nb_kernel(self, enabled):
+        """Normal-burst kernel + leftover list (default) or the general kernel alone (results are bit-identical; a measurement switch)."""
+        _check(self.L.trxhip_set_nb_kernel(self.h, 1 if enabled else 0), "trxhip_set_nb_kernel")
 
     def fast_stats(self, reset=False):
         """Counters of the fused kernels' FAST detector since the last reset: {"reruns": bursts whose TOA search was re-run in

@@ -45,7 +45,7 @@ BLOB = np.dtype([("magic", "<u4"), ("version", "<u4"), ("dec_taps", "<f4", 16), 
                  ("comp_filt", "<f4", (65, 36)), ("edge_derot", "<c8", 16), ("edge_ideal", "<c8", 9),
                  ("edge_rot2", "<c8", 2), ("edge_step", "<f4"), ("edge_pad", "<f4"),
                  ("unit_neg", "<u8", 21), ("unit_ok", "<u4"), ("unit_pad", "<u4"),
-                 ("edge_lo", "<f4", (65, 15, 36)), ("edge8_pad", "<f4", 2), ("edge8", "<f4", (65, 8, 24)),
+                 ("edge_lo", "<f4", (65, 15, 36)), ("fused_u0", "<u4"), ("fused_nt", "<u4"), ("edge8", "<f4", (65, 8, 24)),
                  ("edge_hi", "<f4", (65, 15, 36))])
 
 
