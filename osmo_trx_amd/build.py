@@ -46,8 +46,8 @@ def _run(cmd):
 def build_lib(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = [os.path.join(CSRC, s) for s in LIB_SOURCES]
-    deps = srcs + [os.path.join(CSRC, "trx_tables.h"), os.path.join(CSRC, "trx_device.h"),
-                   os.path.join(ROOT, "include", "trxhip.h")]
+    # every file of csrc/ (headers and the .hip files that are #included, e.g. trx_kernel_nb.hip) + the public header
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "trxhip.h")]
     if force or _stale(LIB, deps):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared"] + COMMON + ["-o", LIB] + srcs
         if verbose:
@@ -62,7 +62,7 @@ def build_diag(force=False):
     """Profiling-only variant with the phase-ablation hooks (-DTRX_DIAG); never loaded by the product."""
     out = os.path.join(LIBDIR, "libtrxhip_diag.so")
     srcs = [os.path.join(CSRC, s) for s in LIB_SOURCES]
-    if force or _stale(out, srcs + [os.path.join(CSRC, "trx_tables.h")]):
+    if force or _stale(out, [os.path.join(CSRC, f) for f in os.listdir(CSRC)]):
         _run([HIPCC, "--offload-arch=gfx950", "-shared", "-DTRX_DIAG"] + COMMON + ["-o", out] + srcs)
     return out
 
