@@ -19,6 +19,7 @@
 //     prefetch loads: vmcnt retires in order);
 //   * a workgroup's static share is one CONTIGUOUS range of bursts (burst = base + item: one scalar add).
 #include "trx_k4_common.h"
+#include "trx_nb_asm.inc"
 
 #define NB_D_LEN    128                                           /* decimated window (64 used) / parking space of the low-edge tap rows (1 KB) */
 #define NB_CZ_LEN   (TRX_CZ_PAD + TRX_CORR_NARROW + TRX_CZ_PAD)
@@ -39,6 +40,13 @@
 
 typedef float v3f __attribute__((ext_vector_type(3)));
 
+// byte address of an LDS object (what the ds_* instructions of the asm blocks take)
+template <typename T>
+__device__ __forceinline__ unsigned lds_addr(const T *p)
+{
+	return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) T *)p;
+}
+
 __global__ void __launch_bounds__(NB_WPB * WAVE)
 nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__restrict__ params,
 		trxhip_burst_result *__restrict__ results, float *__restrict__ soft, const trx_tables *__restrict__ tab,
@@ -46,6 +54,7 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 {
 	static_assert(NB_TABLES_BYTES % 16 == 0 && (NB_SLICE * 8) % 16 == 0 && (K4_XS * 8) % 16 == 0 && (NB_D_LEN * 8) % 16 == 0, "16-byte LDS accesses");
 	static_assert(NB_LDS_BYTES <= 160 * 1024, "LDS");
+	static_assert(NB_ASM_GDEC_OFF == (TRX_SINCV_LDS + 16 * WAVE + NB_COMP_ROWS * 36) * 4, "tools/gen_nb_asm.py: LDS offset of the decimator taps");
 	constexpr int NLD = 10;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const int lane0 = threadIdx.x & (WAVE - 1);
@@ -228,44 +237,47 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 		int fast_nk = 1 << 30;
 		float4 fast_rows = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 		if (!leave) {
-			// maxAmplitude() > 30000 (:1711-1722, :1746); energyDetect (:1573-1585) and RSSI (Transceiver.cpp:741,751)
+			// maxAmplitude() > 30000 (:1711-1722, :1746)
 			clip = __ballot(amax > TRX_CLIP_THRESH) != 0ull;
-			energy = wave_sum_quad0(epart) * 0.0125f;
-			rssi = fs_db - 3.01029996f * __log2f(energy);
-			wave_sync();
 
 			// ---- detectGeneralBurst window of a normal burst (:1887-1904: target 82, head 10, tail 6 + max_toa -> start 71,
 			// len 16 + max_toa): decimated samples 56 .. 70 + len, one per lane
 			const int len = 16 + (int)max_toa;
 			__builtin_assume(len >= 16 && len <= 16 + NB_MAX_TOA);
-			c32 y = make_float2(0.0f, 0.0f);
-			if (lane < 15 + len) {
-				y = decimate16_sym<true>(P + PH_M0 + (56 + lane) - 4, gdec);
-				D[lane] = y;
-			}
-			const bool unit_bad = __ballot(unit_unsafe(y)) != 0ull;
-			wave_sync();
-			if (unit_bad) {
+			// (hand-placed blocks: tools/gen_nb_asm.py)  decimator of the window + the addition-only correlation's guard
+			const unsigned vd_addr = lds_addr(D) + 8u * (unsigned)lane, vcz_addr = lds_addr(cz) + 8u * (unsigned)lane;
+			unsigned long long bad;
+			asm volatile(NB_ASM_DEC
+				     : [bad] "=s"(bad)
+				     : [pd] "v"(lds_addr(P + PH_M0 + 52) + 8u * (unsigned)lane), [vd] "v"(vd_addr), [zero] "v"(0), [nact] "s"(15 + len)
+				     : NB_ASM_CLOBBERS);
+			if (bad != 0ull) {
 				leave = true;
 			} else {
-				// ---- correlation (lane = lag; the twelve lanes behind the window store the right zero pad) and arg-max
-				trx_v2f acc = { 0.0f, 0.0f };
-				if (lane < len)
-					acc = corr_unit(tsc, D + lane);
-				const c32 yc = make_float2(acc.x, acc.y);
-				if (lane < len + TRX_CZ_PAD)
-					cz[lane] = yc;
-				const float v = norm2(yc);
-				const float m = wave_max(v);
+				// ---- correlation (lane = lag; the twelve lanes behind the window store the right zero pad), arg-max and the
+				// energyDetect sum (:1573-1585); the lane constants of the TOA search are fetched in the reductions' wait states
+				float v;
+				asm volatile(NB_ASM_CORR
+					     : [nrm] "=&v"(v)
+					     : [vd] "v"(vd_addr), [vcz] "v"(vcz_addr), [len] "s"(len), [tsc] "s"(tsc)
+					     : NB_ASM_CLOBBERS);
+				int m_bits, es_bits, bidx;
+				PeakConst pkc;
+				asm volatile(NB_ASM_AMAX("ds_read_b32 %[k4], %[l4] offset:%c[pk]+1024", "ds_read_b32 %[k0], %[l4] offset:%c[pk]",
+							 "ds_read_b32 %[k3], %[l4] offset:%c[pk]+768", "ds_read_b32 %[k1], %[l4] offset:%c[pk]+256",
+							 "ds_read_b32 %[k2], %[l4] offset:%c[pk]+512", "s_nop 0", "s_nop 0", "s_nop 0")
+					     "s_waitcnt lgkmcnt(0)"
+					     : [m] "=s"(m_bits), [es] "=s"(es_bits), [bidx] "=s"(bidx), [k0] "=&v"(pkc.flA), [k1] "=&v"(pkc.loA),
+					       [k2] "=&v"(pkc.hiA), [k3] "=&v"(pkc.offB), [k4] "=&v"(pkc.ratio_off)
+					     : [nrm] "v"(v), [ep] "v"(epart), [l4] "v"(4 * lane), [pk] "n"((TRX_SINCV_LDS + 16 * WAVE + NB_COMP_ROWS * 36 + 16 + 64) * 4)
+					     : NB_ASM_CLOBBERS);
+				// RSSI (Transceiver.cpp:741,751)
+				energy = __int_as_float(es_bits) * 0.0125f;
+				rssi = fs_db - 3.01029996f * __log2f(energy);
 				int hit = 0;
 				int toa512 = 0;
-				if (m > 0.0f) {
-					const unsigned long long eqm = __ballot(v == m);
-					const int bidx = __ffsll((unsigned long long)eqm) - 1;
+				if (m_bits != 0) {                                          // fastPeakDetect: a maximum above zero exists (:1120-1139)
 					const float *const hdr = lhdr + 8 * tsc;
-					PeakConst pkc;
-					pkc.flA = pkcl[0 * WAVE + lane]; pkc.loA = pkcl[1 * WAVE + lane]; pkc.hiA = pkcl[2 * WAVE + lane];
-					pkc.offB = pkcl[3 * WAVE + lane]; pkc.ratio_off = pkcl[4 * WAVE + lane];
 					auto on_toa = [&](int t512) {
 						// TOA in 1/512 symbol -> the demodulator's shift and delay filter; fetch of the low-edge tap rows
 						toa512 = t512;
