@@ -25,7 +25,7 @@
 #define NB_CZ_LEN   (TRX_CZ_PAD + TRX_CORR_NARROW + TRX_CZ_PAD)
 #define NB_SLICE    (K4_XS + NB_D_LEN + NB_CZ_LEN)                /* complex samples per wave */
 #define NB_COMP_ROWS (TRX_DELAY_FILTS + 1)
-#define NB_TABLES_FLOATS (TRX_SINCV_LDS + 16 * WAVE + NB_COMP_ROWS * 36 + 16 + 8 * 8 + 5 * WAVE)
+#define NB_TABLES_FLOATS (TRX_SINCV_LDS + 16 * WAVE + NB_COMP_ROWS * 36 + 16 + 8 * 8 + 5 * WAVE + 3 * WAVE)
 #define NB_TABLES_BYTES (NB_TABLES_FLOATS * 4)
 #define NB_WPB 16
 #define NB_POOL_RING 64
@@ -67,7 +67,8 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 	float *const comp = wa4f + 16 * WAVE;                          // [65][36] composite delay-o-decimate filters (shifted by TRX_FUSED_SH)
 	float *const gdec = comp + NB_COMP_ROWS * 36;                  // [16] decimator taps
 	float *const lhdr = gdec + 16;                                 // [8][8] headers of the eight training sequences
-	int *const pkcl = reinterpret_cast<int *>(lhdr + 8 * 8);       // [5][64] PeakConst fields by lane
+	int *const pkcl = reinterpret_cast<int *>(lhdr + 8 * 8);       // [5][64] PeakConst fields by lane (the exact re-run of the TOA search)
+	int *const lcn = pkcl + 5 * WAVE;                              // [3][64] lane constants of the hand-placed detection blocks (below)
 	c32 *const wbase = reinterpret_cast<c32 *>(smem + NB_TABLES_BYTES) + (size_t)wave * NB_SLICE;
 	int *const wg_next = reinterpret_cast<int *>(reinterpret_cast<c32 *>(smem + NB_TABLES_BYTES) + (size_t)NB_WPB * NB_SLICE);
 	int *const pool_g = wg_next + 4;
@@ -99,6 +100,10 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 		pkcl[2 * WAVE + threadIdx.x] = pc0.hiA;
 		pkcl[3 * WAVE + threadIdx.x] = pc0.offB;
 		pkcl[4 * WAVE + threadIdx.x] = pc0.ratio_off;
+		// byte offsets relative to &cz[bidx]: the lane's peak-ratio term; round A's first tap (cz + bidx - 1 + flA - 7); round B's offset
+		lcn[0 * WAVE + threadIdx.x] = pc0.ratio_off * 8;
+		lcn[1 * WAVE + threadIdx.x] = (pc0.flA - 8) * 8;
+		lcn[2 * WAVE + threadIdx.x] = pc0.offB;
 	}
 	for (int i = lane0; i < NB_SLICE; i += WAVE)
 		wbase[i] = make_float2(0.0f, 0.0f);
@@ -109,6 +114,10 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 	__syncthreads();
 
 	const float fs_db = 6.02059991f * __log2f(full_scale);          // 20*log10(full_scale)
+	// the peak-ratio gate's estimate (tools/gen_nb_asm.py, DETA): thresh^2 / num for the four possible term counts, and the
+	// constant term of its certain-pass bound
+	const float thr2 = thresh * thresh;
+	const float gk5 = thr2 * 0.2f, gk6 = thr2 * (1.0f / 6.0f), gk7 = thr2 * (1.0f / 7.0f), gk8 = thr2 * 0.125f, gc0 = thr2 * 1.0001e-5f;
 	// ---- work distribution: groups of 16 consecutive bursts.  Static part: workgroup w owns ONE contiguous range of groups
 	// (7/8 of the batch when the cross-die pool is on, everything otherwise); the rest is drawn group by group from a
 	// device-wide counter (see burst_pull4_kernel).  Waves claim items one at a time from the workgroup's LDS counter.
@@ -262,14 +271,13 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 					     : [vd] "v"(vd_addr), [vcz] "v"(vcz_addr), [len] "s"(len), [tsc] "s"(tsc)
 					     : NB_ASM_CLOBBERS);
 				int m_bits, es_bits, bidx;
-				PeakConst pkc;
-				asm volatile(NB_ASM_AMAX("ds_read_b32 %[k4], %[l4] offset:%c[pk]+1024", "ds_read_b32 %[k0], %[l4] offset:%c[pk]",
-							 "ds_read_b32 %[k3], %[l4] offset:%c[pk]+768", "ds_read_b32 %[k1], %[l4] offset:%c[pk]+256",
-							 "ds_read_b32 %[k2], %[l4] offset:%c[pk]+512", "s_nop 0", "s_nop 0", "s_nop 0")
+				int kr, ka, kb;                                             // lane constants (lcn[])
+				asm volatile(NB_ASM_AMAX("ds_read_b32 %[kr], %[l4] offset:%c[lc]", "ds_read_b32 %[ka], %[l4] offset:%c[lc]+256",
+							 "ds_read_b32 %[kb], %[l4] offset:%c[lc]+512", "s_nop 0", "s_nop 0", "s_nop 0", "s_nop 0", "s_nop 0")
 					     "s_waitcnt lgkmcnt(0)"
-					     : [m] "=s"(m_bits), [es] "=s"(es_bits), [bidx] "=s"(bidx), [k0] "=&v"(pkc.flA), [k1] "=&v"(pkc.loA),
-					       [k2] "=&v"(pkc.hiA), [k3] "=&v"(pkc.offB), [k4] "=&v"(pkc.ratio_off)
-					     : [nrm] "v"(v), [ep] "v"(epart), [l4] "v"(4 * lane), [pk] "n"((TRX_SINCV_LDS + 16 * WAVE + NB_COMP_ROWS * 36 + 16 + 64) * 4)
+					     : [m] "=s"(m_bits), [es] "=s"(es_bits), [bidx] "=s"(bidx), [kr] "=&v"(kr), [ka] "=&v"(ka), [kb] "=&v"(kb)
+					     : [nrm] "v"(v), [ep] "v"(epart), [l4] "v"(4 * lane),
+					       [lc] "n"((TRX_SINCV_LDS + 16 * WAVE + NB_COMP_ROWS * 36 + 16 + 64 + 5 * WAVE) * 4)
 					     : NB_ASM_CLOBBERS);
 				// RSSI (Transceiver.cpp:741,751)
 				energy = __int_as_float(es_bits) * 0.0125f;
@@ -278,19 +286,58 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 				int toa512 = 0;
 				if (m_bits != 0) {                                          // fastPeakDetect: a maximum above zero exists (:1120-1139)
 					const float *const hdr = lhdr + 8 * tsc;
-					auto on_toa = [&](int t512) {
+					// edge gate, peak-ratio gate, round A of the TOA bisection and its walk (DETA); round B, walk, peak value (DETB)
+					int st, e512;
+					float km;
+					asm volatile(NB_ASM_DETA
+						     : [st] "=&s"(st), [e] "=&s"(e512), [km] "=&v"(km)
+						     : [bidx] "s"(bidx), [len] "s"(len), [czb] "s"(lds_addr(cz)), [kr] "v"(kr), [ka] "v"(ka), [l16] "v"(16 * lane),
+						       [k5] "s"(gk5), [k6] "s"(gk6), [k7] "s"(gk7), [k8] "s"(gk8), [c0] "v"(gc0), [nodes] "s"(0x1555555555555555ull)
+						     : NB_ASM_CLOBBERS);
+					int xr_bits = 0, xi_bits = 0;
+					if (st == 1) {
+						asm volatile(NB_ASM_DETB
+							     : [st] "=&s"(st), [toa] "=&s"(toa512), [xr] "=&s"(xr_bits), [xi] "=&s"(xi_bits)
+							     : [e] "s"(e512), [kb] "v"(kb), [czb] "s"(lds_addr(cz)), [km] "v"(km)
+							     : NB_ASM_CLOBBERS);
+					}
+					c32 xcorr = make_float2(__int_as_float(xr_bits), __int_as_float(xi_bits));
+					if (st == 3) {
+						// an uncertified early / late decision on the path: the search again in the reference's operand order
+						if (lane == 0)
+							atomicAdd(&g_trx_fast_stats[0], 1ull);
+						PeakConst pkc;
+						pkc.flA = pkcl[0 * WAVE + lane]; pkc.loA = pkcl[1 * WAVE + lane]; pkc.hiA = pkcl[2 * WAVE + lane];
+						pkc.offB = pkcl[3 * WAVE + lane]; pkc.ratio_off = pkcl[4 * WAVE + lane];
+						peak_detect_spec(cz, bidx, sincv, pkc, lane, &toa512, &xcorr, wa4);
+						toa512 = uni(toa512);
+						xcorr.x = unif(xcorr.x);
+						xcorr.y = unif(xcorr.y);
+						st = 1;
+					}
+					if (st == 2)
+						leave = true;                                          // the gate is too close to call for the estimate
+					if (st == 1) {
+						hit = 1;
 						// TOA in 1/512 symbol -> the demodulator's shift and delay filter; fetch of the low-edge tap rows
-						toa512 = t512;
-						const int nk = -(t512 - (int)(hdr[5] * 512.0f) - 10 * 512);
-						if ((unsigned)(-(nk >> 7)) > 36u)
-							return;
-						fast_nk = nk;
-						const int fr = nk & 127;
-						const int fidx = (fr >= 2) ? (fr >> 1) : TRX_DELAY_FILTS;
-						fast_rows = reinterpret_cast<const float4 *>(&tab->edge8[fidx][0][0])[lane];   // (lanes >= 48: the next row's, unused)
-					};
-					hit = detect_tail_h<true>(D - 56, 156, cz, hdr, 16, thresh, 71, len, bidx, sincv, pkc, lane, &toa, &amp, &ci, on_toa, wa4, 0 DIAG_PASS WI_PASS);
-					wave_sync();
+						const int nk = -(toa512 - (int)(hdr[5] * 512.0f) - 10 * 512);
+						if ((unsigned)(-(nk >> 7)) <= 36u) {
+							fast_nk = nk;
+							const int fr = nk & 127;
+							const int fidx = (fr >= 2) ? (fr >> 1) : TRX_DELAY_FILTS;
+							fast_rows = reinterpret_cast<const float4 *>(&tab->edge8[fidx][0][0])[lane];   // (lanes >= 48: the next row's, unused)
+						}
+						// ---- computeCI (:1608-1639): S = mean sample power over the sequence at the rounded TOA (tree sum), C from the peak
+						const int rt = (toa512 >= 0) ? ((toa512 + 256) >> 9) : -((-toa512 + 256) >> 9);
+						const float pw = norm2(D[rt + (lane < 16 ? lane : 0)]);
+						float S = lane_val(row_sum(pw), 0);
+						S *= 0.0625f;
+						const float C = norm2(xcorr) * hdr[7];
+						ci = 3.0103f * __log2f(C * __builtin_amdgcn_rcpf(S - C));
+						const c32 a = cmul(xcorr, make_float2(hdr[2], hdr[3]));  // xcorr / sync->gain  (:1701)
+						amp = make_float2(unif(a.x), unif(a.y));
+						toa = unif((float)toa512 * (1.0f / 512.0f) - hdr[5]);      // :1704
+					}
 				}
 				rc = hit ? TRXHIP_TSC : (clip ? -TRXHIP_SIGERR_CLIP : 0);                 // :1764, :1953-1954
 				toa -= 10.0f;                                                              // :1768

@@ -10,7 +10,7 @@ blocks below are therefore whole phases of a burst, and this script CHECKS what 
     VGPR -> DPP source 2; VALU-written SGPR / VCC -> VALU reader 2; transcendental result -> VALU reader 1; VALU-written
     VGPR -> v_readlane 1; VALU-written SGPR -> v_readlane lane select 4, -> VMEM address 5; x3 / x4 store data 2;
   * every register loaded from LDS is covered by an s_waitcnt lgkmcnt(n) before its first use (LDS returns in order).
-Registers: operands the compiler allocates are %[name]; the blocks' temporaries are the fixed VGPRs v88..v127 and SGPRs
+Registers: operands the compiler allocates are %[name]; the blocks' temporaries are the fixed VGPRs v64..v127 and SGPRs
 s88..s99, declared as clobbers of every statement (NB_ASM_CLOBBERS)."""
 import os
 import re
@@ -136,7 +136,7 @@ class Block:
             else:
                 dsts, srcs = ops[:1], ops[1:]
             if is_cmp and op.endswith("_e32"):
-                dsts, srcs = ["vcc"], ops
+                dsts, srcs = ["vcc"], ops[1:]
             if op.startswith(("v_cndmask_b32_e32", "v_addc", "v_subb")) or (op.startswith("v_cndmask_b32") and len(ops) == 3):
                 srcs = srcs + ["vcc"]
             if op in ("v_fmac_f32_e32", "v_fmac_f32_dpp", "v_pk_fma_f32") or op.startswith(("v_fmac", "v_mac")) or \
@@ -326,6 +326,29 @@ def block_corr():
     return b
 
 
+def check_paths(b):
+    """blocks with forward branches: the fall-through order and, for every label, the order that starts at the block's head and
+    continues at the label from each branch to it (state at the branch)"""
+    errs = b.check()
+    lines = b.ins
+    for i, t in enumerate(lines):
+        m = re.match(r"^s_cbranch_\w+ (\S+)$|^s_branch (\S+)$", t.strip())
+        if not m:
+            continue
+        lab = (m.group(1) or m.group(2)) + ":"
+        if lab not in lines:
+            continue
+        j = lines.index(lab)
+        if j < i:
+            continue                                                # (a backward branch: the join re-enters checked code)
+        v = Block(f"{b.name}[{t.strip()}]", [n[2:-1] for n in b.sgpr_ops])
+        v.ins = lines[:i] + lines[j:]
+        for e in v.check():
+            if e.split(": ", 1)[1] not in [x.split(": ", 1)[1] for x in errs]:
+                errs.append(e)
+    return errs
+
+
 def check_variants(b):
     """CORR: check each variant as its own straight line (prefix + variant t + suffix)"""
     errs = []
@@ -381,6 +404,244 @@ def block_amax(fill):
     return b
 
 
+
+def fhex(x):
+    import struct
+    return "0x%08x" % struct.unpack("<I", struct.pack("<f", x))[0]
+
+
+KAPPA = 6e-6                     # TRX_FAST_KAPPA (trx_device.h): certified-comparison margin of the FAST detector
+D_ALL = "row_mask:0xf bank_mask:0xf"
+
+
+def fast_walk(b, c, p, pos, levels, w="b64"):
+    """three scalar instructions per level of the bisection tree: bit position of node (L, p), its "early < late" bit, p = 2p + bit"""
+    b(f"s_mov_b32 {p}, 0")
+    for lw in range(levels):
+        b(f"s_lshl1_add_u32 {pos}, {p}, {2 * ((1 << lw) - 1)}")
+        b(f"s_bitcmp1_{w} {c}, {pos}")
+        b(f"s_addc_u32 {p}, {p}, {p}")
+
+
+def careful_walk(b, c, cd, p, pos, levels, unsure_label, w="b64"):
+    """the same walk, checking that every node ON THE PATH has a certified decision (cd = c | c >> 1)"""
+    b(f"s_mov_b32 {p}, 0")
+    for lw in range(levels):
+        b(f"s_lshl1_add_u32 {pos}, {p}, {2 * ((1 << lw) - 1)}")
+        b(f"s_bitcmp0_{w} {cd}, {pos}")
+        b(f"s_cbranch_scc1 {unsure_label}")
+        b(f"s_bitcmp1_{w} {c}, {pos}")
+        b(f"s_addc_u32 {p}, {p}, {p}")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# block DETA: detectBurst() behind fastPeakDetect (sigProcLib.cpp:1683-1695): edge gate, computePeakRatio gate (:1541-1571)
+# on an estimate with a proven margin, round A of peakDetect()'s bisection (levels 0..4, trx_device.h peak_detect_fast) and
+# its certified tree walk.
+#   in : %[bidx] %[len] %[czb] SGPR (czb = LDS byte address of cz[0]); %[kr] %[ka] VGPR lane constants (byte offsets of the
+#        lane's peak-ratio term and of round A's first tap, relative to &cz[bidx]); %[l16] VGPR 16 * lane; %[k5]..%[k8] SGPR
+#        thresh^2 / n; %[c0] VGPR thresh^2 * 1.0001e-5; %[nodes] SGPR pair 0x1555555555555555
+#   out: %[st] SGPR 0 miss / 1 found / 2 gate too close to call / 3 an uncertified decision on the path; %[e] SGPR earlyIndex
+#        * 512 after round A; %[km] VGPR KAPPA * |corr[bidx]|^2 (round B's margin term)
+# The gate: reference |amp| / (sqrtf(avg / num) + 1e-5) < thresh.  Estimate t2 = avg * thresh^2 / num (avg tree-summed: within
+# 6e-7; t2 within 1.2e-6 of the reference's squared threshold without its 1e-5).  (rms + 1e-5)^2 >= rms^2, so amp2 < t2 (1 -
+# 1.2e-5) is a certain miss; (rms + 1e-5)^2 <= rms^2 (1 + 1e-5) + 1.0001e-5 (2ab <= a^2 + b^2), so amp2 > t2 * 1.000024 + c0 is
+# a certain pass; in between (one burst in ~5e4) the burst is left to the general kernel, which rounds as the reference does.
+# ------------------------------------------------------------------------------------------------------------------
+def block_deta(wa4_off):
+    b = Block("DETA", ("bidx", "len", "czb", "k5", "k6", "k7", "k8", "nodes", "st", "e"))
+    X = lambda k: vreg(88 + 2 * k, 2)            # round A samples 0..7
+    Y = lambda k: vreg(112 + 2 * k, 2)           # samples 8..15
+    b("s_mov_b32 %[st], 0")
+    b("s_cmp_lt_i32 %[bidx], 3")                                   # :1683
+    b("s_cbranch_scc1 .Lnb_da_end")
+    b("s_sub_u32 s88, %[len], 3")
+    b("s_cmp_gt_i32 %[bidx], s88")
+    b("s_cbranch_scc1 .Lnb_da_end")
+    b("s_lshl3_add_u32 s89, %[bidx], %[czb]")                      # &cz[bidx]
+    b("s_add_u32 s90, %[len], -1")
+    b("v_mov_b32_e32 v64, s89")
+    b("v_add_u32_e32 v65, s89, %[kr]")
+    b("s_lshl3_add_u32 s90, s90, %[czb]")                          # &cz[len - 1]
+    b("v_add_u32_e32 v66, s89, %[ka]")
+    b("ds_read_b64 v[68:69], v64")                                 # corr[bidx]
+    b("ds_read_b64 v[70:71], v65")                                 # this lane's peak-ratio term (read before cz[len - 1] is zeroed)
+    b("v_mov_b32_e32 v67, s90")
+    b("v_mov_b64_e32 v[72:73], 0")
+    b("s_mov_b64 exec, 1")
+    b("ds_write_b64 v67, v[72:73]")                                # interpolatePoint() never reads the last correlation sample (:1105)
+    b("s_mov_b64 exec, -1")
+    b(f"ds_read_b128 v[76:79], %[l16] offset:{wa4_off}")
+    b(f"ds_read_b128 v[80:83], %[l16] offset:{wa4_off + 1024}")
+    for u in range(8):
+        b(f"ds_read_b64 {X(u)}, v66 offset:{8 * u}")
+    b("v_mov_b64_e32 v[84:85], 0")                                 # p0, p1 of the two-chain sums
+    b("v_mov_b64_e32 v[86:87], 0")
+    # number of in-range terms (:1555-1562) -> thresh^2 / num
+    b("s_add_u32 s91, %[bidx], -1")
+    b("s_sub_u32 s92, %[len], %[bidx]")
+    b("s_min_u32 s91, s91, 4")
+    b("s_add_u32 s92, s92, -2")
+    b("s_min_u32 s92, s92, 4")
+    b("s_add_u32 s91, s91, s92")
+    b("s_cmp_eq_u32 s91, 8")
+    b("s_cselect_b32 s92, %[k8], %[k7]")
+    b("s_cmp_eq_u32 s91, 6")
+    b("s_cselect_b32 s93, %[k6], %[k5]")
+    b("s_cmp_ge_u32 s91, 7")
+    b("s_cselect_b32 s92, s92, s93")
+    b("s_waitcnt lgkmcnt(11)")
+    b("v_pk_mul_f32 v[70:71], v[70:71], v[70:71]")
+    b("v_pk_mul_f32 v[68:69], v[68:69], v[68:69]")
+    b("v_add_f32_e32 v75, v71, v70")
+    b("v_add_f32_e32 v74, v69, v68")                               # m = |corr[bidx]|^2
+    b("s_nop 1")
+    b(f"v_add_f32_dpp v75, v75, v75 quad_perm:[1,0,3,2] {D_ALL}")
+    b(f"v_mul_f32_e32 %[km], {fhex(KAPPA)}, v74")
+    b("s_nop 0")
+    b(f"v_add_f32_dpp v75, v75, v75 quad_perm:[2,3,0,1] {D_ALL}")
+    b("s_nop 1")
+    b(f"v_add_f32_dpp v75, v75, v75 row_half_mirror {D_ALL}")     # every lane: sum of the eight terms
+    b("v_mul_f32_e32 v112, s92, v75")                              # t2
+    b(f"v_mul_f32_e32 v113, {fhex(1.0 - 1.2e-5)}, v112")
+    b(f"v_fmamk_f32 v114, v112, {fhex(1.000024)}, %[c0]")
+    b("v_cmp_lt_f32_e32 vcc, v74, v113")
+    b("s_cbranch_vccnz .Lnb_da_wait_end")                          # certain miss
+    b("v_cmp_gt_f32_e32 vcc, v74, v114")
+    b("s_mov_b32 %[st], 2")
+    b("s_cbranch_vccz .Lnb_da_wait_end")                           # too close to call
+    # ---- round A: interp over taps fl-7 .. fl+8 with this lane's weights, two FMA chains (even / odd taps)
+    b(f"ds_read_b128 v[104:107], %[l16] offset:{wa4_off + 2048}")
+    b(f"ds_read_b128 v[108:111], %[l16] offset:{wa4_off + 3072}")
+    for u in range(8):
+        b(f"ds_read_b64 {Y(u)}, v66 offset:{8 * (8 + u)}")
+    b("s_waitcnt lgkmcnt(10)")
+
+    def fmas(xs, qa, qb):
+        for u in range(0, 8, 2):
+            q = qb if (u & 4) else qa
+            hp = vreg(q + (2 if (u & 2) else 0), 2)
+            b(f"v_pk_fma_f32 v[84:85], {xs(u)}, {hp}, v[84:85] op_sel:[0,0,0] op_sel_hi:[1,0,1]")
+            b(f"v_pk_fma_f32 v[86:87], {xs(u + 1)}, {hp}, v[86:87] op_sel:[0,1,0] op_sel_hi:[1,1,1]")
+    fmas(X, 76, 80)
+    b("s_waitcnt lgkmcnt(0)")
+    fmas(Y, 104, 108)
+    b("s_nop 0")
+    b("v_pk_add_f32 v[84:85], v[84:85], v[86:87]")
+    b("s_nop 0")
+    b("v_pk_mul_f32 v[84:85], v[84:85], v[84:85]")
+    b("s_nop 0")
+    b("v_add_f32_e32 v88, v85, v84")                               # nv = |interp|^2
+    # certified comparison: r = KAPPA (nv + m); sure "early < late" when hi_E < lo_L, sure "early > late" when hi_L < lo_E
+    b(f"v_fmamk_f32 v89, v88, {fhex(KAPPA)}, %[km]")
+    b("v_sub_f32_e32 v90, v88, v89")
+    b("v_add_f32_e32 v91, v88, v89")
+    b("s_lshl_b32 s94, %[bidx], 9")
+    b(f"v_mov_b32_dpp v90, v90 quad_perm:[1,0,3,2] {D_ALL}")
+    b("v_cmp_lt_f32_e64 s[88:89], v91, v90")
+    b("s_mov_b32 %[st], 1")
+    b("s_lshr_b64 s[90:91], s[88:89], 1")
+    b("s_or_b64 s[90:91], s[90:91], s[88:89]")
+    b("s_and_b64 s[92:93], s[90:91], %[nodes]")
+    b("s_cmp_eq_u64 s[92:93], %[nodes]")
+    b("s_cbranch_scc0 .Lnb_da_careful")
+    fast_walk(b, "s[88:89]", "s95", "s96", 5)
+    b(".Lnb_da_walked:")
+    b("s_lshl_b32 s95, s95, 5")                                    # off = 32 p - 496; E = (bidx - 1) * 512 + off
+    b("s_add_u32 s94, s94, s95")
+    b("s_add_u32 %[e], s94, -1008")
+    b("s_branch .Lnb_da_end")
+    b(".Lnb_da_careful:")
+    careful_walk(b, "s[88:89]", "s[90:91]", "s95", "s96", 5, ".Lnb_da_unsure")
+    b("s_branch .Lnb_da_walked")
+    b(".Lnb_da_unsure:")
+    b("s_mov_b32 %[st], 3")
+    b("s_branch .Lnb_da_end")
+    b(".Lnb_da_wait_end:")
+    b("s_waitcnt lgkmcnt(0)")
+    b(".Lnb_da_end:")
+    return b
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# block DETB: round B of the bisection (levels 5..8 on lanes 0..29, the sixteen possible final positions on lanes 32..47),
+# its certified walk, and the interpolated peak value at the final position (peakDetect(), :1141-1186).
+#   in : %[e] SGPR earlyIndex * 512; %[kb] VGPR lane constant offB; %[czb] SGPR; %[km] VGPR
+#   out: %[st] SGPR 1 / 3; %[toa] SGPR final position * 512; %[xr] %[xi] SGPR interpolated value
+# sinc LUT index of a fraction f: taps i <= fl use q = 512 k + f, taps i > fl use q = 512 k + (512 - f), XOR-swizzled
+# (trx_tables.h: q ^ ((q >> 4) & 31); swz(512) = 512, so f = 0 needs no special case).  sincv[] sits at LDS offset 0.
+# ------------------------------------------------------------------------------------------------------------------
+def block_detb():
+    b = Block("DETB", ("e", "czb", "st", "toa", "xr", "xi"))
+    X = lambda k: vreg(80 + 2 * k, 2)
+    W = lambda k: 96 + k
+    Y = lambda k: vreg(104 + 2 * k, 2)
+    V = lambda k: 120 + k
+    b("v_mov_b64_e32 v[64:65], 0")                                 # p0, p1 (lanes outside the round keep 0: |interp|^2 = 0)
+    b("v_mov_b64_e32 v[66:67], 0")
+    b("v_add_u32_e32 v68, %[e], %[kb]")                            # position of this lane (1/512 symbol)
+    b("s_add_u32 s88, %[czb], -56")
+    b("s_mov_b32 exec_lo, 0x3fffffff")                             # lanes 0..29: 15 nodes x {early, late}; 32..47: final positions
+    b("s_mov_b32 exec_hi, 0xffff")
+    b("v_ashrrev_i32_e32 v69, 9, v68")
+    b("v_and_b32_e32 v70, 0x1ff, v68")
+    b("v_lshl_add_u32 v69, v69, 3, s88")                           # &cz[fl - 7]
+    b("v_bfe_u32 v71, v70, 4, 5")
+    b("v_sub_u32_e32 v72, 0x200, v70")
+    b("v_xor_b32_e32 v71, v71, v70")
+    b("v_bfe_u32 v73, v72, 4, 5")
+    b("v_lshlrev_b32_e32 v71, 2, v71")                             # taps fl-7 .. fl: sincv[swz(f) + 512 (7 - u)]
+    b("v_xor_b32_e32 v72, v73, v72")
+    b("v_lshlrev_b32_e32 v72, 2, v72")                             # taps fl+1 .. fl+8: sincv[swz(512 - f) + 512 u]
+    for u in range(8):
+        b(f"ds_read_b64 {X(u)}, v69 offset:{8 * u}")
+        b(f"ds_read_b32 {vreg(W(u))}, v71 offset:{2048 * (7 - u)}")
+
+    def fma2(xs, ws, u):
+        b(f"v_pk_fma_f32 v[64:65], {xs(u)}, {vreg(ws(u), 2)}, v[64:65] op_sel:[0,0,0] op_sel_hi:[1,0,1]")
+        b(f"v_pk_fma_f32 v[66:67], {xs(u + 1)}, {vreg(ws(u), 2)}, v[66:67] op_sel:[0,1,0] op_sel_hi:[1,1,1]")
+    # software pipeline: 12..16 loads in flight; each step consumes two taps of the first half and issues two of the second
+    for k in range(4):
+        b("s_waitcnt lgkmcnt(12)")
+        fma2(X, W, 2 * k)
+        for u in (2 * k, 2 * k + 1):
+            b(f"ds_read_b64 {Y(u)}, v69 offset:{8 * (8 + u)}")
+            b(f"ds_read_b32 {vreg(V(u))}, v72 offset:{2048 * u}")
+    for k in range(4):
+        b(f"s_waitcnt lgkmcnt({12 - 4 * k})")
+        fma2(Y, V, 2 * k)
+    b("s_mov_b64 exec, -1")
+    b("v_pk_add_f32 v[74:75], v[64:65], v[66:67]")                 # interpolated value at this lane's position
+    b("s_add_u32 s92, %[e], 497")
+    b("v_pk_mul_f32 v[76:77], v[74:75], v[74:75]")
+    b("s_mov_b32 %[st], 1")
+    b("v_add_f32_e32 v78, v77, v76")
+    b(f"v_fmamk_f32 v79, v78, {fhex(KAPPA)}, %[km]")
+    b("v_sub_f32_e32 v96, v78, v79")
+    b("v_add_f32_e32 v97, v78, v79")
+    b("s_nop 0")
+    b(f"v_mov_b32_dpp v96, v96 quad_perm:[1,0,3,2] {D_ALL}")
+    b("v_cmp_lt_f32_e64 s[88:89], v97, v96")
+    b("s_lshr_b32 s90, s88, 1")
+    b("s_or_b32 s90, s90, s88")
+    b("s_and_b32 s91, s90, 0x15555555")
+    b("s_cmp_eq_u32 s91, 0x15555555")
+    b("s_cbranch_scc0 .Lnb_db_careful")
+    fast_walk(b, "s88", "s94", "s95", 4, "b32")
+    b(".Lnb_db_walked:")
+    b("s_add_u32 s93, s94, 32")                                    # lane that evaluated the final position
+    b("s_lshl1_add_u32 %[toa], s94, s92")                          # E + offB + 512, offB = 2 p - 15
+    b("v_readlane_b32 %[xr], v74, s93")
+    b("v_readlane_b32 %[xi], v75, s93")
+    b("s_branch .Lnb_db_end")
+    b(".Lnb_db_careful:")
+    careful_walk(b, "s88", "s90", "s94", "s95", 4, ".Lnb_db_unsure", "b32")
+    b("s_branch .Lnb_db_walked")
+    b(".Lnb_db_unsure:")
+    b("s_mov_b32 %[st], 3")
+    b(".Lnb_db_end:")
+    return b
+
 def c_string(lines):
     out = []
     for t in lines:
@@ -396,10 +657,13 @@ def main():
     blocks = {}
     blocks["DEC"] = block_dec(gdec_off)
     blocks["CORR"] = block_corr()
-    errs = blocks["DEC"].check() + check_variants(blocks["CORR"])
+    wa4_off = SINCV_LDS * 4
+    blocks["DETA"] = block_deta(wa4_off)
+    blocks["DETB"] = block_detb()
+    errs = blocks["DEC"].check() + check_variants(blocks["CORR"]) + check_paths(blocks["DETA"]) + check_paths(blocks["DETB"])
     hdr = ["// trx_nb_asm.inc -- GENERATED by tools/gen_nb_asm.py (hazards and LDS waits checked there); do not edit.",
            f"#define NB_ASM_GDEC_OFF {gdec_off}",
-           "#define NB_ASM_CLOBBERS " + ", ".join(f'"v{i}"' for i in range(88, 128)) + ", " +
+           "#define NB_ASM_CLOBBERS " + ", ".join(f'"v{i}"' for i in range(64, 128)) + ", " +
            ", ".join(f'"s{i}"' for i in range(88, 100)) + ', "vcc", "scc", "memory"']
     for name, b in blocks.items():
         hdr.append(f"#define NB_ASM_{name} \\")
