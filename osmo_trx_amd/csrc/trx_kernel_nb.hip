@@ -25,7 +25,7 @@
 #define NB_CZ_LEN   (TRX_CZ_PAD + TRX_CORR_NARROW + TRX_CZ_PAD)
 #define NB_SLICE    (K4_XS + NB_D_LEN + NB_CZ_LEN)                /* complex samples per wave */
 #define NB_COMP_ROWS (TRX_DELAY_FILTS + 1)
-#define NB_TABLES_FLOATS (TRX_SINCV_LDS + 16 * WAVE + NB_COMP_ROWS * 36 + 16 + 8 * 8 + 5 * WAVE + 3 * WAVE)
+#define NB_TABLES_FLOATS (TRX_SINCV_LDS + 16 * WAVE + NB_COMP_ROWS * 36 + 16 + 8 * 8 + 5 * WAVE + 5 * WAVE)
 #define NB_TABLES_BYTES (NB_TABLES_FLOATS * 4)
 #define NB_WPB 16
 #define NB_POOL_RING 64
@@ -68,7 +68,7 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 	float *const gdec = comp + NB_COMP_ROWS * 36;                  // [16] decimator taps
 	float *const lhdr = gdec + 16;                                 // [8][8] headers of the eight training sequences
 	int *const pkcl = reinterpret_cast<int *>(lhdr + 8 * 8);       // [5][64] PeakConst fields by lane (the exact re-run of the TOA search)
-	int *const lcn = pkcl + 5 * WAVE;                              // [3][64] lane constants of the hand-placed detection blocks (below)
+	int *const lcn = pkcl + 5 * WAVE;                              // [5][64] lane constants of the hand-placed blocks (below)
 	c32 *const wbase = reinterpret_cast<c32 *>(smem + NB_TABLES_BYTES) + (size_t)wave * NB_SLICE;
 	int *const wg_next = reinterpret_cast<int *>(reinterpret_cast<c32 *>(smem + NB_TABLES_BYTES) + (size_t)NB_WPB * NB_SLICE);
 	int *const pool_g = wg_next + 4;
@@ -104,6 +104,12 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 		lcn[0 * WAVE + threadIdx.x] = pc0.ratio_off * 8;
 		lcn[1 * WAVE + threadIdx.x] = (pc0.flA - 8) * 8;
 		lcn[2 * WAVE + threadIdx.x] = pc0.offB;
+		// the demodulator's lanes: 0..47 symbols 4 + 3 lane .. with the composite row; 52..55 symbol e = (-lane) & 3, main part of its
+		// truncated row (row e of the parked block); 56..59 the same symbols' taps u < 8 (row 4 + e, window two symbols earlier)
+		const int l = threadIdx.x, e = (-l) & 3;
+		const bool sp = l >= 52 && l < 60;
+		lcn[3 * WAVE + l] = 8 * (sp ? (l < 56 ? e : e - 2) : (l < 48 ? 4 + 3 * l : 148));   // first symbol, bytes
+		lcn[4 * WAVE + l] = sp ? (e + (l >= 56 ? 4 : 0)) * K4_NTP * 4 : -1;                 // tap row inside the parked block, bytes
 	}
 	for (int i = lane0; i < NB_SLICE; i += WAVE)
 		wbase[i] = make_float2(0.0f, 0.0f);
@@ -118,6 +124,17 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 	// constant term of its certain-pass bound
 	const float thr2 = thresh * thresh;
 	const float gk5 = thr2 * 0.2f, gk6 = thr2 * (1.0f / 6.0f), gk7 = thr2 * (1.0f / 7.0f), gk8 = thr2 * 0.125f, gc0 = thr2 * 1.0001e-5f;
+	// (int)(sync->toa * 512) of the eight training sequences, 4 bits each (+-1 for the reference's tables); a table set whose
+	// offsets do not fit leaves every burst to the general kernel
+	int t5pk = 0;
+	bool t5_ok = true;
+	for (int t = 0; t < 8; t++) {
+		const int v = (int)(lhdr[8 * t + 5] * 512.0f);
+		t5_ok = t5_ok && v >= -8 && v <= 7;
+		t5pk |= (v & 15) << (4 * t);
+	}
+	t5pk = uni(t5pk);
+	const unsigned long long e8_addr = reinterpret_cast<unsigned long long>(&tab->edge8[0][0][0]);
 	// ---- work distribution: groups of 16 consecutive bursts.  Static part: workgroup w owns ONE contiguous range of groups
 	// (7/8 of the batch when the cross-die pool is on, everything otherwise); the rest is drawn group by group from a
 	// device-wide counter (see burst_pull4_kernel).  Waves claim items one at a time from the workgroup's LDS counter.
@@ -238,13 +255,8 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 		// ---- is this a slot the kernel handles?
 		const unsigned max_toa = prm0 >> 16;
 		const int tsc = (prm0 >> 8) & 0xff;
-		bool leave = ((prm0 & 0xf8ffu) != (unsigned)TRXHIP_TSC) || (max_toa > NB_MAX_TOA);
-		int rc = 0;
-		float toa = 0.0f, ci = 0.0f, energy = 0.0f, rssi = 0.0f;
-		c32 amp = make_float2(0.0f, 0.0f);
+		bool leave = ((prm0 & 0xf8ffu) != (unsigned)TRXHIP_TSC) || (max_toa > NB_MAX_TOA) || !t5_ok;
 		int clip = 0;
-		int fast_nk = 1 << 30;
-		float4 fast_rows = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 		if (!leave) {
 			// maxAmplitude() > 30000 (:1711-1722, :1746)
 			clip = __ballot(amax > TRX_CLIP_THRESH) != 0ull;
@@ -271,21 +283,19 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 					     : [vd] "v"(vd_addr), [vcz] "v"(vcz_addr), [len] "s"(len), [tsc] "s"(tsc)
 					     : NB_ASM_CLOBBERS);
 				int m_bits, es_bits, bidx;
-				int kr, ka, kb;                                             // lane constants (lcn[])
+				int kr, ka, kb, kic, ktp;                                   // lane constants (lcn[])
 				asm volatile(NB_ASM_AMAX("ds_read_b32 %[kr], %[l4] offset:%c[lc]", "ds_read_b32 %[ka], %[l4] offset:%c[lc]+256",
-							 "ds_read_b32 %[kb], %[l4] offset:%c[lc]+512", "s_nop 0", "s_nop 0", "s_nop 0", "s_nop 0", "s_nop 0")
+							 "ds_read_b32 %[kb], %[l4] offset:%c[lc]+512", "ds_read_b32 %[kic], %[l4] offset:%c[lc]+768",
+							 "ds_read_b32 %[ktp], %[l4] offset:%c[lc]+1024", "s_nop 0", "s_nop 0", "s_nop 0")
 					     "s_waitcnt lgkmcnt(0)"
-					     : [m] "=s"(m_bits), [es] "=s"(es_bits), [bidx] "=s"(bidx), [kr] "=&v"(kr), [ka] "=&v"(ka), [kb] "=&v"(kb)
+					     : [m] "=s"(m_bits), [es] "=s"(es_bits), [bidx] "=s"(bidx), [kr] "=&v"(kr), [ka] "=&v"(ka), [kb] "=&v"(kb),
+					       [kic] "=&v"(kic), [ktp] "=&v"(ktp)
 					     : [nrm] "v"(v), [ep] "v"(epart), [l4] "v"(4 * lane),
 					       [lc] "n"((TRX_SINCV_LDS + 16 * WAVE + NB_COMP_ROWS * 36 + 16 + 64 + 5 * WAVE) * 4)
 					     : NB_ASM_CLOBBERS);
-				// RSSI (Transceiver.cpp:741,751)
-				energy = __int_as_float(es_bits) * 0.0125f;
-				rssi = fs_db - 3.01029996f * __log2f(energy);
 				int hit = 0;
 				int toa512 = 0;
 				if (m_bits != 0) {                                          // fastPeakDetect: a maximum above zero exists (:1120-1139)
-					const float *const hdr = lhdr + 8 * tsc;
 					// edge gate, peak-ratio gate, round A of the TOA bisection and its walk (DETA); round B, walk, peak value (DETB)
 					int st, e512;
 					float km;
@@ -301,7 +311,6 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 							     : [e] "s"(e512), [kb] "v"(kb), [czb] "s"(lds_addr(cz)), [km] "v"(km)
 							     : NB_ASM_CLOBBERS);
 					}
-					c32 xcorr = make_float2(__int_as_float(xr_bits), __int_as_float(xi_bits));
 					if (st == 3) {
 						// an uncertified early / late decision on the path: the search again in the reference's operand order
 						if (lane == 0)
@@ -309,40 +318,55 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 						PeakConst pkc;
 						pkc.flA = pkcl[0 * WAVE + lane]; pkc.loA = pkcl[1 * WAVE + lane]; pkc.hiA = pkcl[2 * WAVE + lane];
 						pkc.offB = pkcl[3 * WAVE + lane]; pkc.ratio_off = pkcl[4 * WAVE + lane];
+						c32 xcorr;
 						peak_detect_spec(cz, bidx, sincv, pkc, lane, &toa512, &xcorr, wa4);
 						toa512 = uni(toa512);
-						xcorr.x = unif(xcorr.x);
-						xcorr.y = unif(xcorr.y);
+						xr_bits = uni(__float_as_int(xcorr.x));
+						xi_bits = uni(__float_as_int(xcorr.y));
 						st = 1;
 					}
 					if (st == 2)
 						leave = true;                                          // the gate is too close to call for the estimate
 					if (st == 1) {
+						// computeCI, amp, toa, the result record, 1 / amp; then demodGmskBurst of the usual geometry (TAIL)
 						hit = 1;
-						// TOA in 1/512 symbol -> the demodulator's shift and delay filter; fetch of the low-edge tap rows
-						const int nk = -(toa512 - (int)(hdr[5] * 512.0f) - 10 * 512);
-						if ((unsigned)(-(nk >> 7)) <= 36u) {
-							fast_nk = nk;
-							const int fr = nk & 127;
-							const int fidx = (fr >= 2) ? (fr >> 1) : TRX_DELAY_FILTS;
-							fast_rows = reinterpret_cast<const float4 *>(&tab->edge8[fidx][0][0])[lane];   // (lanes >= 48: the next row's, unused)
+						int ok;
+						float d0, d1, d2;
+						const int t5 = (t5pk << (28 - 4 * tsc)) >> 28;
+						const uint32_t flags = (uint32_t)tsc | ((uint32_t)clip << 8) | (37u << 24);
+						asm volatile(NB_ASM_TAIL
+							     : [ok] "=&s"(ok), [rec] "=&v"(recw), [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2)
+							     : [toa] "s"(toa512), [xr] "s"(xr_bits), [xi] "s"(xi_bits), [t5] "s"(t5), [hdrb] "s"(lds_addr(lhdr) + 32u * (unsigned)tsc),
+							       [e8lo] "s"((unsigned)e8_addr), [e8hi] "s"((unsigned)(e8_addr >> 32)), [es] "s"(es_bits), [fsdb] "s"(fs_db),
+							       [flags] "s"(flags), [modd] "s"(0xaaaaaaaaaaaaaaaaull), [m23] "s"(0xccccccccccccccccull), [l16] "v"(16 * lane),
+							       [vd] "v"(vd_addr), [pb] "s"(lds_addr(P)), [cb] "s"(lds_addr(comp) + 4u * (K4_U0 + TRX_FUSED_SH)), [db] "s"(lds_addr(D)),
+							       [kic] "v"(kic), [ktp] "v"(ktp)
+							     : NB_ASM_CLOBBERS);
+						if (!ok) {
+							leave = true;                                      // TOA outside the straight-line geometry
+						} else {
+							o.x = __builtin_amdgcn_fmed3f(fmaf(0.5f, d0, 0.5f), 0.0f, 1.0f);     // vectorSlicer: 0.5 * (x + 1), clamped (:546-556)
+							o.y = __builtin_amdgcn_fmed3f(fmaf(0.5f, d1, 0.5f), 0.0f, 1.0f);
+							o.z = __builtin_amdgcn_fmed3f(fmaf(0.5f, d2, 0.5f), 0.0f, 1.0f);
 						}
-						// ---- computeCI (:1608-1639): S = mean sample power over the sequence at the rounded TOA (tree sum), C from the peak
-						const int rt = (toa512 >= 0) ? ((toa512 + 256) >> 9) : -((-toa512 + 256) >> 9);
-						const float pw = norm2(D[rt + (lane < 16 ? lane : 0)]);
-						float S = lane_val(row_sum(pw), 0);
-						S *= 0.0625f;
-						const float C = norm2(xcorr) * hdr[7];
-						ci = 3.0103f * __log2f(C * __builtin_amdgcn_rcpf(S - C));
-						const c32 a = cmul(xcorr, make_float2(hdr[2], hdr[3]));  // xcorr / sync->gain  (:1701)
-						amp = make_float2(unif(a.x), unif(a.y));
-						toa = unif((float)toa512 * (1.0f / 512.0f) - hdr[5]);      // :1704
 					}
 				}
-				rc = hit ? TRXHIP_TSC : (clip ? -TRXHIP_SIGERR_CLIP : 0);                 // :1764, :1953-1954
-				toa -= 10.0f;                                                              // :1768
-				if (hit && fast_nk == (1 << 30))
-					leave = true;                                                          // TOA outside the straight-line geometry
+				if (!hit && !leave) {
+					// nothing found: rc (:1764), energy and RSSI (Transceiver.cpp:741,751), zero soft bits
+					const float energy = __int_as_float(es_bits) * 0.0125f;
+					const float rssi = fs_db - 3.01029996f * __log2f(energy);
+					const uint32_t flags = ((uint32_t)clip << 8) | (1u << 16);
+					int word = clip ? -TRXHIP_SIGERR_CLIP : 0;
+					word = put_lane<1>(word, 0.0f);
+					word = put_lane<2>(word, 0.0f);
+					word = put_lane<3>(word, 0.0f);
+					word = put_lane<4>(word, 0.0f);
+					word = put_lane<5>(word, energy);
+					word = put_lane<6>(word, rssi);
+					word = write_lane<7>(word, (int)flags);
+					recw = word;
+					o = (v3f){ 0.0f, 0.0f, 0.0f };
+				}
 			}
 		}
 		if (leave) {
@@ -352,69 +376,8 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 			}
 			continue;
 		}
-
-		// ---- result record (wave-uniform fields dropped into lanes 0..7 of one register)
-		{
-			const bool det = rc > 0;
-			const uint32_t flags = (uint32_t)(det ? tsc : 0) | ((uint32_t)clip << 8) | ((uint32_t)(det ? 0 : 1) << 16) | ((uint32_t)(det ? 37 : 0) << 24);
-			int word = rc;
-			word = put_lane<1>(word, det ? toa : 0.0f);
-			word = write_lane<2>(word, __float_as_int(det ? amp.x : 0.0f));
-			word = write_lane<3>(word, __float_as_int(det ? amp.y : 0.0f));
-			word = put_lane<4>(word, det ? ci : 0.0f);
-			word = put_lane<5>(word, energy);
-			word = put_lane<6>(word, rssi);
-			word = write_lane<7>(word, (int)flags);
-			recw = word;
-			pend_b = b;
-			pend_any = true;
-		}
-		o = (v3f){ 0.0f, 0.0f, 0.0f };
-		if (rc > 0) {
-			// ---- demodGmskBurst (:2055-2072), fused: delay o decimate as one filter at the symbol instants, usual geometry
-			const int nk = fast_nk;
-			const int w = nk >> 7;                                      // integer shift, -36 .. 0
-			const int fr = nk & 127;
-			const int fidx = (fr >= 2) ? (fr >> 1) : TRX_DELAY_FILTS;   // delay filter row (64 = none)
-			const float ian = __builtin_amdgcn_rcpf(norm2(amp));
-			const float sx = amp.x * ian, sy = -amp.y * ian;            // 1 / amp (Complex.h:75,144-150), 1-ulp reciprocal
-			// park the low-edge rows: lane l < 48 holds floats 4l .. 4l+3 of the burst's 8 x 24 block
-			float *const stage = reinterpret_cast<float *>(D);
-			*reinterpret_cast<float4 *>(stage + 4 * lane) = fast_rows;
-			wave_sync();
-			// lanes 0..47: outputs 4 + 3l .. 6 + 3l with the burst's composite row; lanes 52..55: output e = (-lane) & 3, main
-			// part of its truncated row; lanes 56..59: the same outputs' taps u < 8 (window 8 samples = 2 outputs earlier)
-			const int e = (-lane) & 3;
-			const bool sp = (lane >= 52) && (lane < 60);
-			const float *const tp = sp ? stage + (e + (lane >= 56 ? 4 : 0)) * K4_NTP : comp + fidx * 36 + (K4_U0 + TRX_FUSED_SH);
-			int ic = (lane < 48) ? 4 + 3 * lane : 148;
-			if (sp) ic = (lane < 56) ? e : e - 2;
-			const int c = -24 - w + K4_U0;                              // tap u = K4_U0 of output i reads sample 4i + c
-			const PhBase pb = ph_bases(P, c & 3, ic + (c >> 2));
-			v2f acc[3] = { { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f } };
-			fir24x3(pb, reinterpret_cast<const float4 *>(tp), acc);
-			// rotation (-j)^i, scale 1 / amp and vectorSlicer in registers.  Symbol i wants real((-j)^i s z): with VP = the
-			// lane's entry of [sx, sy, -sx, -sy] (by lane & 3) it is z.x * VP[k] + z.y * VP[k - 1], k = i & 3 = (j - lane) & 3:
-			// a quad permutation of VP, which the DPP operand of v_mul / v_fmac applies for free
-			float vp = (lane & 1) ? sy : sx;
-			vp = (lane & 2) ? -vp : vp;
-			float d0, d1, d2;
-			float a0x = acc[0].x, a0y = acc[0].y;
-			asm volatile("s_nop 1\n\t"
-				     "v_add_f32_dpp %3, %3, %3 row_shl:4 row_mask:0x8 bank_mask:0xf\n\t"      // low-edge outputs (lanes 52..55 += 56..59; row 3 only)
-				     "v_add_f32_dpp %4, %4, %4 row_shl:4 row_mask:0x8 bank_mask:0xf\n\t"
-				     "v_mul_f32_dpp %1, %9, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-				     "v_mul_f32_dpp %2, %9, %7 quad_perm:[2,1,0,3] row_mask:0xf bank_mask:0xf\n\t"
-				     "v_mul_f32_dpp %0, %9, %3 quad_perm:[0,3,2,1] row_mask:0xf bank_mask:0xf\n\t"
-				     "v_fmac_f32_dpp %1, %9, %6 quad_perm:[0,3,2,1] row_mask:0xf bank_mask:0xf\n\t"
-				     "v_fmac_f32_dpp %2, %9, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-				     "v_fmac_f32_dpp %0, %9, %4 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n\t"
-				     : "=&v"(d0), "=&v"(d1), "=&v"(d2), "+v"(a0x), "+v"(a0y)
-				     : "v"(acc[1].x), "v"(acc[1].y), "v"(acc[2].x), "v"(acc[2].y), "v"(vp));
-			o.x = __builtin_amdgcn_fmed3f(fmaf(0.5f, d0, 0.5f), 0.0f, 1.0f);     // vectorSlicer: 0.5 * (x + 1), clamped (:546-556)
-			o.y = __builtin_amdgcn_fmed3f(fmaf(0.5f, d1, 0.5f), 0.0f, 1.0f);
-			o.z = __builtin_amdgcn_fmed3f(fmaf(0.5f, d2, 0.5f), 0.0f, 1.0f);
-		}
+		pend_b = b;
+		pend_any = true;
 	}
 	// ---- the last burst's output
 	if (pend_any) {

@@ -11,7 +11,7 @@ blocks below are therefore whole phases of a burst, and this script CHECKS what 
     VGPR -> v_readlane 1; VALU-written SGPR -> v_readlane lane select 4, -> VMEM address 5; x3 / x4 store data 2;
   * every register loaded from LDS is covered by an s_waitcnt lgkmcnt(n) before its first use (LDS returns in order).
 Registers: operands the compiler allocates are %[name]; the blocks' temporaries are the fixed VGPRs v64..v127 and SGPRs
-s88..s99, declared as clobbers of every statement (NB_ASM_CLOBBERS)."""
+s80..s99, declared as clobbers of every statement (NB_ASM_CLOBBERS)."""
 import os
 import re
 import sys
@@ -642,6 +642,186 @@ def block_detb():
     b(".Lnb_db_end:")
     return b
 
+# ------------------------------------------------------------------------------------------------------------------
+# block TAIL: what detectBurst() does behind peakDetect (:1695-1708) for a found burst, the demodulator's set-up and the
+# burst's result record.
+#   * TOA in 1/512 symbol -> shift and delay-filter row of the straight-line demodulator; fetch of the burst's low-edge
+#     tap rows (trx_tables.edge8: 768 bytes, 16 per lane) from L2, as early as possible
+#   * computeCI (:1608-1639): S = mean power of the 16 samples at the rounded TOA (tree sum), C = |peak|^2 / ci_den
+#   * amp = peak / gain (:1701), toa = position - sync->toa - head (:1704, :1768)
+#   * 1 / amp -> the per-lane multiplier VP of the output stage (block DEMOD); RSSI (Transceiver.cpp:741,751)
+#   * the result record: field k in lane k of one register (rc, toa, amp.re, amp.im, ci, energy, rssi, flags)
+#   in : SGPR toa (position * 512), xr / xi (peak value), t5 ((int)(sync->toa * 512)), hdrb (LDS byte address of the
+#        sequence header), e8lo / e8hi (address of tab->edge8), es (energy sum), fsdb (20 log10 full_scale), flags;
+#        VGPR l16 (16 * lane), vd (LDS byte address of D[lane]); SGPR pairs modd = 0xaaaa.., m23 = 0xcccc..
+#   out: SGPR ok (0: TOA outside the straight-line geometry), nk; VGPR rows (4 registers), vp, rec
+# ------------------------------------------------------------------------------------------------------------------
+def block_tail():
+    b = Block("TAIL", ("toa", "xr", "xi", "t5", "hdrb", "e8lo", "e8hi", "es", "fsdb", "flags", "modd", "m23", "ok", "nk", "pb", "cb", "db"))
+    b("s_sub_u32 s88, %[t5], %[toa]")
+    b("s_add_u32 s87, s88, 5120")                                # nk = -(toa512 - t5 - 10 * 512)
+    b("s_ashr_i32 s89, s87, 7")                                  # w = nk >> 7, must be -36 .. 0
+    b("s_sub_u32 s90, 0, s89")
+    b("s_mov_b32 %[ok], 0")
+    b("s_cmp_gt_u32 s90, 36")
+    b("s_cbranch_scc1 .Lnb_tl_end")
+    b("s_and_b32 s91, s87, 127")
+    b("s_lshr_b32 s92, s91, 1")
+    b("s_cmp_ge_u32 s91, 2")
+    b("s_cselect_b32 s92, s92, 64")                                # delay filter row (64 = none)
+    b("s_mul_i32 s93, s92, 768")
+    b("s_add_u32 s94, %[e8lo], s93")
+    b("s_addc_u32 s95, %[e8hi], 0")
+    b("s_abs_i32 s96, %[toa]")                                     # roundf(toa): half away from zero on k / 512
+    b("s_add_u32 s96, s96, 256")
+    b("global_load_dwordx4 v[120:123], %[l16], s[94:95]")
+    b("s_lshr_b32 s96, s96, 9")
+    b("s_sub_u32 s97, 0, s96")
+    b("s_cmp_lt_i32 %[toa], 0")
+    b("s_cselect_b32 s96, s97, s96")
+    b("s_lshl_b32 s96, s96, 3")
+    b("v_add_u32_e32 v64, s96, %[vd]")                             # &D[rt + lane]: sample ps + lane, ps = start + 1 - N + rt
+    b("v_mov_b32_e32 v65, %[hdrb]")
+    b("ds_read_b64 v[66:67], v64")
+    b("ds_read_b128 v[68:71], v65")                                # gain, 1 / gain
+    b("ds_read_b128 v[72:75], v65 offset:16")                      # ci_den, toa, n, 1 / ci_den
+    b("v_mul_f32_e64 v76, %[xi], %[xi]")
+    b("v_mul_f32_e64 v77, %[xr], %[xr]")
+    b("v_mov_b32_e32 v79, %[es]")
+    b("v_cvt_f32_i32_e32 v78, %[toa]")
+    b("v_add_f32_e32 v76, v76, v77")                               # |peak|^2
+    b(f"v_mul_f32_e32 v79, {fhex(0.0125)}, v79")                   # energyDetect(burst, 20 * sps): / 80
+    b("v_log_f32_e32 v80, v79")
+    b("v_mul_f32_e32 v78, 0x3b000000, v78")                        # position (exact)
+    b("s_mov_b32 %[ok], 1")
+    b(f"v_mul_f32_e32 v80, {fhex(3.01029996)}, v80")
+    b("s_waitcnt lgkmcnt(2)")
+    b("v_pk_mul_f32 v[66:67], v[66:67], v[66:67]")
+    b("v_sub_f32_e32 v80, %[fsdb], v80")                           # rssi
+    b("v_add_f32_e32 v81, v67, v66")                               # |sample|^2
+    b("s_waitcnt lgkmcnt(0)")
+    b("v_mul_f32_e32 v82, %[xr], v70")                             # peak * (1 / gain): Complex.h:74
+    b("v_mul_f32_e32 v83, %[xr], v71")
+    b(f"v_add_f32_dpp v81, v81, v81 quad_perm:[1,0,3,2] {D_ALL}")
+    b("v_mul_f32_e32 v84, %[xi], v71")
+    b("v_mul_f32_e32 v85, %[xi], v70")
+    b(f"v_add_f32_dpp v81, v81, v81 quad_perm:[2,3,0,1] {D_ALL}")
+    b("v_sub_f32_e32 v86, v82, v84")                               # amp.re
+    b("v_add_f32_e32 v87, v83, v85")                               # amp.im
+    b(f"v_add_f32_dpp v81, v81, v81 row_half_mirror {D_ALL}")
+    b("v_mul_f32_e32 v88, v76, v75")                               # C
+    b("v_mul_f32_e32 v89, v87, v87")
+    b(f"v_add_f32_dpp v81, v81, v81 row_mirror {D_ALL}")
+    b("v_mul_f32_e32 v90, v86, v86")
+    b("v_sub_f32_e32 v78, v78, v73")                               # - sync->toa (:1704)
+    b("v_add_f32_e32 v89, v89, v90")                               # |amp|^2
+    b("v_mul_f32_e32 v81, 0x3d800000, v81")                        # S = sum / 16 (row 0)
+    b("v_add_f32_e32 v78, 0xc1200000, v78")                        # - head (:1768)
+    b("v_readlane_b32 s98, v81, 0")
+    b("v_rcp_f32_e32 v89, v89")
+    b("s_nop 0")
+    b("v_sub_f32_e32 v94, s98, v88")                               # S - C
+    b("v_mul_f32_e32 v91, v86, v89")                               # 1 / amp = conj(amp) / |amp|^2 (Complex.h:75,144-150)
+    b("v_rcp_f32_e32 v94, v94")
+    b("v_mul_f32_e64 v92, -v87, v89")
+    b("v_mul_f32_e32 v94, v88, v94")
+    b("v_cndmask_b32_e64 v119, v91, v92, %[modd]")                # VP[lane & 3] = sx, sy, -sx, -sy
+    b("v_log_f32_e32 v94, v94")
+    b("v_cndmask_b32_e64 v119, v119, -v119, %[m23]")
+    b(f"v_mul_f32_e32 v94, {fhex(3.0103)}, v94")                   # C/I, dB (:1637)
+    # record: rc = TSC in lane 0, then one v_cndmask per field under a one-lane mask
+    b("v_mov_b32_e32 %[rec], 1")
+    for k, r in ((1, "v78"), (2, "v86"), (3, "v87"), (4, "v94"), (5, "v79"), (6, "v80")):
+        b(f"s_mov_b64 s[98:99], {1 << k}")
+        b(f"v_cndmask_b32_e64 %[rec], %[rec], {r}, s[98:99]")
+    b("v_writelane_b32 %[rec], %[flags], 7")
+    block_demod(b)
+    b(".Lnb_tl_end:")
+    return b
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# block DEMOD: demodGmskBurst (:2055-2072) of the usual geometry, fused: delay o decimate as one 24-tap filter at the
+# symbol instants (fir24x3, trx_k4_common.h -- the same sums in the same order), rotation / 1/amp / slicer input in
+# registers.
+#   lanes 0..47: symbols 4 + 3 lane + j with the burst's composite row; lanes 52..55: symbol e = (-lane) & 3, main part of
+#   its truncated row (parked in D); lanes 56..59: the same symbols' taps u < 8 (window two symbols earlier)
+#   in : SGPR nk, pb (LDS byte address of P[0] of this wave), cb (LDS byte address of comp + 32: tap U0 of row 0), db (LDS
+#        byte address of D); VGPR rows (4), vp, l16, kic (lane constant: 8 * first symbol), ktp (lane constant: byte offset
+#        of the lane's tap row inside D, -1 for the lanes on the composite row)
+#   out: VGPR d0 d1 d2: real((-j)^i z / amp) of the lane's three symbols (the slicer's input)
+# ------------------------------------------------------------------------------------------------------------------
+def block_demod(b):
+    ACC = [vreg(64 + 2 * j, 2) for j in range(3)]
+    RING = lambda v: vreg(72 + 2 * (v & 15), 2)
+    CQ = [104, 108]
+    P = [112, 113, 114, 115]
+    b("s_ashr_i32 s88, s87, 7")                                  # w
+    b("s_and_b32 s89, s87, 127")
+    b("s_lshr_b32 s90, s89, 1")
+    b("s_cmp_ge_u32 s89, 2")
+    b("s_cselect_b32 s90, s90, 64")                                # fidx
+    b("s_sub_u32 s91, -18, s88")                                   # c = -24 - w + U0: tap U0 of symbol i reads sample 4 i + c
+    b("s_and_b32 s92, s91, 3")                                     # ph0
+    b("s_ashr_i32 s93, s91, 2")
+    b("s_mul_i32 s94, s92, 180")
+    b("s_add_u32 s94, s94, s93")
+    b("s_lshl3_add_u32 s94, s94, %[pb]")                           # &P[ph0][m = c >> 2] - 12 entries
+    b("s_mul_i32 s95, s90, 144")
+    b("s_add_u32 s95, s95, %[cb]")                                 # composite row of the burst's delay filter, from tap U0
+    b("v_add_u32_e32 v116, %[l16], %[db]")
+    b("s_waitcnt vmcnt(0)")
+    b("ds_write_b128 v116, v[120:123]")                               # park the low-edge rows: lane l holds floats 4l .. 4l+3 of the 8 x 24 block
+    b(f"v_add_u32_e32 {vreg(P[0])}, s94, %[kic]")
+    b("v_cmp_lt_i32_e32 vcc, -1, %[ktp]")
+    b("v_add_u32_e32 v117, %[db], %[ktp]")
+    for k in range(1, 4):
+        # p[k] = p[0] + (k * PH_A + ((ph0 + k) >> 2) * (1 - 4 * PH_A)) entries
+        b(f"s_add_u32 s96, s92, {k}")
+        b("s_lshr_b32 s96, s96, 2")
+        b(f"s_mul_i32 s96, s96, {(1 - 4 * PH_A) * 8}")
+        b(f"s_add_u32 s96, s96, {k * PH_A * 8}")
+        b(f"v_add_u32_e32 {vreg(P[k])}, s96, {vreg(P[0])}")
+    b("v_mov_b32_e32 v118, s95")
+    b("v_cndmask_b32_e32 v117, v118, v117, vcc")                   # this lane's tap row
+    for j in range(3):
+        b(f"v_mov_b64_e32 {ACC[j]}, 0")
+    D, NT, NV = 4, 24, 32
+    PH0 = 96                                                       # byte offset of PH_M0 entries
+    b(f"ds_read_b128 {vreg(CQ[0], 4)}, v117")
+    for v in range(8 + D):
+        b(f"ds_read_b64 {RING(v)}, {vreg(P[v & 3])} offset:{PH0 + 8 * (v >> 2)}")
+    outstanding = 0
+    for u in range(NT):
+        if (u & 3) == 0 and u + 4 < NT:
+            b(f"ds_read_b128 {vreg(CQ[((u >> 2) + 1) & 1], 4)}, v117 offset:{16 * ((u >> 2) + 1)}")
+        if (u & 3) == 0:
+            n_new = 0
+            for k in range(4):
+                v = u + 8 + D + k
+                if v < NV:
+                    b(f"ds_read_b64 {RING(v)}, {vreg(P[v & 3])} offset:{PH0 + 8 * (v >> 2)}")
+                    n_new += 1
+            # everything older than this group's own loads (taps of the next group + four samples) must have arrived
+            b(f"s_waitcnt lgkmcnt({n_new + (1 if u + 4 < NT else 0)})")
+        ca = CQ[(u >> 2) & 1]
+        hp = vreg(ca + (2 if (u & 2) else 0), 2)
+        sel = "op_sel:[0,1,0] op_sel_hi:[1,1,1]" if (u & 1) else "op_sel:[0,0,0] op_sel_hi:[1,0,1]"
+        for j in range(3):
+            b(f"v_pk_fma_f32 {ACC[j]}, {RING(u + 4 * j)}, {hp}, {ACC[j]} {sel}")
+    # output stage: low-edge symbols = main part (lane 52 + c) + taps u < 8 (lane 56 + c); symbol i wants real((-j)^i z / amp) =
+    # z.x * VP[k] + z.y * VP[k - 1], k = i & 3 = (j - lane) & 3: a quad permutation of VP, applied by the DPP operand
+    b("s_nop 0")
+    b("v_add_f32_dpp v64, v64, v64 row_shl:4 row_mask:0x8 bank_mask:0xf")
+    b("v_add_f32_dpp v65, v65, v65 row_shl:4 row_mask:0x8 bank_mask:0xf")
+    b(f"v_mul_f32_dpp %[d1], v119, v66 quad_perm:[1,0,3,2] {D_ALL}")
+    b(f"v_mul_f32_dpp %[d2], v119, v68 quad_perm:[2,1,0,3] {D_ALL}")
+    b(f"v_mul_f32_dpp %[d0], v119, v64 quad_perm:[0,3,2,1] {D_ALL}")
+    b(f"v_fmac_f32_dpp %[d1], v119, v67 quad_perm:[0,3,2,1] {D_ALL}")
+    b(f"v_fmac_f32_dpp %[d2], v119, v69 quad_perm:[1,0,3,2] {D_ALL}")
+    b(f"v_fmac_f32_dpp %[d0], v119, v65 quad_perm:[3,2,1,0] {D_ALL}")
+
+
 def c_string(lines):
     out = []
     for t in lines:
@@ -660,11 +840,13 @@ def main():
     wa4_off = SINCV_LDS * 4
     blocks["DETA"] = block_deta(wa4_off)
     blocks["DETB"] = block_detb()
-    errs = blocks["DEC"].check() + check_variants(blocks["CORR"]) + check_paths(blocks["DETA"]) + check_paths(blocks["DETB"])
+    blocks["TAIL"] = block_tail()
+    errs = blocks["DEC"].check() + check_variants(blocks["CORR"]) + check_paths(blocks["DETA"]) + check_paths(blocks["DETB"]) + \
+        check_paths(blocks["TAIL"])
     hdr = ["// trx_nb_asm.inc -- GENERATED by tools/gen_nb_asm.py (hazards and LDS waits checked there); do not edit.",
            f"#define NB_ASM_GDEC_OFF {gdec_off}",
            "#define NB_ASM_CLOBBERS " + ", ".join(f'"v{i}"' for i in range(64, 128)) + ", " +
-           ", ".join(f'"s{i}"' for i in range(88, 100)) + ', "vcc", "scc", "memory"']
+           ", ".join(f'"s{i}"' for i in range(80, 100)) + ', "vcc", "scc", "memory"']
     for name, b in blocks.items():
         hdr.append(f"#define NB_ASM_{name} \\")
         lines = b.text()
