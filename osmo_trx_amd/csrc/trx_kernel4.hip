@@ -1177,7 +1177,8 @@ extern "C" int trx_launch_pull4_nb(unsigned *d_pool_ctr, const void *d_iq, const
 		auto k = nb_pull4_kernel;
 		TRX_ARM_DYNAMIC_LDS(k);
 		hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NB_WPB * WAVE), NB_LDS_BYTES, stream, reinterpret_cast<const uint32_t *>(d_iq),
-				   d_params, d_results, d_soft, d_tab, (unsigned)n_bursts, thresh, full_scale, pool, d_redo);
+				   d_params, d_results, d_soft, d_tab, (unsigned)n_bursts, thresh, full_scale, pool, d_redo,
+				   thresh * thresh * 0.2f, thresh * thresh * (1.0f / 6.0f), thresh * thresh * (1.0f / 7.0f), thresh * thresh * 0.125f);
 	}
 	{
 		auto k = burst_pull4_kernel<false, false, true, true>;

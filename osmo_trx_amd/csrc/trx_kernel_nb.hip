@@ -50,7 +50,8 @@ __device__ __forceinline__ unsigned lds_addr(const T *p)
 __global__ void __launch_bounds__(NB_WPB * WAVE)
 nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__restrict__ params,
 		trxhip_burst_result *__restrict__ results, float *__restrict__ soft, const trx_tables *__restrict__ tab,
-		unsigned n_bursts, float thresh, float full_scale, unsigned *__restrict__ pool_ctr, unsigned *__restrict__ redo)
+		unsigned n_bursts, float thresh, float full_scale, unsigned *__restrict__ pool_ctr, unsigned *__restrict__ redo,
+		float gk5, float gk6, float gk7, float gk8)
 {
 	static_assert(NB_TABLES_BYTES % 16 == 0 && (NB_SLICE * 8) % 16 == 0 && (K4_XS * 8) % 16 == 0 && (NB_D_LEN * 8) % 16 == 0, "16-byte LDS accesses");
 	static_assert(NB_LDS_BYTES <= 160 * 1024, "LDS");
@@ -123,7 +124,8 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 	// the peak-ratio gate's estimate (tools/gen_nb_asm.py, DETA): thresh^2 / num for the four possible term counts, and the
 	// constant term of its certain-pass bound
 	const float thr2 = thresh * thresh;
-	const float gk5 = thr2 * 0.2f, gk6 = thr2 * (1.0f / 6.0f), gk7 = thr2 * (1.0f / 7.0f), gk8 = thr2 * 0.125f, gc0 = thr2 * 1.0001e-5f;
+	// (gk5 .. gk8 = thresh^2 / 5 .. thresh^2 / 8 come as kernel arguments: scalar registers)
+	const float gc0 = thr2 * 1.0001e-5f;
 	// (int)(sync->toa * 512) of the eight training sequences, 4 bits each (+-1 for the reference's tables); a table set whose
 	// offsets do not fit leaves every burst to the general kernel
 	int t5pk = 0;
@@ -337,7 +339,7 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 						asm volatile(NB_ASM_TAIL
 							     : [ok] "=&s"(ok), [rec] "=&v"(recw), [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2)
 							     : [toa] "s"(toa512), [xr] "s"(xr_bits), [xi] "s"(xi_bits), [t5] "s"(t5), [hdrb] "s"(lds_addr(lhdr) + 32u * (unsigned)tsc),
-							       [e8lo] "s"((unsigned)e8_addr), [e8hi] "s"((unsigned)(e8_addr >> 32)), [es] "s"(es_bits), [fsdb] "s"(fs_db),
+							       [e8lo] "s"((unsigned)e8_addr), [e8hi] "s"((unsigned)(e8_addr >> 32)), [es] "s"(es_bits), [fsdb] "s"(unif(fs_db)),
 							       [flags] "s"(flags), [modd] "s"(0xaaaaaaaaaaaaaaaaull), [m23] "s"(0xccccccccccccccccull), [l16] "v"(16 * lane),
 							       [vd] "v"(vd_addr), [pb] "s"(lds_addr(P)), [cb] "s"(lds_addr(comp) + 4u * (K4_U0 + TRX_FUSED_SH)), [db] "s"(lds_addr(D)),
 							       [kic] "v"(kic), [ktp] "v"(ktp)

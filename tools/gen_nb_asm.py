@@ -769,7 +769,7 @@ def block_demod(b):
     b("s_lshl3_add_u32 s94, s94, %[pb]")                           # &P[ph0][m = c >> 2] - 12 entries
     b("s_mul_i32 s95, s90, 144")
     b("s_add_u32 s95, s95, %[cb]")                                 # composite row of the burst's delay filter, from tap U0
-    b("v_add_u32_e32 v116, %[l16], %[db]")
+    b("v_add_u32_e32 v116, %[db], %[l16]")
     b("s_waitcnt vmcnt(0)")
     b("ds_write_b128 v116, v[120:123]")                               # park the low-edge rows: lane l holds floats 4l .. 4l+3 of the 8 x 24 block
     b(f"v_add_u32_e32 {vreg(P[0])}, s94, %[kic]")
