@@ -276,6 +276,7 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 				     : NB_ASM_CLOBBERS);
 			if (bad != 0ull) {
 				leave = true;
+				if (lane == 0) atomicAdd(&g_trx_fast_stats[1], 1ull);          // (cold) left to the general kernel: correlation guard
 			} else {
 				// ---- correlation (lane = lag; the twelve lanes behind the window store the right zero pad), arg-max and the
 				// energyDetect sum (:1573-1585); the lane constants of the TOA search are fetched in the reductions' wait states
@@ -327,8 +328,10 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 						xi_bits = uni(__float_as_int(xcorr.y));
 						st = 1;
 					}
-					if (st == 2)
+					if (st == 2) {
 						leave = true;                                          // the gate is too close to call for the estimate
+						if (lane == 0) atomicAdd(&g_trx_fast_stats[2], 1ull);
+					}
 					if (st == 1) {
 						// computeCI, amp, toa, the result record, 1 / amp; then demodGmskBurst of the usual geometry (TAIL)
 						hit = 1;
@@ -346,6 +349,7 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 							     : NB_ASM_CLOBBERS);
 						if (!ok) {
 							leave = true;                                      // TOA outside the straight-line geometry
+							if (lane == 0) atomicAdd(&g_trx_fast_stats[3], 1ull);
 						} else {
 							o.x = __builtin_amdgcn_fmed3f(fmaf(0.5f, d0, 0.5f), 0.0f, 1.0f);     // vectorSlicer: 0.5 * (x + 1), clamped (:546-556)
 							o.y = __builtin_amdgcn_fmed3f(fmaf(0.5f, d1, 0.5f), 0.0f, 1.0f);

@@ -198,10 +198,11 @@ class TrxHip:
 
     def fast_stats(self, reset=False):
         """Counters of the fused kernels' FAST detector since the last reset: {"reruns": bursts whose TOA search was re-run in
-        the reference's operand order}.  Synchronises the device."""
+        the reference's operand order; left_*: bursts the normal-burst kernel left to the general one (correlation guard, peak-ratio gate
+        too close to call, TOA outside the straight-line demodulator's geometry)}.  Synchronises the device."""
         out = (C.c_uint64 * 4)()
         _check(self.L.trxhip_fast_stats(self.h, out, 1 if reset else 0), "trxhip_fast_stats")
-        return {"reruns": int(out[0])}
+        return {"reruns": int(out[0]), "left_guard": int(out[1]), "left_gate": int(out[2]), "left_geometry": int(out[3])}
 
     def params_tensor(self, params_np):
         """PARAMS_DTYPE[n] numpy -> uint8[n, 8] device tensor."""
