@@ -119,6 +119,49 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 	const int wave = uni((int)(threadIdx.x >> 6));                  // wave-uniform: burst index and its addresses live in SGPRs
 	const int waves_per_block = blockDim.x >> 6;
 
+	// Software prefetch of the next burst (see burst_pull_kernel)
+	uint32_t pre_i[NLD];
+	c32 pre_c[CF32 ? NLD : 1];
+	uint32_t pre_prm = 0u;
+	auto prefetch = [&](unsigned bb) {
+#ifdef TRX_WHATIF_L2INPUT   /* timing only (tools/): every burst reads one of the first 4096 (cache-resident input): what HBM latency costs */
+		bb &= 4095u;
+#endif
+		pre_prm = reinterpret_cast<const uint32_t *>(params)[2 * (size_t)bb];
+		if (CF32) {
+			const c32 *src = reinterpret_cast<const c32 *>(iq_) + (size_t)bb * L;
+#pragma unroll
+			for (int r = 0; r < NLD; r++) {
+				const int i = r * WAVE + lane;
+				pre_c[r] = (r < NLD - 1 || i < L) ? src[i] : make_float2(0.0f, 0.0f);
+			}
+		} else {
+			const uint32_t *src = reinterpret_cast<const uint32_t *>(iq_) + (size_t)bb * L;
+#pragma unroll
+			for (int r = 0; r < NLD; r++) {
+				const int i = r * WAVE + lane;
+				pre_i[r] = (r < NLD - 1 || i < L) ? src[i] : 0u;
+			}
+		}
+	};
+	// LIST: position in the list of the wave's current burst, and the index of the burst after next (fetched a burst ahead).  The
+	// first burst's index and samples are requested BEFORE the tables are staged (the staging then covers their latency: a launch
+	// over a short list is all latency), and a workgroup without a list position leaves before it stages anything.
+	unsigned lpos = blockIdx.x * 16u + (unsigned)wave;
+	const unsigned lstride = gridDim.x * 16u;
+	uint32_t pre_id = K4_NO_BURST;
+	unsigned b_first = K4_NO_BURST;
+	if (LIST) {
+		if (blockIdx.x * 16u >= n_bursts)
+			return;
+		if (lpos < n_bursts)
+			b_first = (unsigned)uni((int)rlist[lpos]);
+		if (lpos + lstride < n_bursts)
+			pre_id = rlist[lpos + lstride];
+		if (b_first != K4_NO_BURST)
+			prefetch(b_first);
+	}
+
 	// ---- LDS carve: [tables][per-wave slices]
 	float *sincv = reinterpret_cast<float *>(smem);                 // [4128] swizzled sinc LUT
 	float *dfilt = sincv + TRX_SINCV_LDS;                          // EXACT: [65][20] fractional-delay filters + identity;
@@ -252,47 +295,11 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 		}
 	};
 
-	// Software prefetch of the next burst (see burst_pull_kernel)
-	uint32_t pre_i[NLD];
-	c32 pre_c[CF32 ? NLD : 1];
-	uint32_t pre_prm = 0u;
-	auto prefetch = [&](unsigned bb) {
-#ifdef TRX_WHATIF_L2INPUT   /* timing only (tools/): every burst reads one of the first 4096 (cache-resident input): what HBM latency costs */
-		bb &= 4095u;
-#endif
-		pre_prm = reinterpret_cast<const uint32_t *>(params)[2 * (size_t)bb];
-		if (CF32) {
-			const c32 *src = reinterpret_cast<const c32 *>(iq_) + (size_t)bb * L;
-#pragma unroll
-			for (int r = 0; r < NLD; r++) {
-				const int i = r * WAVE + lane;
-				pre_c[r] = (r < NLD - 1 || i < L) ? src[i] : make_float2(0.0f, 0.0f);
-			}
-		} else {
-			const uint32_t *src = reinterpret_cast<const uint32_t *>(iq_) + (size_t)bb * L;
-#pragma unroll
-			for (int r = 0; r < NLD; r++) {
-				const int i = r * WAVE + lane;
-				pre_i[r] = (r < NLD - 1 || i < L) ? src[i] : 0u;
-			}
-		}
-	};
-	// LIST: position in the list of the wave's current burst, and the index of the burst after next (fetched a burst ahead)
-	unsigned lpos = blockIdx.x * 16u + (unsigned)wave;
-	const unsigned lstride = n_wg * 16u;
-	uint32_t pre_id = K4_NO_BURST;
-	unsigned b_first;
-	if (LIST) {
-		b_first = K4_NO_BURST;
-		if (lpos < n_bursts)
-			b_first = (unsigned)uni((int)rlist[lpos]);
-		if (lpos + lstride < n_bursts)
-			pre_id = rlist[lpos + lstride];
-	} else {
+	if (!LIST) {
 		b_first = burst_of((unsigned)wave);                         // (static: pooled launches give every workgroup >= 7 groups)
+		if (b_first != K4_NO_BURST)
+			prefetch(b_first);
 	}
-	if (b_first != K4_NO_BURST)
-		prefetch(b_first);
 
 	// loader address: sample r*64 + lane -> phase lane&3, m = 16r + lane>>2
 	c32 *const pload = P + (lane & 3) * PH_A + PH_M0 + (lane >> 2);
@@ -1122,8 +1129,10 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 	if (LIST) {
 		__syncthreads();
 		if (threadIdx.x == 0) {
+			// (workgroups with a list position: ceil(n / 16), capped by the grid; the others left at the top)
+			const unsigned n_active = (n_bursts + 15u) / 16u < gridDim.x ? (n_bursts + 15u) / 16u : gridDim.x;
 			const unsigned d = __hip_atomic_fetch_add(redo + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-			if (d == gridDim.x - 1u) {
+			if (d == n_active - 1u) {
 				__hip_atomic_store(redo, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				__hip_atomic_store(redo + 1, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 			}

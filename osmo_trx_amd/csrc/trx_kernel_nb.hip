@@ -8,7 +8,7 @@
 // but nothing else is in here: no access / EDGE / dummy / wide-window / exact-demodulator code, no run-time flags.  A burst
 // this kernel cannot finish is APPENDED TO A LIST and left to the general kernel, which is launched behind it over that list:
 //   * the slot is not a normal-burst slot (type != TSC, tsc > 7) or its window is wider than one round (max_toa > 32);
-//   * a decimated sample fails the addition-only correlation's guard (unit_unsafe(): about one burst in 3000);
+//   * (a decimated sample that fails the addition-only correlation's guard -- about one burst in 3000 -- takes the multiplying form here)
 //   * the peak-ratio gate is too close to call for the estimate (about one in 1e5);
 //   * the detected TOA is outside the straight-line demodulator's geometry (toa < -0.25 or > 9 symbols).
 // What is different from the general kernel, beside what is absent:
@@ -25,7 +25,7 @@
 #define NB_CZ_LEN   (TRX_CZ_PAD + TRX_CORR_NARROW + TRX_CZ_PAD)
 #define NB_SLICE    (K4_XS + NB_D_LEN + NB_CZ_LEN)                /* complex samples per wave */
 #define NB_COMP_ROWS (TRX_DELAY_FILTS + 1)
-#define NB_TABLES_FLOATS (TRX_SINCV_LDS + 16 * WAVE + NB_COMP_ROWS * 36 + 16 + 8 * 8 + 5 * WAVE + 5 * WAVE)
+#define NB_TABLES_FLOATS (TRX_SINCV_LDS + 16 * WAVE + NB_COMP_ROWS * 36 + 16 + 8 * 8 + 5 * WAVE + 5 * WAVE + 2 * 8 * 16)
 #define NB_TABLES_BYTES (NB_TABLES_FLOATS * 4)
 #define NB_WPB 16
 #define NB_POOL_RING 64
@@ -56,6 +56,7 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 	static_assert(NB_TABLES_BYTES % 16 == 0 && (NB_SLICE * 8) % 16 == 0 && (K4_XS * 8) % 16 == 0 && (NB_D_LEN * 8) % 16 == 0, "16-byte LDS accesses");
 	static_assert(NB_LDS_BYTES <= 160 * 1024, "LDS");
 	static_assert(NB_ASM_GDEC_OFF == (TRX_SINCV_LDS + 16 * WAVE + NB_COMP_ROWS * 36) * 4, "tools/gen_nb_asm.py: LDS offset of the decimator taps");
+	static_assert(NB_ASM_LSEQ_OFF == (NB_TABLES_FLOATS - 2 * 8 * 16) * 4, "tools/gen_nb_asm.py: LDS offset of the training-sequence taps");
 	constexpr int NLD = 10;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const int lane0 = threadIdx.x & (WAVE - 1);
@@ -70,6 +71,7 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 	float *const lhdr = gdec + 16;                                 // [8][8] headers of the eight training sequences
 	int *const pkcl = reinterpret_cast<int *>(lhdr + 8 * 8);       // [5][64] PeakConst fields by lane (the exact re-run of the TOA search)
 	int *const lcn = pkcl + 5 * WAVE;                              // [5][64] lane constants of the hand-placed blocks (below)
+	c32 *const lseq = reinterpret_cast<c32 *>(lcn + 5 * WAVE);     // [8][16] training-sequence taps (the multiplying correlation: guard failures)
 	c32 *const wbase = reinterpret_cast<c32 *>(smem + NB_TABLES_BYTES) + (size_t)wave * NB_SLICE;
 	int *const wg_next = reinterpret_cast<int *>(reinterpret_cast<c32 *>(smem + NB_TABLES_BYTES) + (size_t)NB_WPB * NB_SLICE);
 	int *const pool_g = wg_next + 4;
@@ -92,6 +94,9 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 	}
 	if (threadIdx.x < 16)
 		gdec[threadIdx.x] = tab->dec_taps[threadIdx.x];
+	if (threadIdx.x < 128)
+		lseq[threadIdx.x] = make_float2(tab->seq[TRX_SEQ_TSC0 + (threadIdx.x >> 4)].taps[threadIdx.x & 15].re,
+						tab->seq[TRX_SEQ_TSC0 + (threadIdx.x >> 4)].taps[threadIdx.x & 15].im);
 	if (threadIdx.x < 64)
 		lhdr[threadIdx.x] = reinterpret_cast<const float *>(&tab->seq[TRX_SEQ_TSC0 + (threadIdx.x >> 3)].gain)[threadIdx.x & 7];
 	if (threadIdx.x < WAVE) {
@@ -200,6 +205,20 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 	if (b_first != NB_NO_BURST)
 		prefetch(b_first, lane0);
 
+	// ---- functions of the lane only, in registers for the whole kernel (the kernel is bound by the LDS: 21 registers instead of
+	// 9 LDS reads per burst): round A's sixteen interpolation weights, the lane constants of the hand-placed blocks; and the
+	// /4 decimator's taps 0..7 in four scalar register pairs
+	v2f wra[8];
+#pragma unroll
+	for (int q = 0; q < 4; q++) {
+		const float4 w = wa4[q * WAVE + lane0];
+		wra[2 * q] = (v2f){ w.x, w.y };
+		wra[2 * q + 1] = (v2f){ w.z, w.w };
+	}
+	const int kr = lcn[0 * WAVE + lane0], ka = lcn[1 * WAVE + lane0], kb = lcn[2 * WAVE + lane0], kic = lcn[3 * WAVE + lane0],
+		  ktp = lcn[4 * WAVE + lane0];
+	const unsigned long long *const gp = reinterpret_cast<const unsigned long long *>(tab->dec_taps);
+	const unsigned long long g01 = gp[0], g23 = gp[1], g45 = gp[2], g67 = gp[3];
 	// ---- deferred output (registers): o = the lane's three sliced soft bits, recw = the result record (lanes 0..7)
 	v3f o = { 0.0f, 0.0f, 0.0f };
 	int recw = 0;
@@ -272,29 +291,21 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 			unsigned long long bad;
 			asm volatile(NB_ASM_DEC
 				     : [bad] "=s"(bad)
-				     : [pd] "v"(lds_addr(P + PH_M0 + 52) + 8u * (unsigned)lane), [vd] "v"(vd_addr), [zero] "v"(0), [nact] "s"(15 + len)
+				     : [pd] "v"(lds_addr(P + PH_M0 + 52) + 8u * (unsigned)lane), [vd] "v"(vd_addr), [nact] "s"(15 + len),
+				       [g01] "s"(g01), [g23] "s"(g23), [g45] "s"(g45), [g67] "s"(g67)
 				     : NB_ASM_CLOBBERS);
-			if (bad != 0ull) {
-				leave = true;
-				if (lane == 0) atomicAdd(&g_trx_fast_stats[1], 1ull);          // (cold) left to the general kernel: correlation guard
-			} else {
+			{
 				// ---- correlation (lane = lag; the twelve lanes behind the window store the right zero pad), arg-max and the
 				// energyDetect sum (:1573-1585); the lane constants of the TOA search are fetched in the reductions' wait states
 				float v;
 				asm volatile(NB_ASM_CORR
 					     : [nrm] "=&v"(v)
-					     : [vd] "v"(vd_addr), [vcz] "v"(vcz_addr), [len] "s"(len), [tsc] "s"(tsc)
+					     : [vd] "v"(vd_addr), [vcz] "v"(vcz_addr), [len] "s"(len), [tsc] "s"(tsc), [bad] "s"(bad)
 					     : NB_ASM_CLOBBERS);
 				int m_bits, es_bits, bidx;
-				int kr, ka, kb, kic, ktp;                                   // lane constants (lcn[])
-				asm volatile(NB_ASM_AMAX("ds_read_b32 %[kr], %[l4] offset:%c[lc]", "ds_read_b32 %[ka], %[l4] offset:%c[lc]+256",
-							 "ds_read_b32 %[kb], %[l4] offset:%c[lc]+512", "ds_read_b32 %[kic], %[l4] offset:%c[lc]+768",
-							 "ds_read_b32 %[ktp], %[l4] offset:%c[lc]+1024", "s_nop 0", "s_nop 0", "s_nop 0")
-					     "s_waitcnt lgkmcnt(0)"
-					     : [m] "=s"(m_bits), [es] "=s"(es_bits), [bidx] "=s"(bidx), [kr] "=&v"(kr), [ka] "=&v"(ka), [kb] "=&v"(kb),
-					       [kic] "=&v"(kic), [ktp] "=&v"(ktp)
-					     : [nrm] "v"(v), [ep] "v"(epart), [l4] "v"(4 * lane),
-					       [lc] "n"((TRX_SINCV_LDS + 16 * WAVE + NB_COMP_ROWS * 36 + 16 + 64 + 5 * WAVE) * 4)
+				asm volatile(NB_ASM_AMAX("s_nop 0", "s_nop 0", "s_nop 0", "s_nop 0", "s_nop 0", "s_nop 0", "s_nop 0", "s_nop 0")
+					     : [m] "=s"(m_bits), [es] "=s"(es_bits), [bidx] "=s"(bidx)
+					     : [nrm] "v"(v), [ep] "v"(epart)
 					     : NB_ASM_CLOBBERS);
 				int hit = 0;
 				int toa512 = 0;
@@ -304,7 +315,9 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 					float km;
 					asm volatile(NB_ASM_DETA
 						     : [st] "=&s"(st), [e] "=&s"(e512), [km] "=&v"(km)
-						     : [bidx] "s"(bidx), [len] "s"(len), [czb] "s"(lds_addr(cz)), [kr] "v"(kr), [ka] "v"(ka), [l16] "v"(16 * lane),
+						     : [bidx] "s"(bidx), [len] "s"(len), [czb] "s"(lds_addr(cz)), [kr] "v"(kr), [ka] "v"(ka),
+						       [w0] "v"(wra[0]), [w1] "v"(wra[1]), [w2] "v"(wra[2]), [w3] "v"(wra[3]), [w4] "v"(wra[4]), [w5] "v"(wra[5]),
+						       [w6] "v"(wra[6]), [w7] "v"(wra[7]),
 						       [k5] "s"(gk5), [k6] "s"(gk6), [k7] "s"(gk7), [k8] "s"(gk8), [c0] "v"(gc0), [nodes] "s"(0x1555555555555555ull)
 						     : NB_ASM_CLOBBERS);
 					int xr_bits = 0, xi_bits = 0;

@@ -11,7 +11,7 @@ blocks below are therefore whole phases of a burst, and this script CHECKS what 
     VGPR -> v_readlane 1; VALU-written SGPR -> v_readlane lane select 4, -> VMEM address 5; x3 / x4 store data 2;
   * every register loaded from LDS is covered by an s_waitcnt lgkmcnt(n) before its first use (LDS returns in order).
 Registers: operands the compiler allocates are %[name]; the blocks' temporaries are the fixed VGPRs v64..v127 and SGPRs
-s80..s99, declared as clobbers of every statement (NB_ASM_CLOBBERS)."""
+s87..s99, declared as clobbers of every statement (NB_ASM_CLOBBERS)."""
 import os
 import re
 import sys
@@ -234,21 +234,19 @@ def sreg(i, n=1):
 # only (bitwise symmetric filter).  The sixteen samples arrive in order: four waits, each covering the next four.
 # ------------------------------------------------------------------------------------------------------------------
 def block_dec(gdec_off):
-    b = Block("DEC", ("nact", "bad"))
+    b = Block("DEC", ("nact", "bad", "g01", "g23", "g45", "g67"))
     X = lambda k: vreg(88 + 2 * k, 2)
-    GA, GB = 120, 124
     b(f"s_bfm_b64 exec, %[nact], 0")
-    b(f"ds_read_b128 {vreg(GA, 4)}, %[zero] offset:{gdec_off}")
-    b(f"ds_read_b128 {vreg(GB, 4)}, %[zero] offset:{gdec_off + 16}")
     for k in range(16):
         off = (((k + 1) & 3) * PH_A + ((k + 1) >> 2)) * 8
         b(f"ds_read_b64 {X(k)}, %[pd] offset:{off}")
 
     def mul(k):
+        # taps g[0..7] (the filter is bitwise symmetric) live in four scalar register pairs for the whole kernel
         kk = k if k < 8 else 15 - k
-        base = (GB if (kk >> 2) else GA) + (2 if (kk & 2) else 0)
+        pair = ("%[g01]", "%[g23]", "%[g45]", "%[g67]")[kk >> 1]
         sel = "op_sel:[0,1] op_sel_hi:[1,1]" if (kk & 1) else "op_sel:[0,0] op_sel_hi:[1,0]"
-        b(f"v_pk_mul_f32 {X(k)}, {X(k)}, {vreg(base, 2)} {sel}")
+        b(f"v_pk_mul_f32 {X(k)}, {X(k)}, {pair} {sel}")
 
     def add(k):            # y (in X(0)) += product k
         b(f"v_pk_add_f32 {X(0)}, {X(0)}, {X(k)}")
@@ -284,14 +282,16 @@ def block_dec(gdec_off):
 # for the next sample ARE those wait states.  Eight variants (sign / swap patterns are instruction modifiers), entered by
 # a computed jump.
 # ------------------------------------------------------------------------------------------------------------------
-def block_corr():
-    b = Block("CORR", ("len", "tsc"))
+def block_corr(lseq_off):
+    b = Block("CORR", ("len", "tsc", "bad"))
     X = lambda k: vreg(88 + 2 * k, 2)
     ACC = vreg(120, 2)
     b(f"v_mov_b64_e32 {ACC}, 0")
     b("s_bfm_b64 exec, %[len], 0")
     for k in range(16):
         b(f"ds_read_b64 {X(k)}, %[vd] offset:{8 * k}")
+    b("s_cmp_lg_u64 %[bad], 0")                                    # a sample failed the guard: the multiplying form (below)
+    b("s_cbranch_scc1 .Lnb_corr_mul")
     b("s_getpc_b64 s[88:89]")
     b(".Lnb_corr_pc:")
     b("s_mul_i32 s90, %[tsc], .Lnb_corr_v1-.Lnb_corr_v0")
@@ -323,6 +323,26 @@ def block_corr():
     b(f"v_pk_mul_f32 v[122:123], {ACC}, {ACC}")
     b("s_waitcnt lgkmcnt(0)")
     b("v_add_f32_e32 %[nrm], v123, v122")
+    b("s_branch .Lnb_corr_end")
+    # ---- cold (about one burst in 3000): convolve_complex() as written (convolve_base.c:28-40, :72-85), taps from LDS:
+    # (yr, yi) += (xr hr - xi hi, xr hi + xi hr) as two packed multiplies, one packed add with the low half negated, one accumulate
+    b(".Lnb_corr_mul:")
+    b("s_lshl_b32 s90, %[tsc], 7")
+    b("v_mov_b32_e32 v64, s90")
+    H = lambda k: vreg(66 + 2 * (k & 7), 2)
+    for half in range(2):
+        for q in range(4):
+            b(f"ds_read_b128 {vreg(66 + 4 * q, 4)}, v64 offset:{lseq_off + 64 * half + 16 * q}")
+        b("s_waitcnt lgkmcnt(0)")
+        for k in range(8 * half, 8 * half + 8):
+            b(f"v_pk_mul_f32 v[82:83], {X(k)}, {H(k)} op_sel:[0,0] op_sel_hi:[0,1]")
+            b(f"v_pk_mul_f32 v[84:85], {X(k)}, {H(k)} op_sel:[1,1] op_sel_hi:[1,0]")
+            b("s_nop 0")
+            b("v_pk_add_f32 v[86:87], v[82:83], v[84:85] neg_lo:[0,1] neg_hi:[0,0]")
+            b("s_nop 0")
+            b(f"v_pk_add_f32 {ACC}, {ACC}, v[86:87]")
+    b("s_branch .Lnb_corr_join")
+    b(".Lnb_corr_end:")
     return b
 
 
@@ -353,6 +373,14 @@ def check_variants(b):
     """CORR: check each variant as its own straight line (prefix + variant t + suffix)"""
     errs = []
     lines = b.ins
+    # the multiplying form: prefix up to the branch, the cold block, then the join
+    im, ie = lines.index(".Lnb_corr_mul:"), lines.index(".Lnb_corr_end:")
+    ibr = lines.index("s_cbranch_scc1 .Lnb_corr_mul")
+    jj = lines.index(".Lnb_corr_join:")
+    v = Block("CORR[mul]", ("len", "tsc", "bad"))
+    v.ins = lines[:ibr] + lines[im:ie - 0] + lines[jj:im - 0]
+    errs += v.check()
+    lines = lines[:im] + lines[ie:]
     i0 = lines.index(".Lnb_corr_v0:")
     j = lines.index(".Lnb_corr_join:")
     per = (j - i0) // 8
@@ -439,7 +467,8 @@ def careful_walk(b, c, cd, p, pos, levels, unsure_label, w="b64"):
 # on an estimate with a proven margin, round A of peakDetect()'s bisection (levels 0..4, trx_device.h peak_detect_fast) and
 # its certified tree walk.
 #   in : %[bidx] %[len] %[czb] SGPR (czb = LDS byte address of cz[0]); %[kr] %[ka] VGPR lane constants (byte offsets of the
-#        lane's peak-ratio term and of round A's first tap, relative to &cz[bidx]); %[l16] VGPR 16 * lane; %[k5]..%[k8] SGPR
+#        lane's peak-ratio term and of round A's first tap, relative to &cz[bidx]); %[w0]..%[w7] VGPR pairs: the lane's sixteen
+#        round-A weights, taps fl-7 .. fl+8; %[k5]..%[k8] SGPR
 #        thresh^2 / n; %[c0] VGPR thresh^2 * 1.0001e-5; %[nodes] SGPR pair 0x1555555555555555
 #   out: %[st] SGPR 0 miss / 1 found / 2 gate too close to call / 3 an uncertified decision on the path; %[e] SGPR earlyIndex
 #        * 512 after round A; %[km] VGPR KAPPA * |corr[bidx]|^2 (round B's margin term)
@@ -471,8 +500,6 @@ def block_deta(wa4_off):
     b("s_mov_b64 exec, 1")
     b("ds_write_b64 v67, v[72:73]")                                # interpolatePoint() never reads the last correlation sample (:1105)
     b("s_mov_b64 exec, -1")
-    b(f"ds_read_b128 v[76:79], %[l16] offset:{wa4_off}")
-    b(f"ds_read_b128 v[80:83], %[l16] offset:{wa4_off + 1024}")
     for u in range(8):
         b(f"ds_read_b64 {X(u)}, v66 offset:{8 * u}")
     b("v_mov_b64_e32 v[84:85], 0")                                 # p0, p1 of the two-chain sums
@@ -490,7 +517,7 @@ def block_deta(wa4_off):
     b("s_cselect_b32 s93, %[k6], %[k5]")
     b("s_cmp_ge_u32 s91, 7")
     b("s_cselect_b32 s92, s92, s93")
-    b("s_waitcnt lgkmcnt(11)")
+    b("s_waitcnt lgkmcnt(9)")
     b("v_pk_mul_f32 v[70:71], v[70:71], v[70:71]")
     b("v_pk_mul_f32 v[68:69], v[68:69], v[68:69]")
     b("v_add_f32_e32 v75, v71, v70")
@@ -511,21 +538,19 @@ def block_deta(wa4_off):
     b("s_mov_b32 %[st], 2")
     b("s_cbranch_vccz .Lnb_da_wait_end")                           # too close to call
     # ---- round A: interp over taps fl-7 .. fl+8 with this lane's weights, two FMA chains (even / odd taps)
-    b(f"ds_read_b128 v[104:107], %[l16] offset:{wa4_off + 2048}")
-    b(f"ds_read_b128 v[108:111], %[l16] offset:{wa4_off + 3072}")
     for u in range(8):
         b(f"ds_read_b64 {Y(u)}, v66 offset:{8 * (8 + u)}")
-    b("s_waitcnt lgkmcnt(10)")
+    b("s_waitcnt lgkmcnt(8)")
 
-    def fmas(xs, qa, qb):
+    def fmas(xs, h):
+        # this lane's sixteen weights (functions of the lane only) live in eight register pairs for the whole kernel
         for u in range(0, 8, 2):
-            q = qb if (u & 4) else qa
-            hp = vreg(q + (2 if (u & 2) else 0), 2)
+            hp = f"%[w{4 * h + (u >> 1)}]"
             b(f"v_pk_fma_f32 v[84:85], {xs(u)}, {hp}, v[84:85] op_sel:[0,0,0] op_sel_hi:[1,0,1]")
             b(f"v_pk_fma_f32 v[86:87], {xs(u + 1)}, {hp}, v[86:87] op_sel:[0,1,0] op_sel_hi:[1,1,1]")
-    fmas(X, 76, 80)
+    fmas(X, 0)
     b("s_waitcnt lgkmcnt(0)")
-    fmas(Y, 104, 108)
+    fmas(Y, 1)
     b("s_nop 0")
     b("v_pk_add_f32 v[84:85], v[84:85], v[86:87]")
     b("s_nop 0")
@@ -834,9 +859,11 @@ def main():
     # LDS layout of the kernel's tables (must match trx_kernel_nb.hip; the kernel static_asserts these numbers)
     SINCV_LDS = 4096 + 32
     gdec_off = (SINCV_LDS + 16 * 64 + 65 * 36) * 4
+    NB_TABLES_END_OLD = SINCV_LDS + 16 * 64 + 65 * 36 + 16 + 64 + 5 * 64 + 5 * 64      # floats in front of the training-sequence taps
     blocks = {}
     blocks["DEC"] = block_dec(gdec_off)
-    blocks["CORR"] = block_corr()
+    lseq_off = NB_TABLES_END_OLD * 4
+    blocks["CORR"] = block_corr(lseq_off)
     wa4_off = SINCV_LDS * 4
     blocks["DETA"] = block_deta(wa4_off)
     blocks["DETB"] = block_detb()
@@ -845,8 +872,9 @@ def main():
         check_paths(blocks["TAIL"])
     hdr = ["// trx_nb_asm.inc -- GENERATED by tools/gen_nb_asm.py (hazards and LDS waits checked there); do not edit.",
            f"#define NB_ASM_GDEC_OFF {gdec_off}",
+           f"#define NB_ASM_LSEQ_OFF {lseq_off}",
            "#define NB_ASM_CLOBBERS " + ", ".join(f'"v{i}"' for i in range(64, 128)) + ", " +
-           ", ".join(f'"s{i}"' for i in range(80, 100)) + ', "vcc", "scc", "memory"']
+           ", ".join(f'"s{i}"' for i in range(87, 100)) + ', "vcc", "scc", "memory"']
     for name, b in blocks.items():
         hdr.append(f"#define NB_ASM_{name} \\")
         lines = b.text()
