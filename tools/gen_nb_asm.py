@@ -192,7 +192,7 @@ class Block:
                 if r.startswith(("v", "%")) and r not in self.sgpr_ops:
                     # a full overwrite under the full mask defines every lane; a write under a narrowed mask leaves the other
                     # lanes as they were: defined only if they were defined before (tracked as the narrower of the two)
-                    if exec_tok == "full" or r not in w_exec:
+                    if exec_tok == "full" or w_exec.get(r) != "full":
                         w_exec[r] = exec_tok
             if "exec" in wr or any(d.strip().startswith("exec") for d in dsts):
                 exec_tok = "full" if re.search(r"exec(_lo|_hi)?, -1$", text.strip()) and "exec_" not in text else text.strip()
@@ -494,9 +494,11 @@ def block_deta(wa4_off):
     b("s_lshl3_add_u32 s90, s90, %[czb]")                          # &cz[len - 1]
     b("v_add_u32_e32 v66, s89, %[ka]")
     b("ds_read_b64 v[68:69], v64")                                 # corr[bidx]
-    b("ds_read_b64 v[70:71], v65")                                 # this lane's peak-ratio term (read before cz[len - 1] is zeroed)
     b("v_mov_b32_e32 v67, s90")
     b("v_mov_b64_e32 v[72:73], 0")
+    # (the chip runs at its power limit: what only a few lanes need runs on those lanes -- the eight terms of the gate on lanes 0..7)
+    b("s_bfm_b64 exec, 8, 0")
+    b("ds_read_b64 v[70:71], v65")                                 # this lane's peak-ratio term (read before cz[len - 1] is zeroed)
     b("s_mov_b64 exec, 1")
     b("ds_write_b64 v67, v[72:73]")                                # interpolatePoint() never reads the last correlation sample (:1105)
     b("s_mov_b64 exec, -1")
@@ -504,31 +506,32 @@ def block_deta(wa4_off):
         b(f"ds_read_b64 {X(u)}, v66 offset:{8 * u}")
     b("v_mov_b64_e32 v[84:85], 0")                                 # p0, p1 of the two-chain sums
     b("v_mov_b64_e32 v[86:87], 0")
-    # number of in-range terms (:1555-1562) -> thresh^2 / num
-    b("s_add_u32 s91, %[bidx], -1")
-    b("s_sub_u32 s92, %[len], %[bidx]")
-    b("s_min_u32 s91, s91, 4")
-    b("s_add_u32 s92, s92, -2")
-    b("s_min_u32 s92, s92, 4")
-    b("s_add_u32 s91, s91, s92")
-    b("s_cmp_eq_u32 s91, 8")
-    b("s_cselect_b32 s92, %[k8], %[k7]")
-    b("s_cmp_eq_u32 s91, 6")
-    b("s_cselect_b32 s93, %[k6], %[k5]")
-    b("s_cmp_ge_u32 s91, 7")
-    b("s_cselect_b32 s92, s92, s93")
+    # number of in-range terms (:1555-1562) -> thresh^2 / num: scalar instructions, placed in the wait states of the vector ones
+    sc = ["s_add_u32 s91, %[bidx], -1", "s_sub_u32 s92, %[len], %[bidx]", "s_min_u32 s91, s91, 4", "s_add_u32 s92, s92, -2",
+          "s_min_u32 s92, s92, 4", "s_add_u32 s91, s91, s92", "s_cmp_eq_u32 s91, 8", "s_cselect_b32 s92, %[k8], %[k7]",
+          "s_cmp_eq_u32 s91, 6", "s_cselect_b32 s93, %[k6], %[k5]", "s_cmp_ge_u32 s91, 7", "s_cselect_b32 s92, s92, s93"]
+    for t in sc[:3]:
+        b(t)
     b("s_waitcnt lgkmcnt(9)")
-    b("v_pk_mul_f32 v[70:71], v[70:71], v[70:71]")
     b("v_pk_mul_f32 v[68:69], v[68:69], v[68:69]")
-    b("v_add_f32_e32 v75, v71, v70")
+    b(sc[3])
     b("v_add_f32_e32 v74, v69, v68")                               # m = |corr[bidx]|^2
-    b("s_nop 1")
-    b(f"v_add_f32_dpp v75, v75, v75 quad_perm:[1,0,3,2] {D_ALL}")
     b(f"v_mul_f32_e32 %[km], {fhex(KAPPA)}, v74")
-    b("s_nop 0")
+    # (the chip runs at its power limit: what only a few lanes need runs on those lanes -- the eight terms of the gate on lanes 0..7)
+    b("s_bfm_b64 exec, 8, 0")
+    b("v_pk_mul_f32 v[70:71], v[70:71], v[70:71]")
+    b(sc[4])
+    b("v_add_f32_e32 v75, v71, v70")
+    b(sc[5])
+    b(sc[6])
+    b(f"v_add_f32_dpp v75, v75, v75 quad_perm:[1,0,3,2] {D_ALL}")
+    b(sc[7])
+    b(sc[8])
     b(f"v_add_f32_dpp v75, v75, v75 quad_perm:[2,3,0,1] {D_ALL}")
-    b("s_nop 1")
-    b(f"v_add_f32_dpp v75, v75, v75 row_half_mirror {D_ALL}")     # every lane: sum of the eight terms
+    b(sc[9])
+    b(sc[10])
+    b(f"v_add_f32_dpp v75, v75, v75 row_half_mirror {D_ALL}")     # lanes 0..7: sum of the eight terms
+    b(sc[11])
     b("v_mul_f32_e32 v112, s92, v75")                              # t2
     b(f"v_mul_f32_e32 v113, {fhex(1.0 - 1.2e-5)}, v112")
     b(f"v_fmamk_f32 v114, v112, {fhex(1.000024)}, %[c0]")
@@ -537,6 +540,7 @@ def block_deta(wa4_off):
     b("v_cmp_gt_f32_e32 vcc, v74, v114")
     b("s_mov_b32 %[st], 2")
     b("s_cbranch_vccz .Lnb_da_wait_end")                           # too close to call
+    b("s_mov_b64 exec, -1")
     # ---- round A: interp over taps fl-7 .. fl+8 with this lane's weights, two FMA chains (even / odd taps)
     for u in range(8):
         b(f"ds_read_b64 {Y(u)}, v66 offset:{8 * (8 + u)}")
@@ -583,6 +587,7 @@ def block_deta(wa4_off):
     b("s_mov_b32 %[st], 3")
     b("s_branch .Lnb_da_end")
     b(".Lnb_da_wait_end:")
+    b("s_mov_b64 exec, -1")
     b("s_waitcnt lgkmcnt(0)")
     b(".Lnb_da_end:")
     return b
@@ -683,13 +688,15 @@ def block_detb():
 # ------------------------------------------------------------------------------------------------------------------
 def block_tail():
     b = Block("TAIL", ("toa", "xr", "xi", "t5", "hdrb", "e8lo", "e8hi", "es", "fsdb", "flags", "modd", "m23", "ok", "nk", "pb", "cb", "db"))
+    b("v_mov_b32_e32 v65, %[hdrb]")
+    b("ds_read_b128 v[68:71], v65")                                # gain, 1 / gain
     b("s_sub_u32 s88, %[t5], %[toa]")
-    b("s_add_u32 s87, s88, 5120")                                # nk = -(toa512 - t5 - 10 * 512)
-    b("s_ashr_i32 s89, s87, 7")                                  # w = nk >> 7, must be -36 .. 0
+    b("s_add_u32 s87, s88, 5120")                                  # nk = -(toa512 - t5 - 10 * 512)
+    b("s_ashr_i32 s89, s87, 7")                                    # w = nk >> 7, must be -36 .. 0
     b("s_sub_u32 s90, 0, s89")
     b("s_mov_b32 %[ok], 0")
     b("s_cmp_gt_u32 s90, 36")
-    b("s_cbranch_scc1 .Lnb_tl_end")
+    b("s_cbranch_scc1 .Lnb_tl_wait_end")
     b("s_and_b32 s91, s87, 127")
     b("s_lshr_b32 s92, s91, 1")
     b("s_cmp_ge_u32 s91, 2")
@@ -705,62 +712,79 @@ def block_tail():
     b("s_cmp_lt_i32 %[toa], 0")
     b("s_cselect_b32 s96, s97, s96")
     b("s_lshl_b32 s96, s96, 3")
+    b("s_mov_b32 %[ok], 1")
     b("v_add_u32_e32 v64, s96, %[vd]")                             # &D[rt + lane]: sample ps + lane, ps = start + 1 - N + rt
-    b("v_mov_b32_e32 v65, %[hdrb]")
+    b("s_waitcnt lgkmcnt(0)")
+    # ---- every lane: amp = peak / gain (:1701), 1 / amp, the output stage's multiplier VP
+    b("v_mul_f32_e32 v82, %[xr], v70")                             # peak * (1 / gain): Complex.h:74
+    b("v_mul_f32_e32 v83, %[xr], v71")
+    b("v_mul_f32_e32 v84, %[xi], v71")
+    b("v_mul_f32_e32 v85, %[xi], v70")
+    b("v_sub_f32_e32 v86, v82, v84")                               # amp.re
+    b("v_add_f32_e32 v87, v83, v85")                               # amp.im
+    b("v_mul_f32_e32 v90, v86, v86")
+    b("v_mul_f32_e32 v89, v87, v87")
+    b("v_add_f32_e32 v89, v89, v90")                               # |amp|^2
+    b("v_rcp_f32_e32 v89, v89")
+    # ---- sixteen lanes (the chip runs at its power limit: wave-uniform arithmetic does not need 64 of them): computeCI, toa,
+    # RSSI, the result record
+    b("s_bfm_b64 exec, 16, 0")
     b("ds_read_b64 v[66:67], v64")
-    b("ds_read_b128 v[68:71], v65")                                # gain, 1 / gain
     b("ds_read_b128 v[72:75], v65 offset:16")                      # ci_den, toa, n, 1 / ci_den
+    b("s_mov_b64 exec, -1")
+    b("v_mul_f32_e32 v91, v86, v89")                               # 1 / amp = conj(amp) / |amp|^2 (Complex.h:75,144-150)
+    b("v_mul_f32_e64 v92, -v87, v89")
+    b("v_cndmask_b32_e64 v119, v91, v92, %[modd]")                # VP[lane & 3] = sx, sy, -sx, -sy
+    b("s_nop 0")
+    b("v_cndmask_b32_e64 v119, v119, -v119, %[m23]")
+    b("s_bfm_b64 exec, 16, 0")
     b("v_mul_f32_e64 v76, %[xi], %[xi]")
     b("v_mul_f32_e64 v77, %[xr], %[xr]")
     b("v_mov_b32_e32 v79, %[es]")
     b("v_cvt_f32_i32_e32 v78, %[toa]")
     b("v_add_f32_e32 v76, v76, v77")                               # |peak|^2
     b(f"v_mul_f32_e32 v79, {fhex(0.0125)}, v79")                   # energyDetect(burst, 20 * sps): / 80
-    b("v_log_f32_e32 v80, v79")
     b("v_mul_f32_e32 v78, 0x3b000000, v78")                        # position (exact)
-    b("s_mov_b32 %[ok], 1")
-    b(f"v_mul_f32_e32 v80, {fhex(3.01029996)}, v80")
-    b("s_waitcnt lgkmcnt(2)")
-    b("v_pk_mul_f32 v[66:67], v[66:67], v[66:67]")
-    b("v_sub_f32_e32 v80, %[fsdb], v80")                           # rssi
-    b("v_add_f32_e32 v81, v67, v66")                               # |sample|^2
+    b("v_log_f32_e32 v80, v79")
     b("s_waitcnt lgkmcnt(0)")
-    b("v_mul_f32_e32 v82, %[xr], v70")                             # peak * (1 / gain): Complex.h:74
-    b("v_mul_f32_e32 v83, %[xr], v71")
-    b(f"v_add_f32_dpp v81, v81, v81 quad_perm:[1,0,3,2] {D_ALL}")
-    b("v_mul_f32_e32 v84, %[xi], v71")
-    b("v_mul_f32_e32 v85, %[xi], v70")
-    b(f"v_add_f32_dpp v81, v81, v81 quad_perm:[2,3,0,1] {D_ALL}")
-    b("v_sub_f32_e32 v86, v82, v84")                               # amp.re
-    b("v_add_f32_e32 v87, v83, v85")                               # amp.im
-    b(f"v_add_f32_dpp v81, v81, v81 row_half_mirror {D_ALL}")
+    b("v_pk_mul_f32 v[66:67], v[66:67], v[66:67]")
+    b(f"v_mul_f32_e32 v80, {fhex(3.01029996)}, v80")
+    b("v_add_f32_e32 v81, v67, v66")                               # |sample|^2
+    b("v_sub_f32_e32 v80, %[fsdb], v80")                           # rssi
     b("v_mul_f32_e32 v88, v76, v75")                               # C
-    b("v_mul_f32_e32 v89, v87, v87")
-    b(f"v_add_f32_dpp v81, v81, v81 row_mirror {D_ALL}")
-    b("v_mul_f32_e32 v90, v86, v86")
+    b(f"v_add_f32_dpp v81, v81, v81 quad_perm:[1,0,3,2] {D_ALL}")
     b("v_sub_f32_e32 v78, v78, v73")                               # - sync->toa (:1704)
-    b("v_add_f32_e32 v89, v89, v90")                               # |amp|^2
-    b("v_mul_f32_e32 v81, 0x3d800000, v81")                        # S = sum / 16 (row 0)
-    b("v_add_f32_e32 v78, 0xc1200000, v78")                        # - head (:1768)
-    b("v_readlane_b32 s98, v81, 0")
-    b("v_rcp_f32_e32 v89, v89")
-    b("s_nop 0")
-    b("v_sub_f32_e32 v94, s98, v88")                               # S - C
-    b("v_mul_f32_e32 v91, v86, v89")                               # 1 / amp = conj(amp) / |amp|^2 (Complex.h:75,144-150)
-    b("v_rcp_f32_e32 v94, v94")
-    b("v_mul_f32_e64 v92, -v87, v89")
-    b("v_mul_f32_e32 v94, v88, v94")
-    b("v_cndmask_b32_e64 v119, v91, v92, %[modd]")                # VP[lane & 3] = sx, sy, -sx, -sy
-    b("v_log_f32_e32 v94, v94")
-    b("v_cndmask_b32_e64 v119, v119, -v119, %[m23]")
-    b(f"v_mul_f32_e32 v94, {fhex(3.0103)}, v94")                   # C/I, dB (:1637)
-    # record: rc = TSC in lane 0, then one v_cndmask per field under a one-lane mask
     b("v_mov_b32_e32 %[rec], 1")
-    for k, r in ((1, "v78"), (2, "v86"), (3, "v87"), (4, "v94"), (5, "v79"), (6, "v80")):
-        b(f"s_mov_b64 s[98:99], {1 << k}")
-        b(f"v_cndmask_b32_e64 %[rec], %[rec], {r}, s[98:99]")
+    b(f"v_add_f32_dpp v81, v81, v81 quad_perm:[2,3,0,1] {D_ALL}")
+    b("v_add_f32_e32 v78, 0xc1200000, v78")                        # - head (:1768)
+    b("s_mov_b64 s[98:99], 4")
+    b(f"v_add_f32_dpp v81, v81, v81 row_half_mirror {D_ALL}")
+    b("v_cndmask_b32_e64 %[rec], %[rec], v86, s[98:99]")
+    b("s_mov_b64 s[98:99], 8")
+    b(f"v_add_f32_dpp v81, v81, v81 row_mirror {D_ALL}")
+    b("v_cndmask_b32_e64 %[rec], %[rec], v87, s[98:99]")
+    b("s_mov_b64 s[98:99], 2")
+    b("v_mul_f32_e32 v81, 0x3d800000, v81")                        # S = sum / 16 (row 0)
+    b("v_cndmask_b32_e64 %[rec], %[rec], v78, s[98:99]")
+    b("v_readlane_b32 s97, v81, 0")
+    b("s_mov_b64 s[98:99], 32")
+    b("v_cndmask_b32_e64 %[rec], %[rec], v79, s[98:99]")
+    b("s_mov_b64 s[98:99], 64")
+    b("v_sub_f32_e32 v94, s97, v88")                               # S - C
+    b("v_cndmask_b32_e64 %[rec], %[rec], v80, s[98:99]")
+    b("v_rcp_f32_e32 v94, v94")
     b("v_writelane_b32 %[rec], %[flags], 7")
+    b("v_mul_f32_e32 v94, v88, v94")
+    b("s_mov_b64 s[98:99], 16")
+    b("v_log_f32_e32 v94, v94")
+    b("s_nop 0")
+    b(f"v_mul_f32_e32 v94, {fhex(3.0103)}, v94")                   # C/I, dB (:1637)
+    b("v_cndmask_b32_e64 %[rec], %[rec], v94, s[98:99]")
+    b("s_mov_b64 exec, -1")
     block_demod(b)
+    b("s_branch .Lnb_tl_end")
+    b(".Lnb_tl_wait_end:")
+    b("s_waitcnt lgkmcnt(0)")
     b(".Lnb_tl_end:")
     return b
 
@@ -811,6 +835,7 @@ def block_demod(b):
     b("v_cndmask_b32_e32 v117, v118, v117, vcc")                   # this lane's tap row
     for j in range(3):
         b(f"v_mov_b64_e32 {ACC[j]}, 0")
+    b("s_mov_b32 exec_hi, 0x0ff0ffff")                             # lanes 48..51 and 60..63 have no symbol: off for the filter
     D, NT, NV = 4, 24, 32
     PH0 = 96                                                       # byte offset of PH_M0 entries
     b(f"ds_read_b128 {vreg(CQ[0], 4)}, v117")
@@ -845,6 +870,7 @@ def block_demod(b):
     b(f"v_fmac_f32_dpp %[d1], v119, v67 quad_perm:[0,3,2,1] {D_ALL}")
     b(f"v_fmac_f32_dpp %[d2], v119, v69 quad_perm:[1,0,3,2] {D_ALL}")
     b(f"v_fmac_f32_dpp %[d0], v119, v65 quad_perm:[3,2,1,0] {D_ALL}")
+    b("s_mov_b64 exec, -1")
 
 
 def c_string(lines):
