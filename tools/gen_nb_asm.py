@@ -818,12 +818,7 @@ def block_demod(b):
     b("s_lshl3_add_u32 s94, s94, %[pb]")                           # &P[ph0][m = c >> 2] - 12 entries
     b("s_mul_i32 s95, s90, 144")
     b("s_add_u32 s95, s95, %[cb]")                                 # composite row of the burst's delay filter, from tap U0
-    b("v_add_u32_e32 v116, %[db], %[l16]")
-    b("s_waitcnt vmcnt(0)")
-    b("ds_write_b128 v116, v[120:123]")                               # park the low-edge rows: lane l holds floats 4l .. 4l+3 of the 8 x 24 block
     b(f"v_add_u32_e32 {vreg(P[0])}, s94, %[kic]")
-    b("v_cmp_lt_i32_e32 vcc, -1, %[ktp]")
-    b("v_add_u32_e32 v117, %[db], %[ktp]")
     for k in range(1, 4):
         # p[k] = p[0] + (k * PH_A + ((ph0 + k) >> 2) * (1 - 4 * PH_A)) entries
         b(f"s_add_u32 s96, s92, {k}")
@@ -831,16 +826,22 @@ def block_demod(b):
         b(f"s_mul_i32 s96, s96, {(1 - 4 * PH_A) * 8}")
         b(f"s_add_u32 s96, s96, {k * PH_A * 8}")
         b(f"v_add_u32_e32 {vreg(P[k])}, s96, {vreg(P[0])}")
-    b("v_mov_b32_e32 v118, s95")
-    b("v_cndmask_b32_e32 v117, v118, v117, vcc")                   # this lane's tap row
-    for j in range(3):
-        b(f"v_mov_b64_e32 {ACC[j]}, 0")
-    b("s_mov_b32 exec_hi, 0x0ff0ffff")                             # lanes 48..51 and 60..63 have no symbol: off for the filter
     D, NT, NV = 4, 24, 32
     PH0 = 96                                                       # byte offset of PH_M0 entries
-    b(f"ds_read_b128 {vreg(CQ[0], 4)}, v117")
+    b("s_mov_b32 exec_hi, 0x0ff0ffff")                             # lanes 48..51 and 60..63 have no symbol: off for the filter
+    # the first twelve samples do not depend on the tap rows: requested in front of the wait for those (L2 latency)
     for v in range(8 + D):
         b(f"ds_read_b64 {RING(v)}, {vreg(P[v & 3])} offset:{PH0 + 8 * (v >> 2)}")
+    b("v_add_u32_e32 v116, %[db], %[l16]")
+    b("v_cmp_lt_i32_e32 vcc, -1, %[ktp]")
+    b("v_add_u32_e32 v117, %[db], %[ktp]")
+    b("v_mov_b32_e32 v118, s95")
+    for j_ in range(3):
+        b(f"v_mov_b64_e32 {ACC[j_]}, 0")
+    b("v_cndmask_b32_e32 v117, v118, v117, vcc")                   # this lane's tap row
+    b("s_waitcnt vmcnt(0)")
+    b("ds_write_b128 v116, v[120:123]")                            # park the low-edge rows: lane l < 48 holds floats 4l .. 4l+3 of the 8 x 24 block
+    b(f"ds_read_b128 {vreg(CQ[0], 4)}, v117")
     outstanding = 0
     for u in range(NT):
         if (u & 3) == 0 and u + 4 < NT:
