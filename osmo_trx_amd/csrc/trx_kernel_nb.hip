@@ -21,7 +21,8 @@
 #include "trx_k4_common.h"
 #include "trx_nb_asm.inc"
 
-#define NB_D_LEN    128                                           /* decimated window (64 used) / parking space of the low-edge tap rows (1 KB) */
+#define NB_D_LEN    160                                           /* decimated window (64 used) / parking space of the low-edge tap rows (1 KB) / the
+                                                                      156 symbols of the general demodulator (cold) */
 #define NB_CZ_LEN   (TRX_CZ_PAD + TRX_CORR_NARROW + TRX_CZ_PAD)
 #define NB_SLICE    (K4_XS + NB_D_LEN + NB_CZ_LEN)                /* complex samples per wave */
 #define NB_COMP_ROWS (TRX_DELAY_FILTS + 1)
@@ -137,7 +138,7 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 	bool t5_ok = true;
 	for (int t = 0; t < 8; t++) {
 		const int v = (int)(lhdr[8 * t + 5] * 512.0f);
-		t5_ok = t5_ok && v >= -8 && v <= 7;
+		t5_ok = t5_ok && v >= -8 && v <= 7 && (float)v == lhdr[8 * t + 5] * 512.0f;   // (exact: toa = -nk / 512 then is, too)
 		t5pk |= (v & 15) << (4 * t);
 	}
 	t5pk = uni(t5pk);
@@ -205,25 +206,126 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 	if (b_first != NB_NO_BURST)
 		prefetch(b_first, lane0);
 
-	// ---- functions of the lane only, in registers for the whole kernel (the kernel is bound by the LDS: 21 registers instead of
-	// 9 LDS reads per burst): round A's sixteen interpolation weights, the lane constants of the hand-placed blocks; and the
-	// /4 decimator's taps 0..7 in four scalar register pairs
-	v2f wra[8];
-#pragma unroll
-	for (int q = 0; q < 4; q++) {
-		const float4 w = wa4[q * WAVE + lane0];
-		wra[2 * q] = (v2f){ w.x, w.y };
-		wra[2 * q + 1] = (v2f){ w.z, w.w };
-	}
-	const int kr = lcn[0 * WAVE + lane0], ka = lcn[1 * WAVE + lane0], kb = lcn[2 * WAVE + lane0], kic = lcn[3 * WAVE + lane0],
-		  ktp = lcn[4 * WAVE + lane0];
-	const unsigned long long *const gp = reinterpret_cast<const unsigned long long *>(tab->dec_taps);
-	const unsigned long long g01 = gp[0], g23 = gp[1], g45 = gp[2], g67 = gp[3];
 	// ---- deferred output (registers): o = the lane's three sliced soft bits, recw = the result record (lanes 0..7)
 	v3f o = { 0.0f, 0.0f, 0.0f };
 	int recw = 0;
 	bool pend_any = false;
 	unsigned pend_b = 0;
+
+	// ---- cold: demodGmskBurst for a TOA outside the straight-line geometry (shift w = nk >> 7 above 0: an early burst; below -36:
+	// later than 9 symbols).  The general kernel's fused demodulator (trx_kernel4.hip, "FUSED": same sums, same order -- the
+	// results are bit-identical to its) on this kernel's buffers: full outputs from the composite filter, the partial ones at the
+	// low / high edge from the truncated-composite tables or the masked two-stage sum; the 156 symbols go through D[], from
+	// where every lane picks up its three (rotation, slicer: the general kernel's flush()).
+	// Returns false for a geometry whose partial outputs the tables do not cover (the general kernel's masked two-stage sum:
+	// bursts shorter than the window -- cannot happen with 625 samples and |TOA| within the search windows; such a burst is left to
+	// the general kernel).
+	auto demod_general = [&](const int nk, const c32 ampv, const int lane) -> bool {
+		constexpr int L = 625, nwrite = 148;
+		c32 *const dec = D;
+		const trx_tables *tabc = tab;                               // (opaque copy: the table addresses of this cold path are formed here,
+		asm volatile("" : "+s"(tabc));                              //  not kept in scalar registers across the burst loop)
+		const int w = nk >> 7, fr = nk & 127;
+		const int fidx = (fr >= 2) ? (fr >> 1) : TRX_DELAY_FILTS;
+		const float ian = __builtin_amdgcn_rcpf(norm2(ampv));
+		const c32 scale = make_float2(ampv.x * ian, -ampv.y * ian);
+		const int n_lo = w > 0 ? w : 0;
+		const int n_hi = (L - 1 + w < 623) ? L - 1 + w : 623;
+		const int i_full_lo = cdiv4(n_lo + 15), i_full_hi = fdiv4(n_hi);
+		const int i0l = cdiv4(n_lo), i0h = i_full_hi + 1;
+		const bool need_lo = (n_hi >= n_lo) && (i0l < i_full_lo) && (i0l < nwrite);
+		const bool need_hi = (n_hi >= n_lo) && (i0h <= fdiv4(n_hi + 15)) && (i0h < nwrite);
+		const bool lo_tab = need_lo && (n_hi >= 4 * (i_full_lo - 1));
+		float ct0 = 0.0f, ct1 = 0.0f, ct2 = 0.0f;
+		const int le = lane >> 4, lt = lane & 15;
+		const int li = i0l + le;
+		const int lt0 = n_lo + 15 - 4 * li;
+		const bool lact = lt0 >= 1;
+		if (lo_tab) {
+			const float *row = &tabc->edge_lo[fidx][(lact ? lt0 : 1) - 1][lt];
+			ct0 = row[0];
+			ct1 = row[16];
+			ct2 = (lt < 4) ? row[32] : 0.0f;
+		}
+		const bool hi_tab = need_hi && (w <= -2) && (n_lo <= 4 * i0h - 15);
+		if ((need_lo && !lo_tab) || (need_hi && !hi_tab))
+			return false;
+		float ch0 = 0.0f, ch1 = 0.0f, ch2 = 0.0f;
+		const int hi_i = i0h + le;
+		const int htm = n_hi + 15 - 4 * hi_i;
+		const bool hact = htm >= 0;
+		if (hi_tab) {
+			const float *row = &tabc->edge_hi[fidx][hact ? htm : 0][lt];
+			ch0 = row[0];
+			ch1 = row[16];
+			ch2 = (lt < 4) ? row[32] : 0.0f;
+		}
+		{
+			const int c_full = -24 - w;
+			const int i_min = cdiv4(-36 - c_full), i_max = fdiv4(L + 1 - c_full);
+			int ic = 3 * lane;
+			if (ic < i_min) ic = i_min;
+			if (ic > i_max - 2) ic = i_max - 2;
+			// (the filter as a hand-placed block -- fir24x3's sums in its order -- so that the compiler does not have to find
+			// fifty registers for it inside the burst loop)
+			v2f acc[3];
+			asm volatile(NB_ASM_FIRG
+				     : [a0] "=&v"(acc[0]), [a1] "=&v"(acc[1]), [a2] "=&v"(acc[2])
+				     : [nk] "s"(nk), [pb] "s"(lds_addr(P)), [cb] "s"(lds_addr(comp) + 4u * (K4_U0 + TRX_FUSED_SH)), [kic] "v"(8 * ic)
+				     : NB_ASM_CLOBBERS);
+			if (n_lo == 0 && lo_tab && i_full_hi >= nwrite - 1) {
+				if (lane < 52) {
+#pragma unroll
+					for (int j = 0; j < 3; j++)
+						dec[3 * lane + j] = cmul(make_float2(acc[j].x, acc[j].y), scale);
+				}
+			} else {
+#pragma unroll
+				for (int j = 0; j < 3; j++) {
+					const int i = 3 * lane + j;
+					const bool full = (i >= i_full_lo) && (i <= i_full_hi);
+					const c32 d = full ? cmul(make_float2(acc[j].x, acc[j].y), scale) : make_float2(0.0f, 0.0f);
+					if (i < 156)
+						dec[i] = d;
+				}
+			}
+		}
+		if (lo_tab) {
+			const int s0 = 4 * li - 24 - w + lt;
+			const c32 *pp = P + ((s0 & 3) * PH_A + PH_M0 + (s0 >> 2));
+			const c32 x0 = lds_c32(pp), x1 = lds_c32(pp + 4), x2 = lds_c32(pp + 8);
+			float ar = x0.x * ct0, ai = x0.y * ct0;
+			ar = fmaf(x1.x, ct1, ar); ai = fmaf(x1.y, ct1, ai);
+			ar = fmaf(x2.x, ct2, ar); ai = fmaf(x2.y, ct2, ai);
+			const float sr = row_sum(ar), si = row_sum(ai);
+			if (lt == 0 && lact)
+				dec[li] = cmul(make_float2(sr, si), scale);
+		}
+		if (hi_tab) {
+			const int s0 = 4 * hi_i - 24 - w + lt;
+			const c32 *pp = P + ((s0 & 3) * PH_A + PH_M0 + (s0 >> 2));
+			const c32 x0 = lds_c32(pp), x1 = lds_c32(pp + 4), x2 = lds_c32(pp + 8);
+			float ar = x0.x * ch0, ai = x0.y * ch0;
+			ar = fmaf(x1.x, ch1, ar); ai = fmaf(x1.y, ch1, ai);
+			ar = fmaf(x2.x, ch2, ar); ai = fmaf(x2.y, ch2, ai);
+			const float sr = row_sum(ar), si = row_sum(ai);
+			if (lt == 0 && hact && hi_i < 156)
+				dec[hi_i] = cmul(make_float2(sr, si), scale);
+		}
+		wave_sync();
+		// this kernel's lanes: 0..47 symbols 4 + 3 lane + j, 52..55 symbol (-lane) & 3; real((-j)^i x) and the slicer as the general
+		// kernel's flush() has them (component i & 1, sign by i & 2)
+		auto pick = [&](int i) {
+			const float d = reinterpret_cast<const float *>(dec + i)[i & 1];
+			return __builtin_amdgcn_fmed3f(fmaf((i & 2) ? -0.5f : 0.5f, d, 0.5f), 0.0f, 1.0f);
+		};
+		const int i0 = (lane < 48) ? 4 + 3 * lane : ((-lane) & 3);
+		o.x = pick(i0);
+		o.y = pick(lane < 48 ? i0 + 1 : 0);
+		o.z = pick(lane < 48 ? i0 + 2 : 0);
+		wave_sync();
+		return true;
+	};
 
 	DIAG_DECL;
 	WI_LOCAL;
@@ -291,8 +393,7 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 			unsigned long long bad;
 			asm volatile(NB_ASM_DEC
 				     : [bad] "=s"(bad)
-				     : [pd] "v"(lds_addr(P + PH_M0 + 52) + 8u * (unsigned)lane), [vd] "v"(vd_addr), [nact] "s"(15 + len),
-				       [g01] "s"(g01), [g23] "s"(g23), [g45] "s"(g45), [g67] "s"(g67)
+				     : [pd] "v"(lds_addr(P + PH_M0 + 52) + 8u * (unsigned)lane), [vd] "v"(vd_addr), [zero] "v"(0), [nact] "s"(15 + len)
 				     : NB_ASM_CLOBBERS);
 			{
 				// ---- correlation (lane = lag; the twelve lanes behind the window store the right zero pad), arg-max and the
@@ -303,9 +404,15 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 					     : [vd] "v"(vd_addr), [vcz] "v"(vcz_addr), [len] "s"(len), [tsc] "s"(tsc), [bad] "s"(bad)
 					     : NB_ASM_CLOBBERS);
 				int m_bits, es_bits, bidx;
-				asm volatile(NB_ASM_AMAX("s_nop 0", "s_nop 0", "s_nop 0", "s_nop 0", "s_nop 0", "s_nop 0", "s_nop 0", "s_nop 0")
-					     : [m] "=s"(m_bits), [es] "=s"(es_bits), [bidx] "=s"(bidx)
-					     : [nrm] "v"(v), [ep] "v"(epart)
+				int kr, ka, kb, kic, ktp;                                   // lane constants (lcn[])
+				asm volatile(NB_ASM_AMAX("ds_read_b32 %[kr], %[l4] offset:%c[lc]", "ds_read_b32 %[ka], %[l4] offset:%c[lc]+256",
+							 "ds_read_b32 %[kb], %[l4] offset:%c[lc]+512", "ds_read_b32 %[kic], %[l4] offset:%c[lc]+768",
+							 "ds_read_b32 %[ktp], %[l4] offset:%c[lc]+1024", "s_nop 0", "s_nop 0", "s_nop 0")
+					     "s_waitcnt lgkmcnt(0)"
+					     : [m] "=s"(m_bits), [es] "=s"(es_bits), [bidx] "=s"(bidx), [kr] "=&v"(kr), [ka] "=&v"(ka), [kb] "=&v"(kb),
+					       [kic] "=&v"(kic), [ktp] "=&v"(ktp)
+					     : [nrm] "v"(v), [ep] "v"(epart), [l4] "v"(4 * lane),
+					       [lc] "n"((TRX_SINCV_LDS + 16 * WAVE + NB_COMP_ROWS * 36 + 16 + 64 + 5 * WAVE) * 4)
 					     : NB_ASM_CLOBBERS);
 				int hit = 0;
 				int toa512 = 0;
@@ -315,10 +422,8 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 					float km;
 					asm volatile(NB_ASM_DETA
 						     : [st] "=&s"(st), [e] "=&s"(e512), [km] "=&v"(km)
-						     : [bidx] "s"(bidx), [len] "s"(len), [czb] "s"(lds_addr(cz)), [kr] "v"(kr), [ka] "v"(ka),
-						       [w0] "v"(wra[0]), [w1] "v"(wra[1]), [w2] "v"(wra[2]), [w3] "v"(wra[3]), [w4] "v"(wra[4]), [w5] "v"(wra[5]),
-						       [w6] "v"(wra[6]), [w7] "v"(wra[7]),
-						       [k5] "s"(gk5), [k6] "s"(gk6), [k7] "s"(gk7), [k8] "s"(gk8), [c0] "v"(gc0), [nodes] "s"(0x1555555555555555ull)
+						     : [bidx] "s"(bidx), [len] "s"(len), [czb] "s"(lds_addr(cz)), [kr] "v"(kr), [ka] "v"(ka), [l16] "v"(16 * lane),
+						       [k5] "s"(gk5), [k6] "s"(gk6), [k7] "s"(gk7), [k8] "s"(gk8), [c0] "v"(gc0)
 						     : NB_ASM_CLOBBERS);
 					int xr_bits = 0, xi_bits = 0;
 					if (st == 1) {
@@ -356,13 +461,17 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 							     : [ok] "=&s"(ok), [rec] "=&v"(recw), [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2)
 							     : [toa] "s"(toa512), [xr] "s"(xr_bits), [xi] "s"(xi_bits), [t5] "s"(t5), [hdrb] "s"(lds_addr(lhdr) + 32u * (unsigned)tsc),
 							       [e8lo] "s"((unsigned)e8_addr), [e8hi] "s"((unsigned)(e8_addr >> 32)), [es] "s"(es_bits), [fsdb] "s"(unif(fs_db)),
-							       [flags] "s"(flags), [modd] "s"(0xaaaaaaaaaaaaaaaaull), [m23] "s"(0xccccccccccccccccull), [l16] "v"(16 * lane),
+							       [flags] "s"(flags), [l16] "v"(16 * lane),
 							       [vd] "v"(vd_addr), [pb] "s"(lds_addr(P)), [cb] "s"(lds_addr(comp) + 4u * (K4_U0 + TRX_FUSED_SH)), [db] "s"(lds_addr(D)),
 							       [kic] "v"(kic), [ktp] "v"(ktp)
 							     : NB_ASM_CLOBBERS);
 						if (!ok) {
-							leave = true;                                      // TOA outside the straight-line geometry
+							// TOA outside the straight-line geometry (an early burst, or one later than 9 symbols): the general form
 							if (lane == 0) atomicAdd(&g_trx_fast_stats[3], 1ull);
+							const c32 ampv = make_float2(__int_as_float(__builtin_amdgcn_readlane(recw, 2)),
+										     __int_as_float(__builtin_amdgcn_readlane(recw, 3)));
+							if (!demod_general(t5 + 10 * 512 - toa512, ampv, lane))
+								leave = true;
 						} else {
 							o.x = __builtin_amdgcn_fmed3f(fmaf(0.5f, d0, 0.5f), 0.0f, 1.0f);     // vectorSlicer: 0.5 * (x + 1), clamped (:546-556)
 							o.y = __builtin_amdgcn_fmed3f(fmaf(0.5f, d1, 0.5f), 0.0f, 1.0f);
@@ -418,7 +527,9 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 	}
 	if (pooled) {
 		__syncthreads();
-		if (threadIdx.x == 0) {
+		int tid0;                                                   // (re-derived: not a mask kept in scalar registers since the prologue)
+		asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(tid0));
+		if (tid0 == 0 && wave == 0) {
 			const unsigned d = __hip_atomic_fetch_add(pool_ctr + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
 			if (d == gridDim.x - 1u) {
 				__hip_atomic_store(pool_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

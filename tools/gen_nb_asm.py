@@ -234,19 +234,21 @@ def sreg(i, n=1):
 # only (bitwise symmetric filter).  The sixteen samples arrive in order: four waits, each covering the next four.
 # ------------------------------------------------------------------------------------------------------------------
 def block_dec(gdec_off):
-    b = Block("DEC", ("nact", "bad", "g01", "g23", "g45", "g67"))
+    b = Block("DEC", ("nact", "bad"))
     X = lambda k: vreg(88 + 2 * k, 2)
+    GA, GB = 120, 124
     b(f"s_bfm_b64 exec, %[nact], 0")
+    b(f"ds_read_b128 {vreg(GA, 4)}, %[zero] offset:{gdec_off}")
+    b(f"ds_read_b128 {vreg(GB, 4)}, %[zero] offset:{gdec_off + 16}")
     for k in range(16):
         off = (((k + 1) & 3) * PH_A + ((k + 1) >> 2)) * 8
         b(f"ds_read_b64 {X(k)}, %[pd] offset:{off}")
 
     def mul(k):
-        # taps g[0..7] (the filter is bitwise symmetric) live in four scalar register pairs for the whole kernel
         kk = k if k < 8 else 15 - k
-        pair = ("%[g01]", "%[g23]", "%[g45]", "%[g67]")[kk >> 1]
+        base = (GB if (kk >> 2) else GA) + (2 if (kk & 2) else 0)
         sel = "op_sel:[0,1] op_sel_hi:[1,1]" if (kk & 1) else "op_sel:[0,0] op_sel_hi:[1,0]"
-        b(f"v_pk_mul_f32 {X(k)}, {X(k)}, {pair} {sel}")
+        b(f"v_pk_mul_f32 {X(k)}, {X(k)}, {vreg(base, 2)} {sel}")
 
     def add(k):            # y (in X(0)) += product k
         b(f"v_pk_add_f32 {X(0)}, {X(0)}, {X(k)}")
@@ -467,8 +469,7 @@ def careful_walk(b, c, cd, p, pos, levels, unsure_label, w="b64"):
 # on an estimate with a proven margin, round A of peakDetect()'s bisection (levels 0..4, trx_device.h peak_detect_fast) and
 # its certified tree walk.
 #   in : %[bidx] %[len] %[czb] SGPR (czb = LDS byte address of cz[0]); %[kr] %[ka] VGPR lane constants (byte offsets of the
-#        lane's peak-ratio term and of round A's first tap, relative to &cz[bidx]); %[w0]..%[w7] VGPR pairs: the lane's sixteen
-#        round-A weights, taps fl-7 .. fl+8; %[k5]..%[k8] SGPR
+#        lane's peak-ratio term and of round A's first tap, relative to &cz[bidx]); %[l16] VGPR 16 * lane; %[k5]..%[k8] SGPR
 #        thresh^2 / n; %[c0] VGPR thresh^2 * 1.0001e-5; %[nodes] SGPR pair 0x1555555555555555
 #   out: %[st] SGPR 0 miss / 1 found / 2 gate too close to call / 3 an uncertified decision on the path; %[e] SGPR earlyIndex
 #        * 512 after round A; %[km] VGPR KAPPA * |corr[bidx]|^2 (round B's margin term)
@@ -478,7 +479,7 @@ def careful_walk(b, c, cd, p, pos, levels, unsure_label, w="b64"):
 # a certain pass; in between (one burst in ~5e4) the burst is left to the general kernel, which rounds as the reference does.
 # ------------------------------------------------------------------------------------------------------------------
 def block_deta(wa4_off):
-    b = Block("DETA", ("bidx", "len", "czb", "k5", "k6", "k7", "k8", "nodes", "st", "e"))
+    b = Block("DETA", ("bidx", "len", "czb", "k5", "k6", "k7", "k8", "st", "e"))
     X = lambda k: vreg(88 + 2 * k, 2)            # round A samples 0..7
     Y = lambda k: vreg(112 + 2 * k, 2)           # samples 8..15
     b("s_mov_b32 %[st], 0")
@@ -502,6 +503,8 @@ def block_deta(wa4_off):
     b("s_mov_b64 exec, 1")
     b("ds_write_b64 v67, v[72:73]")                                # interpolatePoint() never reads the last correlation sample (:1105)
     b("s_mov_b64 exec, -1")
+    b(f"ds_read_b128 v[76:79], %[l16] offset:{wa4_off}")
+    b(f"ds_read_b128 v[80:83], %[l16] offset:{wa4_off + 1024}")
     for u in range(8):
         b(f"ds_read_b64 {X(u)}, v66 offset:{8 * u}")
     b("v_mov_b64_e32 v[84:85], 0")                                 # p0, p1 of the two-chain sums
@@ -512,7 +515,7 @@ def block_deta(wa4_off):
           "s_cmp_eq_u32 s91, 6", "s_cselect_b32 s93, %[k6], %[k5]", "s_cmp_ge_u32 s91, 7", "s_cselect_b32 s92, s92, s93"]
     for t in sc[:3]:
         b(t)
-    b("s_waitcnt lgkmcnt(9)")
+    b("s_waitcnt lgkmcnt(11)")
     b("v_pk_mul_f32 v[68:69], v[68:69], v[68:69]")
     b(sc[3])
     b("v_add_f32_e32 v74, v69, v68")                               # m = |corr[bidx]|^2
@@ -542,19 +545,21 @@ def block_deta(wa4_off):
     b("s_cbranch_vccz .Lnb_da_wait_end")                           # too close to call
     b("s_mov_b64 exec, -1")
     # ---- round A: interp over taps fl-7 .. fl+8 with this lane's weights, two FMA chains (even / odd taps)
+    b(f"ds_read_b128 v[104:107], %[l16] offset:{wa4_off + 2048}")
+    b(f"ds_read_b128 v[108:111], %[l16] offset:{wa4_off + 3072}")
     for u in range(8):
         b(f"ds_read_b64 {Y(u)}, v66 offset:{8 * (8 + u)}")
-    b("s_waitcnt lgkmcnt(8)")
+    b("s_waitcnt lgkmcnt(10)")
 
-    def fmas(xs, h):
-        # this lane's sixteen weights (functions of the lane only) live in eight register pairs for the whole kernel
+    def fmas(xs, qa, qb):
         for u in range(0, 8, 2):
-            hp = f"%[w{4 * h + (u >> 1)}]"
+            q = qb if (u & 4) else qa
+            hp = vreg(q + (2 if (u & 2) else 0), 2)
             b(f"v_pk_fma_f32 v[84:85], {xs(u)}, {hp}, v[84:85] op_sel:[0,0,0] op_sel_hi:[1,0,1]")
             b(f"v_pk_fma_f32 v[86:87], {xs(u + 1)}, {hp}, v[86:87] op_sel:[0,1,0] op_sel_hi:[1,1,1]")
-    fmas(X, 0)
+    fmas(X, 76, 80)
     b("s_waitcnt lgkmcnt(0)")
-    fmas(Y, 1)
+    fmas(Y, 104, 108)
     b("s_nop 0")
     b("v_pk_add_f32 v[84:85], v[84:85], v[86:87]")
     b("s_nop 0")
@@ -571,8 +576,10 @@ def block_deta(wa4_off):
     b("s_mov_b32 %[st], 1")
     b("s_lshr_b64 s[90:91], s[88:89], 1")
     b("s_or_b64 s[90:91], s[90:91], s[88:89]")
-    b("s_and_b64 s[92:93], s[90:91], %[nodes]")
-    b("s_cmp_eq_u64 s[92:93], %[nodes]")
+    b("s_mov_b32 s96, 0x55555555")
+    b("s_mov_b32 s97, 0x15555555")
+    b("s_and_b64 s[92:93], s[90:91], s[96:97]")
+    b("s_cmp_eq_u64 s[92:93], s[96:97]")
     b("s_cbranch_scc0 .Lnb_da_careful")
     fast_walk(b, "s[88:89]", "s95", "s96", 5)
     b(".Lnb_da_walked:")
@@ -687,16 +694,12 @@ def block_detb():
 #   out: SGPR ok (0: TOA outside the straight-line geometry), nk; VGPR rows (4 registers), vp, rec
 # ------------------------------------------------------------------------------------------------------------------
 def block_tail():
-    b = Block("TAIL", ("toa", "xr", "xi", "t5", "hdrb", "e8lo", "e8hi", "es", "fsdb", "flags", "modd", "m23", "ok", "nk", "pb", "cb", "db"))
+    b = Block("TAIL", ("toa", "xr", "xi", "t5", "hdrb", "e8lo", "e8hi", "es", "fsdb", "flags", "ok", "nk", "pb", "cb", "db"))
     b("v_mov_b32_e32 v65, %[hdrb]")
     b("ds_read_b128 v[68:71], v65")                                # gain, 1 / gain
     b("s_sub_u32 s88, %[t5], %[toa]")
     b("s_add_u32 s87, s88, 5120")                                  # nk = -(toa512 - t5 - 10 * 512)
-    b("s_ashr_i32 s89, s87, 7")                                    # w = nk >> 7, must be -36 .. 0
-    b("s_sub_u32 s90, 0, s89")
     b("s_mov_b32 %[ok], 0")
-    b("s_cmp_gt_u32 s90, 36")
-    b("s_cbranch_scc1 .Lnb_tl_wait_end")
     b("s_and_b32 s91, s87, 127")
     b("s_lshr_b32 s92, s91, 1")
     b("s_cmp_ge_u32 s91, 2")
@@ -712,7 +715,6 @@ def block_tail():
     b("s_cmp_lt_i32 %[toa], 0")
     b("s_cselect_b32 s96, s97, s96")
     b("s_lshl_b32 s96, s96, 3")
-    b("s_mov_b32 %[ok], 1")
     b("v_add_u32_e32 v64, s96, %[vd]")                             # &D[rt + lane]: sample ps + lane, ps = start + 1 - N + rt
     b("s_waitcnt lgkmcnt(0)")
     # ---- every lane: amp = peak / gain (:1701), 1 / amp, the output stage's multiplier VP
@@ -732,11 +734,14 @@ def block_tail():
     b("ds_read_b64 v[66:67], v64")
     b("ds_read_b128 v[72:75], v65 offset:16")                      # ci_den, toa, n, 1 / ci_den
     b("s_mov_b64 exec, -1")
+    b("s_mov_b32 s88, 0xaaaaaaaa")
+    b("s_mov_b32 s89, 0xaaaaaaaa")
     b("v_mul_f32_e32 v91, v86, v89")                               # 1 / amp = conj(amp) / |amp|^2 (Complex.h:75,144-150)
     b("v_mul_f32_e64 v92, -v87, v89")
-    b("v_cndmask_b32_e64 v119, v91, v92, %[modd]")                # VP[lane & 3] = sx, sy, -sx, -sy
-    b("s_nop 0")
-    b("v_cndmask_b32_e64 v119, v119, -v119, %[m23]")
+    b("v_cndmask_b32_e64 v119, v91, v92, s[88:89]")               # VP[lane & 3] = sx, sy, -sx, -sy (odd lanes: sy)
+    b("s_mov_b32 s88, 0xcccccccc")
+    b("s_mov_b32 s89, 0xcccccccc")
+    b("v_cndmask_b32_e64 v119, v119, -v119, s[88:89]")            # (lanes 2, 3 mod 4: negated)
     b("s_bfm_b64 exec, 16, 0")
     b("v_mul_f32_e64 v76, %[xi], %[xi]")
     b("v_mul_f32_e64 v77, %[xr], %[xr]")
@@ -784,7 +789,7 @@ def block_tail():
     block_demod(b)
     b("s_branch .Lnb_tl_end")
     b(".Lnb_tl_wait_end:")
-    b("s_waitcnt lgkmcnt(0)")
+    b("s_waitcnt vmcnt(0)")                                        # (the tap rows were requested: their registers are free again behind this)
     b(".Lnb_tl_end:")
     return b
 
@@ -801,6 +806,13 @@ def block_tail():
 #   out: VGPR d0 d1 d2: real((-j)^i z / amp) of the lane's three symbols (the slicer's input)
 # ------------------------------------------------------------------------------------------------------------------
 def block_demod(b):
+    # the straight-line geometry: shift w = nk >> 7 in -36 .. 0 (0 <= TOA <= 9 symbols); other bursts leave with ok = 0 -- record
+    # and 1 / amp are done -- and take the general form of the demodulator (trx_kernel_nb.hip, cold)
+    b("s_ashr_i32 s88, s87, 7")
+    b("s_sub_u32 s90, 0, s88")
+    b("s_cmp_gt_u32 s90, 36")
+    b("s_cbranch_scc1 .Lnb_tl_wait_end")
+    b("s_mov_b32 %[ok], 1")
     ACC = [vreg(64 + 2 * j, 2) for j in range(3)]
     RING = lambda v: vreg(72 + 2 * (v & 15), 2)
     CQ = [104, 108]
@@ -841,8 +853,71 @@ def block_demod(b):
     b("v_cndmask_b32_e32 v117, v118, v117, vcc")                   # this lane's tap row
     b("s_waitcnt vmcnt(0)")
     b("ds_write_b128 v116, v[120:123]")                            # park the low-edge rows: lane l < 48 holds floats 4l .. 4l+3 of the 8 x 24 block
+    fir_core(b, ACC, RING, CQ, P, preload=False)
+    # output stage: low-edge symbols = main part (lane 52 + c) + taps u < 8 (lane 56 + c); symbol i wants real((-j)^i z / amp) =
+    # z.x * VP[k] + z.y * VP[k - 1], k = i & 3 = (j - lane) & 3: a quad permutation of VP, applied by the DPP operand
+    b("s_nop 0")
+    b("v_add_f32_dpp v64, v64, v64 row_shl:4 row_mask:0x8 bank_mask:0xf")
+    b("v_add_f32_dpp v65, v65, v65 row_shl:4 row_mask:0x8 bank_mask:0xf")
+    b(f"v_mul_f32_dpp %[d1], v119, v66 quad_perm:[1,0,3,2] {D_ALL}")
+    b(f"v_mul_f32_dpp %[d2], v119, v68 quad_perm:[2,1,0,3] {D_ALL}")
+    b(f"v_mul_f32_dpp %[d0], v119, v64 quad_perm:[0,3,2,1] {D_ALL}")
+    b(f"v_fmac_f32_dpp %[d1], v119, v67 quad_perm:[0,3,2,1] {D_ALL}")
+    b(f"v_fmac_f32_dpp %[d2], v119, v69 quad_perm:[1,0,3,2] {D_ALL}")
+    b(f"v_fmac_f32_dpp %[d0], v119, v65 quad_perm:[3,2,1,0] {D_ALL}")
+    b("s_mov_b64 exec, -1")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# block FIRG: the composite filter alone, for the general form of the demodulator (cold: trx_kernel_nb.hip demod_general) --
+# lane l < 52 computes the raw sums of symbols ic .. ic + 2 over taps U0 .. U0 + 23 of the burst's composite row.
+#   in : SGPR %[nk], %[pb], %[cb] (as DEMOD); VGPR %[kic] 8 * ic of this lane (clamped by the caller)
+#   out: VGPR pairs %[a0] %[a1] %[a2]
+# ------------------------------------------------------------------------------------------------------------------
+def block_firg():
+    b = Block("FIRG", ("nk", "pb", "cb"))
+    ACC = ["%[a0]", "%[a1]", "%[a2]"]
+    RING = lambda v: vreg(72 + 2 * (v & 15), 2)
+    CQ = [104, 108]
+    P = [112, 113, 114, 115]
+    b("s_ashr_i32 s88, %[nk], 7")                                  # w
+    b("s_and_b32 s89, %[nk], 127")
+    b("s_lshr_b32 s90, s89, 1")
+    b("s_cmp_ge_u32 s89, 2")
+    b("s_cselect_b32 s90, s90, 64")                                # fidx
+    b("s_sub_u32 s91, -18, s88")                                   # c = -24 - w + U0
+    b("s_and_b32 s92, s91, 3")
+    b("s_ashr_i32 s93, s91, 2")
+    b("s_mul_i32 s94, s92, 180")
+    b("s_add_u32 s94, s94, s93")
+    b("s_lshl3_add_u32 s94, s94, %[pb]")
+    b("s_mul_i32 s95, s90, 144")
+    b("s_add_u32 s95, s95, %[cb]")
+    b(f"v_add_u32_e32 {vreg(P[0])}, s94, %[kic]")
+    for k in range(1, 4):
+        b(f"s_add_u32 s96, s92, {k}")
+        b("s_lshr_b32 s96, s96, 2")
+        b(f"s_mul_i32 s96, s96, {(1 - 4 * PH_A) * 8}")
+        b(f"s_add_u32 s96, s96, {k * PH_A * 8}")
+        b(f"v_add_u32_e32 {vreg(P[k])}, s96, {vreg(P[0])}")
+    for j_ in range(3):
+        b(f"v_mov_b64_e32 {ACC[j_]}, 0")
+    b("v_mov_b32_e32 v117, s95")
+    b("s_bfm_b64 exec, 52, 0")
+    fir_core(b, ACC, RING, CQ, P, preload=True)
+    b("s_mov_b64 exec, -1")
+    return b
+
+
+def fir_core(b, ACC, RING, CQ, P, preload):
+    """fir24x3 (trx_k4_common.h): taps outer, a ring of sixteen samples running four ahead, taps four at a time; v117 = the lane's
+    tap row.  preload: the first twelve samples are requested here (DEMOD requests them earlier)"""
+    D, NT, NV = 4, 24, 32
+    PH0 = 96                                                       # byte offset of PH_M0 entries
+    if preload:
+        for v in range(8 + D):
+            b(f"ds_read_b64 {RING(v)}, {vreg(P[v & 3])} offset:{PH0 + 8 * (v >> 2)}")
     b(f"ds_read_b128 {vreg(CQ[0], 4)}, v117")
-    outstanding = 0
     for u in range(NT):
         if (u & 3) == 0 and u + 4 < NT:
             b(f"ds_read_b128 {vreg(CQ[((u >> 2) + 1) & 1], 4)}, v117 offset:{16 * ((u >> 2) + 1)}")
@@ -860,18 +935,6 @@ def block_demod(b):
         sel = "op_sel:[0,1,0] op_sel_hi:[1,1,1]" if (u & 1) else "op_sel:[0,0,0] op_sel_hi:[1,0,1]"
         for j in range(3):
             b(f"v_pk_fma_f32 {ACC[j]}, {RING(u + 4 * j)}, {hp}, {ACC[j]} {sel}")
-    # output stage: low-edge symbols = main part (lane 52 + c) + taps u < 8 (lane 56 + c); symbol i wants real((-j)^i z / amp) =
-    # z.x * VP[k] + z.y * VP[k - 1], k = i & 3 = (j - lane) & 3: a quad permutation of VP, applied by the DPP operand
-    b("s_nop 0")
-    b("v_add_f32_dpp v64, v64, v64 row_shl:4 row_mask:0x8 bank_mask:0xf")
-    b("v_add_f32_dpp v65, v65, v65 row_shl:4 row_mask:0x8 bank_mask:0xf")
-    b(f"v_mul_f32_dpp %[d1], v119, v66 quad_perm:[1,0,3,2] {D_ALL}")
-    b(f"v_mul_f32_dpp %[d2], v119, v68 quad_perm:[2,1,0,3] {D_ALL}")
-    b(f"v_mul_f32_dpp %[d0], v119, v64 quad_perm:[0,3,2,1] {D_ALL}")
-    b(f"v_fmac_f32_dpp %[d1], v119, v67 quad_perm:[0,3,2,1] {D_ALL}")
-    b(f"v_fmac_f32_dpp %[d2], v119, v69 quad_perm:[1,0,3,2] {D_ALL}")
-    b(f"v_fmac_f32_dpp %[d0], v119, v65 quad_perm:[3,2,1,0] {D_ALL}")
-    b("s_mov_b64 exec, -1")
 
 
 def c_string(lines):
@@ -895,8 +958,9 @@ def main():
     blocks["DETA"] = block_deta(wa4_off)
     blocks["DETB"] = block_detb()
     blocks["TAIL"] = block_tail()
+    blocks["FIRG"] = block_firg()
     errs = blocks["DEC"].check() + check_variants(blocks["CORR"]) + check_paths(blocks["DETA"]) + check_paths(blocks["DETB"]) + \
-        check_paths(blocks["TAIL"])
+        check_paths(blocks["TAIL"]) + check_paths(blocks["FIRG"])
     hdr = ["// trx_nb_asm.inc -- GENERATED by tools/gen_nb_asm.py (hazards and LDS waits checked there); do not edit.",
            f"#define NB_ASM_GDEC_OFF {gdec_off}",
            f"#define NB_ASM_LSEQ_OFF {lseq_off}",
