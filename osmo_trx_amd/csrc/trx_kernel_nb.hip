@@ -198,7 +198,7 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 #pragma unroll
 		for (int r = 0; r < NLD; r++) {
 			const int i = r * WAVE + lane;
-			pre_i[r] = (r < NLD - 1 || i < 625) ? src[i] : 0u;
+			pre_i[r] = (r < NLD - 1 || i < 625) ? __builtin_nontemporal_load(src + i) : 0u;   // read once: streaming
 		}
 	};
 	// items j < 16 * my_groups of the static range exist for every workgroup of a launch the launcher sizes (>= 1 group each)
