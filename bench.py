@@ -146,7 +146,7 @@ def side_legs(args, trx, synth, shard, step, iq, n, dev, rank, world, results, s
         step_mixed()
     torch.cuda.synchronize()
     shard.barrier()
-    mixed_s = shard.max_over_ranks(time.perf_counter() - t0m, dev if world > 1 else None)
+    mixed_s = shard.max_over_ranks(time.perf_counter() - t0m, dev if shard.backend_name() else None)
     mixed_detected = int((trx.results_to_numpy(results)["rc"] > 0).sum())
 
     # side measurement (not `value`): host-fed, PCIe-inclusive.  Bursts sit in pinned host memory (where a producer such
@@ -253,7 +253,7 @@ def timed_passes(fn, shard, dev, world, passes=5):
         b.record()
     torch.cuda.synchronize()
     shard.barrier()
-    wall = shard.max_over_ranks(time.perf_counter() - t0, dev if world > 1 else None)
+    wall = shard.max_over_ranks(time.perf_counter() - t0, dev if shard.backend_name() else None)
     return wall, sum(a.elapsed_time(b) for a, b in ev) / passes
 
 
@@ -275,8 +275,9 @@ def config_legs(args, trx, synth, shard, n, dev, rank, world):
 
     def pull_leg(key, workload, iq, params, burst_len, sps=4):
         dp = trx.params_tensor(params)
+        # (host_params: the caller's copy of the slot types -> the TRXHIP_FLAG_FEW_NB_SLOTS hint, as the host pipe gives it)
         wall, ms = timed_passes(lambda: trx.detect_demod(iq, dp, sps=sps, soft_stride=148, slice_bits=True, results=results,
-                                                         soft=soft), shard, dev, world)
+                                                         soft=soft, host_params=params), shard, dev, world)
         det = int((trx.results_to_numpy(results)["rc"] > 0).sum())
         out[key] = {"workload": workload, "mbursts_per_s_all_gpus": round(5 * n * world / wall / 1e6, 2),
                     "kernel_ms": round(ms, 4), "detected_fraction": round(det / n, 4),
@@ -372,7 +373,7 @@ def strong_leg(trx, synth, shard, dev, rank, world, out):
         soft_s = torch.empty((m, 148), dtype=torch.float32, device=dev)
         wall, ms = timed_passes(lambda: trx.detect_demod(iq, dp, sps=4, soft_stride=148, slice_bits=True, results=res_s,
                                                          soft=soft_s), shard, dev, world, passes=3)
-        det = shard.sum_over_ranks(int((trx.results_to_numpy(res_s)["rc"] > 0).sum()), dev if world > 1 else None)
+        det = shard.sum_over_ranks(int((trx.results_to_numpy(res_s)["rc"] > 0).sum()), dev if shard.backend_name() else None)
         out["configs[4]_strong"] = {
             "workload": f"BASELINE.json configs[4]: ONE fixed batch of {total} mixed bursts (7:1 NB:RACH), contiguous shard "
                         f"[N*r/G, N*(r+1)/G) per rank with the edges rounded down to {8 * chunk} bursts, no data-path collective",
@@ -473,7 +474,7 @@ def main():
     torch.cuda.set_device(local_rank)
 
     # tables: generated on rank 0, RCCL-broadcast, checksum-verified, adopted on every rank
-    blob = shard.broadcast_tables(dev if world > 1 else None)
+    blob = shard.broadcast_tables(dev if shard.backend_name() else None)
     trx = TrxHip(local_rank, tables_blob=blob)
 
     n = args.bursts
@@ -506,9 +507,9 @@ def main():
     shard.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    elapsed = shard.max_over_ranks(elapsed, dev if world > 1 else None)
+    elapsed = shard.max_over_ranks(elapsed, dev if shard.backend_name() else None)
     kernel_ms = ev_a.elapsed_time(ev_b) / max(1, args.steps)
-    kernel_ms = shard.max_over_ranks(kernel_ms, dev if world > 1 else None)
+    kernel_ms = shard.max_over_ranks(kernel_ms, dev if shard.backend_name() else None)
 
     # sustained leg (not `value`): >= --sustain-seconds of back-to-back launches of the same step, queued without a host
     # synchronisation in between, so that the 20-step timed region can be read against a second of continuous load
@@ -534,7 +535,7 @@ def main():
         if watcher:
             watcher.join(timeout=5.0)
         shard.barrier()
-        t_sus = shard.max_over_ranks(t_sus, dev if world > 1 else None)
+        t_sus = shard.max_over_ranks(t_sus, dev if shard.backend_name() else None)
         sustained = {"seconds": round(t_sus, 3), "launches": k_sus, "mbursts_per_s_all_gpus": round(n * world * k_sus / t_sus / 1e6, 3),
                      "ms_per_step": round(t_sus / k_sus * 1e3, 4), "sclk_mhz_under_load": clock.get("sclk_mhz"),
                      "note": "back-to-back launches behind the timed region, no host synchronisation in between; never `value`"}
@@ -542,7 +543,7 @@ def main():
     # who ran: every rank's device, gathered over the same backend the tables were broadcast on
     props = torch.cuda.get_device_properties(local_rank)
     me = f"rank {rank}: cuda:{local_rank} {props.name} {getattr(props, 'gcnArchName', '')} pci {getattr(props, 'pci_bus_id', '?')}"
-    devices = shard.gather_strings(me, dev if world > 1 else None)
+    devices = shard.gather_strings(me, dev if shard.backend_name() else None)
     backend = shard.backend_name()
 
     r = trx.results_to_numpy(results)
@@ -566,20 +567,20 @@ def main():
         total_bursts = n * world * args.steps
         value = total_bursts / elapsed / 1e6
         achieved = BYTES_PER_BURST * n / (kernel_ms * 1e-3) / 1e9
-        traffic = traffic_source = compute = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                j = json.load(open(pmc))
-                traffic = j["hbm_bytes_per_burst"] * n
-                traffic_source = ("recorded PMC profile, not this run: profiles/pmc_traffic.json (" + str(j.get("tag", "?")) +
-                                  ": FETCH_SIZE x2 + WRITE_SIZE per burst, separate --pmc passes) x bursts_per_launch")
-                if "compute" in j:
-                    # what actually bounds the kernel: the vector ALU's issue rate (SQ counters of the same recorded profile)
-                    compute = dict(j["compute"], bound="valu-issue",
-                                   source="recorded SQ counter passes, not this run: profiles/" + str(j.get("tag", "?")) + "_sq_counters.json")
-            except Exception:
-                traffic = traffic_source = compute = None
+        # PMC counters are a recorded profile (separate --pmc passes cannot run inside this command): replayed only while the hot
+        # kernels' sources still hash to what the profile was measured on (osmo_trx_amd/srchash.py), else null with the reason
+        from osmo_trx_amd.srchash import replay_counters
+        traffic = compute = None
+        j, traffic_source = replay_counters(os.path.join(ROOT, "profiles", "pmc_traffic.json"))
+        if j is not None:
+            traffic = j["hbm_bytes_per_burst"] * n
+            traffic_source = ("recorded PMC profile, not this run: profiles/pmc_traffic.json (" + str(j.get("tag", "?")) + ", kernel sources " +
+                              str(j.get("source_hash")) + " = the working tree: FETCH_SIZE x2 + WRITE_SIZE per burst, separate --pmc passes) "
+                              "x bursts_per_launch")
+            if "compute" in j:
+                # what loads the kernel in practice: vector ALU and LDS (SQ counters of the same recorded profile)
+                compute = dict(j["compute"], bound="valu + lds at the chip's power limit",
+                               source="recorded SQ counter passes, not this run: profiles/" + str(j.get("tag", "?")) + "_sq_counters.json")
         out = {
             "metric": "Mbursts/s detect+demod (156.25 sym, 4 SPS)",
             "value": round(value, 4), "unit": "Mbursts/s",
@@ -617,14 +618,15 @@ def main():
             "roofline": {
                 # `bound` names the roofline the fraction is priced against (the measurement contract: HBM bytes); what limits
                 # the kernel in practice is in `compute` -- the vector ALU's issue rate, not HBM
-                "bound": "hbm", "bound_note": "valu-issue in practice, at the chip's power limit (see compute, and config.sustained.sclk_mhz_under_load "
+                "bound": "hbm", "bound_note": "vector ALU + LDS in practice, at the chip's power limit (see compute, and config.sustained.sclk_mhz_under_load "
                                               "of 2400 MHz): `bound` names the roofline `frac` is priced against",
                 "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,
                 "compute": compute,
-                "kernel": "burst_pull4_kernel<false, false, true>", "kernel_ms": round(kernel_ms, 4),
-                "kernel_ms_note": "HIP events around the K timed launches / K (launch gaps included); the rocprofv3 kernel-trace "
-                                  "average of the same command is the pure kernel duration",
+                "kernel": "nb_pull4_kernel", "kernel_ms": round(kernel_ms, 4),
+                "kernel_ms_note": "HIP events around the K timed steps / K: one step = the normal-burst kernel + the general kernel over the "
+                                  "list it leaves behind (empty for this workload: returns at once), launch gaps included; the rocprofv3 "
+                                  "kernel-trace average of nb_pull4_kernel in the same command is the pure kernel duration",
                 "algorithmic_bytes_per_burst": BYTES_PER_BURST, "bursts_per_launch": n,
             },
         }
@@ -632,7 +634,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(iq_cpu_sample, params[:ns])
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if shard.backend_name():
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

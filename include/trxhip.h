@@ -27,6 +27,7 @@
 #ifndef TRXHIP_H
 #define TRXHIP_H
 
+#include <math.h>     /* powf() in TRXHIP_FAST_CI_ATOL_DB */
 #include <stddef.h>
 #include <stdint.h>
 
@@ -71,12 +72,27 @@ enum trxhip_signal_error {
                                      * (csrc/trx_device.h, peak_detect_fast) -- while the interpolated peak value is an FMA sum:
                                      * amp within TRXHIP_FAST_AMP_RTOL, C/I within TRXHIP_FAST_CI_ATOL_DB(ci) of the reference's.
                                      * Only the 4-SPS / 625-sample kernel has a fused path; others are always exact. */
+#define TRXHIP_FLAG_IDLE_DUMMY   4  /* search IDLE slots for the dummy burst, as detectAnyBurst(IDLE) does (detectDummyBurst,
+                                     * sigProcLib.cpp:1863-1877, :1945-1947; rc = IDLE on a hit) instead of skipping them as
+                                     * pullRadioVector does (Transceiver.cpp:754-755) */
+#define TRXHIP_FLAG_USE_VA       8  /* trxhip_hostpipe_cfg.flags only: see there */
+#define TRXHIP_FLAG_FEW_NB_SLOTS 16 /* a HINT from a caller that knows its slot types (expectedCorrType() runs on the host,
+                                     * Transceiver.cpp:513-601): fewer than half of the batch's slots are normal-burst slots
+                                     * (type TSC, max_toa <= 32).  Results never depend on it; the call then runs the general
+                                     * kernel alone instead of the normal-burst kernel + the general one over what that leaves
+                                     * (which reads every burst of another type twice).  The host pipe sets it from the
+                                     * parameters it is handed. */
 /* The FAST detector's tolerance statement (fused kernels only; tests quote these).  amp = interpolated correlation peak / gain:
  * one 16-term sum per component, FMA against product-then-sum; |amp - ref| <= TRXHIP_FAST_AMP_RTOL * |ref| (complex distance;
  * proven bound 2.6 * 25 u = 3.9e-6 relative to the correlation's arg-max magnitude, measured <= 3e-7).
  * C/I = 10 log10(C / (S - C)) with C = |peak|^2 / den and S the mean sample power (tree-summed in the FAST detector: within
  * 1.2e-6 of the reference's ordered sum): S - C cancels by the factor 1 + C/I, so relative errors eC of C and eS of S become
- * (eC + eS) (1 + 10^(ci/10)) of the ratio:  |ci - ref| <= 1e-4 dB + 4.35 * (2 * TRXHIP_FAST_AMP_RTOL + 1.2e-6) * (1 + 10^(ci/10)) dB. */
+ * (eC + eS) (1 + 10^(ci/10)) of the ratio:  |ci - ref| <= 1e-4 dB + 4.35 * (2 * TRXHIP_FAST_AMP_RTOL + 1.2e-6) * (1 + 10^(ci/10)) dB.
+ * NaN: S < C (a noise slot whose peak estimate exceeds the mean sample power) makes C / (S - C) negative and C/I NaN in the
+ * reference as here (sigProcLib.cpp:1637 has no guard); the tests require the SAME NaN pattern (tests/oracle_lib.py
+ * assert_fast_ci).  Where S - C cancels to within the relative errors above -- |S - C| <= 3e-6 S, i.e. C/I beyond +55 dB: a peak that
+ * explains the whole sample power to six digits, which no burst with any noise or sample rounding in it reaches -- its sign is not
+ * covered by the bar: NaN on one side could meet a large finite value on the other. */
 #define TRXHIP_FAST_AMP_RTOL        1e-6f
 #define TRXHIP_FAST_CI_ATOL_DB(ci)  (1e-4f + 1.4e-5f * (1.0f + powf(10.0f, (ci) * 0.1f)))
 /* The one statement of the default (fused) demodulator's tolerance; tests/, tools/parity_campaign.py, bench.py and DESIGN.md
@@ -94,11 +110,6 @@ enum trxhip_signal_error {
 
 /* Per-burst input: what pullRadioVector() knows before calling detectAnyBurst()
  * (expectedCorrType() Transceiver.cpp:513-601, mTSC, mMaxExpectedDelayAB/NB :757-758). 8 bytes. */
-#define TRXHIP_FLAG_USE_VA       8  /* trxhip_hostpipe_cfg.flags only: see there */
-#define TRXHIP_FLAG_IDLE_DUMMY   4  /* search IDLE slots for the dummy burst, as detectAnyBurst(IDLE) does (detectDummyBurst,
-                                     * sigProcLib.cpp:1863-1877, :1945-1947; rc = IDLE on a hit) instead of skipping them as
-                                     * pullRadioVector does (Transceiver.cpp:754-755) */
-
 typedef struct trxhip_burst_params {
 	uint8_t  type;      /* enum trxhip_corr_type expected for the slot */
 	uint8_t  tsc;       /* training sequence code 0..7 */

@@ -276,8 +276,10 @@ static int pull_common(trxhip_ctx *ctx, const void *d_iq, int cf32, const trxhip
 		return TRXHIP_EINVAL;
 	if (with_device(ctx))
 		return TRXHIP_EIO;
-	if (flags & ~(TRXHIP_FLAG_SLICE | TRXHIP_FLAG_EXACT_DEMOD | TRXHIP_FLAG_IDLE_DUMMY | TRXHIP_FLAG_DIAG_MASK))
+	if (flags & ~(TRXHIP_FLAG_SLICE | TRXHIP_FLAG_EXACT_DEMOD | TRXHIP_FLAG_IDLE_DUMMY | TRXHIP_FLAG_FEW_NB_SLOTS | TRXHIP_FLAG_DIAG_MASK))
 		return TRXHIP_EINVAL;
+	const bool few_nb = (flags & TRXHIP_FLAG_FEW_NB_SLOTS) != 0;  /* a hint, not a kernel flag */
+	flags &= ~TRXHIP_FLAG_FEW_NB_SLOTS;
 	if (ctx->no_unit)
 		flags |= TRXHIP_IFLAG_NO_UNIT;
 	if (ctx->no_sym)
@@ -296,7 +298,7 @@ static int pull_common(trxhip_ctx *ctx, const void *d_iq, int cf32, const trxhip
 		pool = ctx->d_pool + (size_t)(ctx->pool_next.fetch_add(1u, std::memory_order_relaxed) % TRX_POOL_SLOTS) * 16;
 	/* The call pullRadioVector() makes for its traffic slots (int16 bursts of 625 samples at 4 SPS, fused demodulator, sliced rows
 	 * of 148 soft bits): the normal-burst kernel over the batch, then the general kernel over whatever it left on its list. */
-	if (ctx->nb_enabled && !capturing && !cf32 && !d_ebp_in && sps == 4 && burst_len == 625 && d_soft && soft_stride == 148 &&
+	if (ctx->nb_enabled && !few_nb && !capturing && !cf32 && !d_ebp_in && sps == 4 && burst_len == 625 && d_soft && soft_stride == 148 &&
 	    flags == TRXHIP_FLAG_SLICE) {
 		std::lock_guard<std::mutex> lk(ctx->redo_mu);
 		trxhip_ctx::redo_slot &sl = ctx->redo[ctx->redo_next++ % TRX_REDO_SLOTS];
@@ -312,8 +314,12 @@ static int pull_common(trxhip_ctx *ctx, const void *d_iq, int cf32, const trxhip
 			sl.d = nullptr;
 			sl.cap = 0;
 			const size_t cap_new = n_bursts < 65536 ? 65536 : n_bursts;
-			ok = hipMalloc(reinterpret_cast<void **>(&sl.d), (TRX_REDO_HDR_WORDS + cap_new) * sizeof(unsigned)) == hipSuccess &&
-			     hipMemset(sl.d, 0, TRX_REDO_HDR_WORDS * sizeof(unsigned)) == hipSuccess;
+			/* header words + one flag byte per burst, padded to whole chunks of 256; all zero between launches */
+			const size_t bytes = TRX_REDO_HDR_WORDS * sizeof(unsigned) + ((cap_new + 255) & ~(size_t)255);
+			/* (the memset runs on the null stream: drained before a kernel on the caller's -- possibly non-blocking -- stream
+			 * may touch the buffer; this is the allocation path, a handful of calls per context) */
+			ok = hipMalloc(reinterpret_cast<void **>(&sl.d), bytes) == hipSuccess && hipMemset(sl.d, 0, bytes) == hipSuccess &&
+			     hipDeviceSynchronize() == hipSuccess;
 			if (ok)
 				sl.cap = cap_new;
 			else if (sl.d) {

@@ -26,7 +26,7 @@ struct trxhip_ctx {
 	int pool_enabled;                  /* trxhip_set_work_pool(); default 1, 0 when TRXHIP_NO_POOL is set at creation */
 	std::atomic<unsigned> pool_next;
 	/* The normal-burst kernel (trx_kernel_nb.hip) and the list of bursts it leaves to the general kernel: TRX_REDO_SLOTS device
-	 * buffers of TRX_REDO_HDR + capacity words, handed out round-robin per launch under redo_mu.  A slot's header is zero
+	 * buffers of TRX_REDO_HDR words + one flag byte per burst, handed out round-robin per launch under redo_mu.  A slot's header is zero
 	 * between launches (the general kernel's last workgroup re-arms it); its event marks the end of the launch pair that used
 	 * it last -- a slot is only handed out again (or re-allocated larger) once that event has completed. */
 	int nb_enabled;                    /* trxhip_set_nb_kernel(); default 1, 0 when TRXHIP_NO_NB_KERNEL is set at creation */

@@ -270,9 +270,15 @@ static int submit_slot(trxhip_hostpipe *p, int slot, size_t n, bool by_ref)
 		if (rc == TRXHIP_OK)                                      /* energy / rssi of the record: the burst as read (:724-751) */
 			rc = trxhip_apply_diversity_power(p->ctx, sl.d_results, d_params, sl.d_avg, n, c.full_scale, st);
 	} else {
+		/* the slot types are known here (the host's copy of the parameters): a batch with few normal-burst slots goes to the
+		 * general kernel alone (include/trxhip.h, TRXHIP_FLAG_FEW_NB_SLOTS) */
+		size_t n_nb = 0;
+		for (size_t i = 0; i < n; i++)
+			n_nb += sl.h.params[i].type == TRXHIP_TSC && sl.h.params[i].tsc < 8 && sl.h.params[i].max_toa <= 32;
 		if (rc == TRXHIP_OK)
 			rc = trxhip_detect_demod_batch(p->ctx, d_bursts, d_params, sl.d_results, sl.d_soft, n, c.burst_len, c.sps,
-						       c.threshold, c.full_scale, p->dev_soft_stride, c.flags, st);
+						       c.threshold, c.full_scale, p->dev_soft_stride,
+						       c.flags | (2 * n_nb < n ? TRXHIP_FLAG_FEW_NB_SLOTS : 0), st);
 		if (rc == TRXHIP_OK && np > 1)                            /* :741, :751: rssi from the path average */
 			rc = trxhip_apply_diversity_power(p->ctx, sl.d_results, d_params, sl.d_avg, n, c.full_scale, st);
 	}

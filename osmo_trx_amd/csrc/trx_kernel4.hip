@@ -87,12 +87,12 @@ __device__ __forceinline__ int cdiv4(int a) { return (a + 3) >> 2; }
 // + demodulation, vectorSlicer applied, rows of 148 soft bits, no diagnostic flags.  Those launch parameters are then
 // compile-time constants (the launcher checks them) and the scalar tests, selects and generic store loops they feed
 // disappear from the burst loop; every other call takes the general instantiation of the same source.
-// LIST: the launch works through a LIST of burst indices in device memory -- redo[0] = their number, entries from
-// redo[TRX_REDO_HDR] -- that the normal-burst kernel (trx_kernel_nb.hip) left behind: slots of other types, wide windows, the
-// rare bursts its straight-line paths do not cover.  The count is only known on the device: the grid is the persistent one,
-// a launch over an empty list returns before it stages anything.  List positions are dealt statically (wave w of workgroup g
-// takes positions 16 g + w + k * 16 * gridDim.x) so that the index of the burst after next can be fetched a burst ahead.
-#define TRX_REDO_HDR 16                   /* [0] count, [1] workgroups done (this kernel), entries from [16] */
+// LIST: the launch works through the bursts the normal-burst kernel (trx_kernel_nb.hip) left behind -- slots of other types, wide
+// windows, the rare bursts its paths do not cover -- marked in a FLAG BYTE PER BURST (redo + TRX_REDO_HDR words; plain stores, no
+// atomics: a type-mixed batch leaves a million of them).  redo[0] != 0: something was left; a launch that finds 0 returns at
+// once.  A wave scans the flags 256 at a time (one dword per lane; chunks gw, gw + waves, ...), clears what it read and works
+// through the set ones; the next burst is known when the current one is prefetched, as in the claiming form.
+#define TRX_REDO_HDR 16                   /* words: [0] anything left, [1] workgroups done (this kernel); flag bytes behind them */
 template <bool CF32, bool EXACT, bool COMMON, bool LIST = false>
 __global__ void __launch_bounds__(K4_WPB(CF32, EXACT) * WAVE)
 burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__restrict__ params,
@@ -101,10 +101,10 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 		   unsigned n_bursts_arg, int L_arg, float thresh, float full_scale, int soft_stride_arg, int slice_arg,
 		   unsigned *__restrict__ pool_ctr, unsigned *__restrict__ redo)
 {
-	const unsigned n_bursts = LIST ? (unsigned)uni((int)__hip_atomic_load(redo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : n_bursts_arg;
-	if (LIST && n_bursts == 0u)
+	const unsigned n_bursts = n_bursts_arg;
+	if (LIST && uni((int)__hip_atomic_load(redo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0)
 		return;
-	const unsigned *const rlist = LIST ? redo + TRX_REDO_HDR : nullptr;
+	uint32_t *const rflags = LIST ? reinterpret_cast<uint32_t *>(redo + TRX_REDO_HDR) : nullptr;   // four flag bytes per word
 	static_assert(!(COMMON && CF32 && EXACT), "complex64 input: the common instantiation exists for the fused demodulator only (16 waves per CU)");
 	static_assert(K4_TABLES_BYTES % 16 == 0 && (K4_SLICE * 8) % 16 == 0 && (K4_XS * 8) % 16 == 0 &&
 		      ((TRX_DEC_NARROW + TRX_CZ_PAD) * 8) % 16 == 0, "dec[] and cz[] are read / written 16 bytes at a time");
@@ -144,20 +144,68 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 			}
 		}
 	};
-	// LIST: position in the list of the wave's current burst, and the index of the burst after next (fetched a burst ahead).  The
-	// first burst's index and samples are requested BEFORE the tables are staged (the staging then covers their latency: a launch
-	// over a short list is all latency), and a workgroup without a list position leaves before it stages anything.
-	unsigned lpos = blockIdx.x * 16u + (unsigned)wave;
-	const unsigned lstride = gridDim.x * 16u;
-	uint32_t pre_id = K4_NO_BURST;
+	// LIST: the wave's iterator over the flagged bursts.  Chunk c = bursts 256 c .. 256 c + 255, lane l holding the flags of
+	// bursts 256 c + 4 l + q in byte q of its word; l_mask = lanes whose byte l_q is set and not yet handed out.
+	const unsigned l_chunks = (n_bursts + 255u) >> 8, l_stride = gridDim.x * 16u;
+	unsigned l_next_chunk = blockIdx.x * 16u + (unsigned)wave, l_chunk = 0;
+	uint32_t l_word = 0u;
+	int l_q = 4;
+	unsigned long long l_mask = 0ull;
+	auto list_next = [&]() -> unsigned {
+		for (;;) {
+			if (l_mask != 0ull) {
+				const int ln = __ffsll((unsigned long long)l_mask) - 1;
+				l_mask &= l_mask - 1ull;
+				const unsigned bb = (l_chunk << 8) + 4u * (unsigned)ln + (unsigned)l_q;
+				if (bb < n_bursts)
+					return bb;
+				continue;
+			}
+			if (++l_q < 4) {
+				l_mask = __ballot(((l_word >> (8 * l_q)) & 0xffu) != 0u);
+				continue;
+			}
+			if (l_next_chunk >= l_chunks)
+				return K4_NO_BURST;
+			l_chunk = l_next_chunk;
+			l_next_chunk += l_stride;
+			uint32_t *const wp = rflags + ((size_t)l_chunk << 6) + lane;       // (the flag area is padded to whole chunks)
+			l_word = *wp;
+			if (l_word != 0u)
+				*wp = 0u;                                                       // consumed: the area is all zero again behind this launch
+			l_q = -1;
+		}
+	};
 	unsigned b_first = K4_NO_BURST;
 	if (LIST) {
-		if (blockIdx.x * 16u >= n_bursts)
+		// the first burst's samples are requested BEFORE the tables are staged (the staging then covers their latency: a launch
+		// over a few bursts is all latency); a workgroup none of whose waves found a flag leaves before it stages anything
+		// (decided on the first chunk of every wave: exact when the batch has at most one chunk per wave)
+		b_first = list_next();
+		// (workgroup-wide OR through a word at the end of the dynamic LDS -- the pool ring's first entry, unused in this form; the
+		// library's __syncthreads_or() would add static LDS to a kernel that uses all 160 KB)
+		volatile int *const any_w = reinterpret_cast<volatile int *>(smem + K4_TABLES_BYTES + (size_t)waves_per_block * K4_SLICE * sizeof(c32)) + 4;
+		bool wg_any = true;
+		if (l_chunks <= l_stride) {
+			if (threadIdx.x == 0)
+				*any_w = 0;
+			__syncthreads();
+			if (b_first != K4_NO_BURST && lane == 0)
+				*any_w = 1;
+			__syncthreads();
+			wg_any = *any_w != 0;
+			__syncthreads();
+		}
+		if (!wg_any) {
+			if (threadIdx.x == 0) {
+				const unsigned d = __hip_atomic_fetch_add(redo + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+				if (d == gridDim.x - 1u) {
+					__hip_atomic_store(redo, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					__hip_atomic_store(redo + 1, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+				}
+			}
 			return;
-		if (lpos < n_bursts)
-			b_first = (unsigned)uni((int)rlist[lpos]);
-		if (lpos + lstride < n_bursts)
-			pre_id = rlist[lpos + lstride];
+		}
 		if (b_first != K4_NO_BURST)
 			prefetch(b_first);
 	}
@@ -498,10 +546,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 		pend_mode = 0;
 		DIAG_MARK(16);
 		if (LIST) {
-			lpos += lstride;
-			b_next = (lpos < n_bursts) ? (unsigned)uni((int)pre_id) : K4_NO_BURST;
-			if (lpos + lstride < n_bursts)
-				pre_id = rlist[lpos + lstride];
+			b_next = list_next();
 		} else {
 			j_next = (unsigned)claim_take(ticket);
 			DIAG_MARK(17);
@@ -1129,10 +1174,9 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 	if (LIST) {
 		__syncthreads();
 		if (threadIdx.x == 0) {
-			// (workgroups with a list position: ceil(n / 16), capped by the grid; the others left at the top)
-			const unsigned n_active = (n_bursts + 15u) / 16u < gridDim.x ? (n_bursts + 15u) / 16u : gridDim.x;
+			// (every workgroup of the grid is counted: the ones that found nothing counted themselves when they left)
 			const unsigned d = __hip_atomic_fetch_add(redo + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-			if (d == n_active - 1u) {
+			if (d == gridDim.x - 1u) {
 				__hip_atomic_store(redo, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				__hip_atomic_store(redo + 1, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 			}
@@ -1169,8 +1213,8 @@ extern "C" int trx_unit_masks_match(const trx_tables *t)
 #include "trx_kernel_nb.hip"
 
 // The normal-burst kernel over the whole batch, then the general kernel (fused demodulator, common launch parameters) over the
-// list of bursts the first one left behind (d_redo: TRX_REDO_HDR words of header + one word per burst, header zero on entry
-// and zero again when the second kernel has finished).  Preconditions (the caller checks them): int16 input of 625 samples,
+// bursts the first one left behind (d_redo: TRX_REDO_HDR words of header + one flag byte per burst, padded to a multiple of
+// 256: all zero on entry and all zero again when the second kernel has finished).  Preconditions (the caller checks them): int16 input of 625 samples,
 // fused demodulator, sliced rows of 148 soft bits, tables with the unit / symmetric / FAST structure.
 extern "C" int trx_launch_pull4_nb(unsigned *d_pool_ctr, const void *d_iq, const trxhip_burst_params *d_params,
 				   trxhip_burst_result *d_results, float *d_soft, const trx_tables *d_tab, size_t n_bursts,
@@ -1194,7 +1238,7 @@ extern "C" int trx_launch_pull4_nb(unsigned *d_pool_ctr, const void *d_iq, const
 		TRX_ARM_DYNAMIC_LDS(k);
 		const size_t lds = K4_TABLES_BYTES + (size_t)K4_WPB(false, false) * K4_SLICE * sizeof(c32) + K4_LDS_TAIL;
 		hipLaunchKernelGGL(k, dim3((unsigned)n_cu), dim3(K4_WPB(false, false) * WAVE), lds, stream, d_iq, d_params, d_results, d_soft, d_tab,
-				   (const float4 *)nullptr, 0u, 625, thresh, full_scale, 148, TRXHIP_FLAG_SLICE, (unsigned *)nullptr, d_redo);
+				   (const float4 *)nullptr, (unsigned)n_bursts, 625, thresh, full_scale, 148, TRXHIP_FLAG_SLICE, (unsigned *)nullptr, d_redo);
 	}
 	return hipGetLastError() == hipSuccess ? 0 : TRXHIP_EIO;
 }

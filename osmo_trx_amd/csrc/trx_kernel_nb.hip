@@ -6,7 +6,7 @@
 //
 // Same arithmetic as the COMMON instantiation of burst_pull4_kernel (trx_kernel4.hip) -- results are bit-identical to it --
 // but nothing else is in here: no access / EDGE / dummy / wide-window / exact-demodulator code, no run-time flags.  A burst
-// this kernel cannot finish is APPENDED TO A LIST and left to the general kernel, which is launched behind it over that list:
+// this kernel cannot finish is FLAGGED (a byte per burst) and left to the general kernel, which is launched behind it over the flags:
 //   * the slot is not a normal-burst slot (type != TSC, tsc > 7) or its window is wider than one round (max_toa > 32);
 //   * (a decimated sample that fails the addition-only correlation's guard -- about one burst in 3000 -- takes the multiplying form here)
 //   * the peak-ratio gate is too close to call for the estimate (about one in 1e5);
@@ -211,6 +211,7 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 	int recw = 0;
 	bool pend_any = false;
 	unsigned pend_b = 0;
+	bool left_any = false;
 
 	// ---- cold: demodGmskBurst for a TOA outside the straight-line geometry (shift w = nk >> 7 above 0: an early burst; below -36:
 	// later than 9 symbols).  The general kernel's fused demodulator (trx_kernel4.hip, "FUSED": same sums, same order -- the
@@ -335,19 +336,25 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 		asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
 		const int ticket = claim_issue(wg_next);
 		const unsigned prm0 = (unsigned)uni((int)pre_prm);
+		// ---- is this a slot the kernel handles?  (a slot of another type is flagged before anything is spent on its samples)
+		const unsigned max_toa = prm0 >> 16;
+		const int tsc = (prm0 >> 8) & 0xff;
+		bool leave = ((prm0 & 0xf8ffu) != (unsigned)TRXHIP_TSC) || (max_toa > NB_MAX_TOA) || !t5_ok;
 
 		// ---- phase 0: registers -> fp32 polyphase LDS; clip scan and energyDetect partial sums on the fly
 		c32 *const pload = P + (lane & 3) * PH_A + PH_M0 + (lane >> 2);
 		float amax = 0.0f, epart = 0.0f;
+		if (!leave) {
 #pragma unroll
-		for (int r = 0; r < NLD; r++) {
-			const int i = r * WAVE + lane;
-			if (r < NLD - 1 || i < 625) {
-				const c32 v = make_float2((float)(int16_t)(pre_i[r] & 0xffffu), (float)(int16_t)(pre_i[r] >> 16));
-				pload[16 * r] = v;
-				asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(v.x), "v"(v.y));
-				if (r < 5)
-					epart = fmaf(v.x, v.x, fmaf(v.y, v.y, epart));
+			for (int r = 0; r < NLD; r++) {
+				const int i = r * WAVE + lane;
+				if (r < NLD - 1 || i < 625) {
+					const c32 v = make_float2((float)(int16_t)(pre_i[r] & 0xffffu), (float)(int16_t)(pre_i[r] >> 16));
+					pload[16 * r] = v;
+					asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(v.x), "v"(v.y));
+					if (r < 5)
+						epart = fmaf(v.x, v.x, fmaf(v.y, v.y, epart));
+				}
 			}
 		}
 		// ---- the previous burst's output: 148 soft bits (lanes 0..47: symbols 4 + 3 lane + j as one 12-byte store, lanes
@@ -375,10 +382,6 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 		if (b_next != NB_NO_BURST)
 			prefetch(b_next, lane);
 
-		// ---- is this a slot the kernel handles?
-		const unsigned max_toa = prm0 >> 16;
-		const int tsc = (prm0 >> 8) & 0xff;
-		bool leave = ((prm0 & 0xf8ffu) != (unsigned)TRXHIP_TSC) || (max_toa > NB_MAX_TOA) || !t5_ok;
 		int clip = 0;
 		if (!leave) {
 			// maxAmplitude() > 30000 (:1711-1722, :1746)
@@ -498,10 +501,15 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 			}
 		}
 		if (leave) {
+			// left to the general kernel: the burst's flag byte, and "something was left" (plain stores: a type-mixed batch leaves a
+			// million bursts, and a million atomics on one counter cost ten times the batch)
+			// ("something was left" once per wave: a million stores to one address serialise in the L2 like a million atomics)
 			if (lane == 0) {
-				const unsigned idx = __hip_atomic_fetch_add(redo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				redo[TRX_REDO_HDR + idx] = b;
+				reinterpret_cast<uint8_t *>(redo + TRX_REDO_HDR)[b] = 1;
+				if (!left_any)
+					__hip_atomic_store(redo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			}
+			left_any = true;
 			continue;
 		}
 		pend_b = b;

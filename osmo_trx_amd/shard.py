@@ -21,7 +21,11 @@ def env_world():
 
 def init_distributed(backend=None):
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    # world 1 with WORLD_SIZE=1 and TRXHIP_DIST_BACKEND spelled out: the process group is still created, so that the collectives of
+    # the N > 1 path (table broadcast, max / sum over ranks, barrier) run on the named backend with one rank -- RCCL's first
+    # contact on a 1-GPU box (tests/test_gpu_sharded.py)
+    forced = world == 1 and "WORLD_SIZE" in os.environ and bool(os.environ.get("TRXHIP_DIST_BACKEND"))
+    if (world > 1 or forced) and not dist.is_initialized():
         # before anything initialises the GPU runtime: dmabuf IPC (RCCL peer buffers on hosts without the legacy mode)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
@@ -60,7 +64,7 @@ def gather_strings(text, device=None, width=96):
     """Every rank's `text` (ASCII, cut to `width` bytes) on every rank, in rank order: one all_gather of fixed-size byte
     tensors -- works on RCCL (device tensors) and gloo alike."""
     rank, _, world = env_world()
-    if world == 1 or not dist.is_initialized():
+    if not dist.is_initialized():
         return [text]
     dev = torch.device(device) if device is not None else torch.device("cpu")
     raw = text.encode("ascii", "replace")[:width].ljust(width, b"\0")
@@ -75,7 +79,7 @@ def broadcast_tables(device=None):
     the FNV-1a checksum.  Returns the blob as bytes."""
     rank, _, world = env_world()
     size = int(trxhip.load_library().trxhip_tables_size())
-    if world == 1 or not dist.is_initialized():
+    if not dist.is_initialized():
         return trxhip.generate_tables_host()
     dev = torch.device(device) if device is not None else torch.device("cpu")
     if rank == 0:
@@ -95,7 +99,7 @@ def broadcast_tables(device=None):
 
 def max_over_ranks(value, device=None):
     rank, _, world = env_world()
-    if world == 1 or not dist.is_initialized():
+    if not dist.is_initialized():
         return float(value)
     dev = torch.device(device) if device is not None else torch.device("cpu")
     t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
@@ -105,7 +109,7 @@ def max_over_ranks(value, device=None):
 
 def sum_over_ranks(value, device=None):
     rank, _, world = env_world()
-    if world == 1 or not dist.is_initialized():
+    if not dist.is_initialized():
         return float(value)
     dev = torch.device(device) if device is not None else torch.device("cpu")
     t = torch.tensor([float(value)], dtype=torch.float64, device=dev)

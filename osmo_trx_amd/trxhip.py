@@ -26,7 +26,17 @@ TRXD_RECORD_BYTES = 156
 FLAG_SLICE = 1          # TRXHIP_FLAG_SLICE
 FLAG_EXACT_DEMOD = 2    # TRXHIP_FLAG_EXACT_DEMOD
 FLAG_IDLE_DUMMY = 4     # TRXHIP_FLAG_IDLE_DUMMY
+FLAG_FEW_NB_SLOTS = 16  # TRXHIP_FLAG_FEW_NB_SLOTS (a hint: see include/trxhip.h)
 SCH_DETECT_FULL, SCH_DETECT_NARROW, SCH_DETECT_BUFFER = 0, 1, 2   # sch_detect_type (sigProcLib.h:139-143)
+
+
+def few_nb_hint(host_params):
+    """TRXHIP_FLAG_FEW_NB_SLOTS when fewer than half of the slots of `host_params` (PARAMS_DTYPE[n], or None: no hint) are
+    normal-burst slots the normal-burst kernel takes (type TSC = 1, tsc < 8, max_toa <= 32)."""
+    if host_params is None or len(host_params) == 0:
+        return 0
+    nb = (host_params["type"] == 1) & (host_params["tsc"] < 8) & (host_params["max_toa"] <= 32)
+    return FLAG_FEW_NB_SLOTS if 2 * int(nb.sum()) < len(host_params) else 0
 
 
 class TrxHipError(RuntimeError):
@@ -231,8 +241,11 @@ class TrxHip:
 
     # ---- hot path ------------------------------------------------------------------------------
     def detect_demod(self, iq, params, sps=4, threshold=4.0, full_scale=32767.0, soft_stride=148, slice_bits=True,
-                     results=None, soft=None, stream=None, want_soft=True, exact=False, idle_dummy=False, _diag_mask=0):
+                     results=None, soft=None, stream=None, want_soft=True, exact=False, idle_dummy=False, _diag_mask=0,
+                     host_params=None):
         """iq: int16[n, burst_len, 2] or complex64[n, burst_len] (device).  params: uint8[n, 8] (device).
+        host_params: the caller's host copy of the parameters (PARAMS_DTYPE[n]), if it has one: the slot types decide the
+        TRXHIP_FLAG_FEW_NB_SLOTS hint (a batch with few normal-burst slots runs the general kernel alone; results do not change).
         Returns (results uint8[n, 32], soft float32[n, soft_stride]) device tensors."""
         torch = self.torch
         n = iq.shape[0]
@@ -256,7 +269,7 @@ class TrxHip:
         rc = fn(self.h, ip, self._dev(params), self._dev(results), sp, n, burst_len, sps,
                 threshold, full_scale, soft_stride,
                 (FLAG_SLICE if slice_bits else 0) | (FLAG_EXACT_DEMOD if exact else 0) |
-                (FLAG_IDLE_DUMMY if idle_dummy else 0) | (int(_diag_mask) << 8),
+                (FLAG_IDLE_DUMMY if idle_dummy else 0) | (int(_diag_mask) << 8) | few_nb_hint(host_params),
                 self._stream(stream))
         _check(rc, "trxhip_detect_demod_batch")
         return results, soft

@@ -20,7 +20,11 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out")
-KERNEL = "burst_pull4_kernel<false, false, true>"
+sys.path.insert(0, ROOT)
+from osmo_trx_amd.srchash import hot_kernel_source_hash   # noqa: E402
+
+KERNEL = "nb_pull4_kernel"                                 # the hot kernel (round 6: the normal-burst kernel)
+LIST_KERNEL = "burst_pull4_kernel<false, false, true, true>"   # the general kernel over the list it leaves behind
 
 
 def counter(path, name):
@@ -35,18 +39,22 @@ def counter(path, name):
 def main(tag, bursts=1 << 20):
     shutil.copyfile(os.path.join(G, "prof_stats", f"{tag}_kernel_stats.csv"),
                     os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"))
-    stats = {}
+    stats, list_stats = {}, {}
     with open(os.path.join(G, "prof_stats", f"{tag}_kernel_stats.csv")) as f:
         for row in csv.DictReader(f):
             if KERNEL in row["Name"]:
                 stats = {"calls": int(row["Calls"]), "avg_ns": float(row["AverageNs"]), "min_ns": int(row["MinNs"]),
                          "max_ns": int(row["MaxNs"])}
+            if LIST_KERNEL in row["Name"]:
+                list_stats = {"calls": int(row["Calls"]), "avg_ns": float(row["AverageNs"]), "min_ns": int(row["MinNs"]),
+                              "max_ns": int(row["MaxNs"])}
     fetch = counter(os.path.join(G, "prof_fetch", f"{tag}_counter_collection.csv"), "FETCH_SIZE")
     write = counter(os.path.join(G, "prof_write", f"{tag}_counter_collection.csv"), "WRITE_SIZE")
     fetch_b = 2.0 * 1024.0 * sum(fetch) / len(fetch)        # gfx950 half-count correction
     write_b = 1024.0 * sum(write) / len(write)
     out = {
-        "tag": tag, "kernel": KERNEL, "bursts_per_launch": bursts, "kernel_trace": stats,
+        "tag": tag, "kernel": KERNEL, "bursts_per_launch": bursts, "kernel_trace": stats, "list_kernel_trace": list_stats,
+        "source_hash": hot_kernel_source_hash(),
         "FETCH_SIZE_KB_raw_avg": sum(fetch) / len(fetch), "WRITE_SIZE_KB_avg": sum(write) / len(write),
         "hbm_read_bytes_per_launch": fetch_b, "hbm_write_bytes_per_launch": write_b,
         "hbm_bytes_per_burst": (fetch_b + write_b) / bursts,
@@ -55,7 +63,7 @@ def main(tag, bursts=1 << 20):
                 "separate --pmc passes for FETCH_SIZE and WRITE_SIZE",
     }
     json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_pmc.json"), "w"), indent=1)
-    json.dump({"tag": tag, "hbm_bytes_per_burst": out["hbm_bytes_per_burst"]},
+    json.dump({"tag": tag, "source_hash": out["source_hash"], "hbm_bytes_per_burst": out["hbm_bytes_per_burst"]},
               open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"))
     print(json.dumps(out, indent=1))
 

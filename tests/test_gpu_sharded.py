@@ -241,3 +241,56 @@ def check_two_rank_line(r, launcher):
     s = j["config"]["other_configs"]["configs[4]_strong"]
     assert s["scaling"] == "strong" and s["global_bursts"] == 1 << 20 and s["bursts_this_rank"] == 1 << 19
     assert 0.85 < s["detected_fraction"] < 1.0
+
+
+RCCL_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch
+from osmo_trx_amd import TrxHip, shard, trxhip
+rank, local_rank, world = shard.init_distributed()                    # WORLD_SIZE=1 TRXHIP_DIST_BACKEND=nccl: one rank over RCCL
+assert shard.backend_name() == "nccl" and world == 1
+dev = "cuda:0"
+blob = shard.broadcast_tables(dev)                                    # uint8 + int64 broadcasts on device tensors, checksum verified
+assert blob == trxhip.generate_tables_host()
+assert shard.max_over_ranks(1.25, dev) == 1.25 and shard.sum_over_ranks(3.0, dev) == 3.0
+assert shard.gather_strings("cuda:0 test", dev) == ["cuda:0 test"]
+shard.barrier()
+trx = TrxHip(0, tables_blob=blob)                                     # the broadcast blob is what the context adopts
+torch.cuda.synchronize()
+import torch.distributed as dist
+dist.destroy_process_group()
+print("rccl first contact ok", len(blob))
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_rccl_first_contact_world_1():
+    """RCCL (torch.distributed "nccl") exercised with one rank in a FRESH process -- nothing in it has touched the GPU before the
+    process group is created: the table broadcast of shard.broadcast_tables on device tensors, max / sum over ranks, the
+    all_gather of gather_strings, barrier (VERDICT r5 item 6).  The multi-rank logic is the gloo tests'; this is the backend."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               TRXHIP_DIST_BACKEND="nccl", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", RCCL_WORKER, ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "rccl first contact ok" in r.stdout
+
+
+def test_bench_main_leg_over_rccl_world_1():
+    """bench.py --gpus 1 with WORLD_SIZE=1 TRXHIP_DIST_BACKEND=nccl: the line says backend nccl, and its collectives (table
+    broadcast, max over ranks of the timings, device list) ran on RCCL"""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               TRXHIP_DIST_BACKEND="nccl", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--main-only", "--steps", "3", "--warmup", "1",
+                        "--bursts", "65536"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["backend"] == "nccl" and d["n_gpus"] == 1 and d["value"] > 0
