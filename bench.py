@@ -137,7 +137,7 @@ def side_legs(args, trx, synth, shard, step, iq, n, dev, rank, world, results, s
     d_params_m = trx.params_tensor(params_m)
 
     def step_mixed():
-        trx.detect_demod(iq_m, d_params_m, sps=4, soft_stride=148, slice_bits=True, results=results, soft=soft)
+        trx.detect_demod(iq_m, d_params_m, sps=4, soft_stride=148, slice_bits=True, results=results, soft=soft, host_params=params_m)
 
     warm_clocks(step_mixed)
     shard.barrier()

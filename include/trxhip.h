@@ -77,11 +77,13 @@ enum trxhip_signal_error {
                                      * pullRadioVector does (Transceiver.cpp:754-755) */
 #define TRXHIP_FLAG_USE_VA       8  /* trxhip_hostpipe_cfg.flags only: see there */
 #define TRXHIP_FLAG_FEW_NB_SLOTS 16 /* a HINT from a caller that knows its slot types (expectedCorrType() runs on the host,
-                                     * Transceiver.cpp:513-601): fewer than half of the batch's slots are normal-burst slots
-                                     * (type TSC, max_toa <= 32).  Results never depend on it; the call then runs the general
-                                     * kernel alone instead of the normal-burst kernel + the general one over what that leaves
-                                     * (which reads every burst of another type twice).  The host pipe sets it from the
-                                     * parameters it is handed. */
+                                     * Transceiver.cpp:513-601): more than 1/32 of the batch's slots are not normal-burst slots
+                                     * (type TSC, tsc < 8, max_toa <= 32).  Results never depend on it; the call then runs the
+                                     * general kernel alone instead of the normal-burst kernel + the general one over what that
+                                     * leaves (which reads every burst of another type twice).  The host pipe sets it from the
+                                     * parameters it is handed; without a hint the library finds out by itself -- the second
+                                     * kernel reports how much it was left, and a context that sees more than 1/32 runs the
+                                     * general kernel alone for its next 63 launches before it tries again. */
 /* The FAST detector's tolerance statement (fused kernels only; tests quote these).  amp = interpolated correlation peak / gain:
  * one 16-term sum per component, FMA against product-then-sum; |amp - ref| <= TRXHIP_FAST_AMP_RTOL * |ref| (complex distance;
  * proven bound 2.6 * 25 u = 3.9e-6 relative to the correlation's arg-max magnitude, measured <= 3e-7).

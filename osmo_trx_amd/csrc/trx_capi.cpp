@@ -19,7 +19,7 @@ extern "C" int trx_launch_pull(unsigned *d_pool_ctr, const void *d_iq, int cf32,
 			       int soft_stride, int slice, int n_cu, hipStream_t stream);
 extern "C" int trx_launch_pull4_nb(unsigned *d_pool_ctr, const void *d_iq, const trxhip_burst_params *d_params,
 				   trxhip_burst_result *d_results, float *d_soft, const trx_tables *d_tab, size_t n_bursts,
-				   float thresh, float full_scale, int n_cu, unsigned *d_redo, hipStream_t stream);
+				   float thresh, float full_scale, int n_cu, unsigned *d_redo, unsigned *h_left, hipStream_t stream);
 extern "C" int trx_unit_masks_match(const trx_tables *t);       /* trx_kernel4.hip: compiled-in sign masks vs the tables */
 extern "C" int trx_launch_pack_trxd(const trxhip_burst_result *d_results, const float *d_soft, int soft_stride,
 				    uint8_t *d_pkt, size_t n_bursts, float rssi_offset, hipStream_t stream);
@@ -150,7 +150,10 @@ int trxhip_create_from_tables(trxhip_ctx **out, int device, const void *h_blob, 
 		ctx->redo[i].cap = 0;
 		ctx->redo[i].ev = nullptr;
 		ctx->redo[i].busy = 0;
+		ctx->redo[i].h_left = nullptr;
+		ctx->redo[i].n_last = 0;
 	}
+	ctx->split_backoff = 0;
 	ctx->no_sym = 0;                                           /* the straight-line decimator reads taps 0..7 and mirrors them */
 	for (int k = 0; k < 8; k++)
 		if (memcmp(&t->dec_taps[k], &t->dec_taps[15 - k], sizeof(float)) != 0)
@@ -212,6 +215,7 @@ void trxhip_destroy(trxhip_ctx *ctx)
 			if (ctx->redo[i].busy) (void)hipEventSynchronize(ctx->redo[i].ev);
 			if (ctx->redo[i].ev) (void)hipEventDestroy(ctx->redo[i].ev);
 			if (ctx->redo[i].d) (void)hipFree(ctx->redo[i].d);
+			if (ctx->redo[i].h_left) (void)hipHostFree(ctx->redo[i].h_left);
 		}
 	}
 	delete ctx;
@@ -301,11 +305,24 @@ static int pull_common(trxhip_ctx *ctx, const void *d_iq, int cf32, const trxhip
 	if (ctx->nb_enabled && !few_nb && !capturing && !cf32 && !d_ebp_in && sps == 4 && burst_len == 625 && d_soft && soft_stride == 148 &&
 	    flags == TRXHIP_FLAG_SLICE) {
 		std::lock_guard<std::mutex> lk(ctx->redo_mu);
+		if (ctx->split_backoff) {
+			ctx->split_backoff--;                                   /* a recent batch left too much: the general kernel alone */
+			return trx_launch_pull(pool, d_iq, cf32, d_params, d_results, d_soft, ctx->d_tables, d_ebp_in, n_bursts, burst_len, sps,
+					       threshold, full_scale, soft_stride, flags, ctx->n_cu, static_cast<hipStream_t>(stream));
+		}
 		trxhip_ctx::redo_slot &sl = ctx->redo[ctx->redo_next++ % TRX_REDO_SLOTS];
 		bool ok = true;
 		if (sl.busy) {
 			ok = hipEventSynchronize(sl.ev) == hipSuccess;
 			sl.busy = 0;
+			if (ok && sl.h_left && sl.n_last && (size_t)*reinterpret_cast<volatile unsigned *>(sl.h_left) * 32 > sl.n_last)
+				ctx->split_backoff = 63;
+		}
+		if (ok && !sl.h_left)
+			ok = hipHostMalloc(reinterpret_cast<void **>(&sl.h_left), 64, hipHostMallocDefault) == hipSuccess;
+		if (ok) {
+			*sl.h_left = 0u;
+			sl.n_last = n_bursts;
 		}
 		if (ok && !sl.ev)
 			ok = hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming) == hipSuccess;
@@ -329,7 +346,7 @@ static int pull_common(trxhip_ctx *ctx, const void *d_iq, int cf32, const trxhip
 		}
 		if (ok) {
 			const int rc = trx_launch_pull4_nb(pool, d_iq, d_params, d_results, d_soft, ctx->d_tables, n_bursts, threshold, full_scale,
-							   ctx->n_cu, sl.d, static_cast<hipStream_t>(stream));
+							   ctx->n_cu, sl.d, sl.h_left, static_cast<hipStream_t>(stream));
 			if (rc == 0 && hipEventRecord(sl.ev, static_cast<hipStream_t>(stream)) == hipSuccess)
 				sl.busy = 1;
 			else if (rc == 0)

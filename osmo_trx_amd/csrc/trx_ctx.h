@@ -31,8 +31,13 @@ struct trxhip_ctx {
 	 * it last -- a slot is only handed out again (or re-allocated larger) once that event has completed. */
 	int nb_enabled;                    /* trxhip_set_nb_kernel(); default 1, 0 when TRXHIP_NO_NB_KERNEL is set at creation */
 	std::mutex redo_mu;
-	struct redo_slot { unsigned *d; size_t cap; hipEvent_t ev; int busy; } redo[4];
+	struct redo_slot { unsigned *d; size_t cap; hipEvent_t ev; int busy; unsigned *h_left; size_t n_last; } redo[4];
 	unsigned redo_next;
+	/* Feedback: the general kernel reports (into the slot's pinned word h_left) how many bursts the normal-burst kernel left it.
+	 * Read when the slot comes round again (its event has completed by then): a batch that left more than 1/32 of its bursts --
+	 * slots of other types the caller gave no hint about -- makes the next 63 eligible launches run the general kernel alone
+	 * (every left burst is read twice and stalls the first kernel's prefetch), then one launch probes again. */
+	unsigned split_backoff;
 };
 #define TRX_POOL_SLOTS 1024
 #define TRX_REDO_SLOTS 4

@@ -278,7 +278,7 @@ static int submit_slot(trxhip_hostpipe *p, int slot, size_t n, bool by_ref)
 		if (rc == TRXHIP_OK)
 			rc = trxhip_detect_demod_batch(p->ctx, d_bursts, d_params, sl.d_results, sl.d_soft, n, c.burst_len, c.sps,
 						       c.threshold, c.full_scale, p->dev_soft_stride,
-						       c.flags | (2 * n_nb < n ? TRXHIP_FLAG_FEW_NB_SLOTS : 0), st);
+						       c.flags | (32 * (n - n_nb) > n ? TRXHIP_FLAG_FEW_NB_SLOTS : 0), st);
 		if (rc == TRXHIP_OK && np > 1)                            /* :741, :751: rssi from the path average */
 			rc = trxhip_apply_diversity_power(p->ctx, sl.d_results, d_params, sl.d_avg, n, c.full_scale, st);
 	}

@@ -151,14 +151,17 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 	uint32_t l_word = 0u;
 	int l_q = 4;
 	unsigned long long l_mask = 0ull;
+	unsigned l_done = 0u;                                          // bursts this wave was handed
 	auto list_next = [&]() -> unsigned {
 		for (;;) {
 			if (l_mask != 0ull) {
 				const int ln = __ffsll((unsigned long long)l_mask) - 1;
 				l_mask &= l_mask - 1ull;
 				const unsigned bb = (l_chunk << 8) + 4u * (unsigned)ln + (unsigned)l_q;
-				if (bb < n_bursts)
+				if (bb < n_bursts) {
+					l_done++;
 					return bb;
+				}
 				continue;
 			}
 			if (++l_q < 4) {
@@ -200,6 +203,10 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 			if (threadIdx.x == 0) {
 				const unsigned d = __hip_atomic_fetch_add(redo + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
 				if (d == gridDim.x - 1u) {
+					if (pool_ctr)
+						__hip_atomic_store(pool_ctr, __hip_atomic_load(redo + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED,
+								   __HIP_MEMORY_SCOPE_SYSTEM);
+					__hip_atomic_store(redo + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 					__hip_atomic_store(redo, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 					__hip_atomic_store(redo + 1, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 				}
@@ -1170,13 +1177,20 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 			}
 		}
 	}
-	// LIST: the last workgroup to finish empties the list for the next launch that is handed it
+	// LIST: the last workgroup to finish re-arms the header for the next launch that is handed it and reports the number of bursts
+	// this launch worked through to the host (pool_ctr: in this form a word of pinned host memory; trx_ctx.h, split_backoff)
 	if (LIST) {
+		if (lane == 0 && l_done)
+			__hip_atomic_fetch_add(redo + 2, l_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		__syncthreads();
 		if (threadIdx.x == 0) {
 			// (every workgroup of the grid is counted: the ones that found nothing counted themselves when they left)
 			const unsigned d = __hip_atomic_fetch_add(redo + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
 			if (d == gridDim.x - 1u) {
+				if (pool_ctr)
+					__hip_atomic_store(pool_ctr, __hip_atomic_load(redo + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED,
+							   __HIP_MEMORY_SCOPE_SYSTEM);
+				__hip_atomic_store(redo + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				__hip_atomic_store(redo, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				__hip_atomic_store(redo + 1, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 			}
@@ -1218,7 +1232,7 @@ extern "C" int trx_unit_masks_match(const trx_tables *t)
 // fused demodulator, sliced rows of 148 soft bits, tables with the unit / symmetric / FAST structure.
 extern "C" int trx_launch_pull4_nb(unsigned *d_pool_ctr, const void *d_iq, const trxhip_burst_params *d_params,
 				   trxhip_burst_result *d_results, float *d_soft, const trx_tables *d_tab, size_t n_bursts,
-				   float thresh, float full_scale, int n_cu, unsigned *d_redo, hipStream_t stream)
+				   float thresh, float full_scale, int n_cu, unsigned *d_redo, unsigned *h_left, hipStream_t stream)
 {
 	if (n_bursts == 0)
 		return 0;
@@ -1238,7 +1252,7 @@ extern "C" int trx_launch_pull4_nb(unsigned *d_pool_ctr, const void *d_iq, const
 		TRX_ARM_DYNAMIC_LDS(k);
 		const size_t lds = K4_TABLES_BYTES + (size_t)K4_WPB(false, false) * K4_SLICE * sizeof(c32) + K4_LDS_TAIL;
 		hipLaunchKernelGGL(k, dim3((unsigned)n_cu), dim3(K4_WPB(false, false) * WAVE), lds, stream, d_iq, d_params, d_results, d_soft, d_tab,
-				   (const float4 *)nullptr, (unsigned)n_bursts, 625, thresh, full_scale, 148, TRXHIP_FLAG_SLICE, (unsigned *)nullptr, d_redo);
+				   (const float4 *)nullptr, (unsigned)n_bursts, 625, thresh, full_scale, 148, TRXHIP_FLAG_SLICE, h_left, d_redo);
 	}
 	return hipGetLastError() == hipSuccess ? 0 : TRXHIP_EIO;
 }

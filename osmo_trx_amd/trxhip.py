@@ -31,12 +31,12 @@ SCH_DETECT_FULL, SCH_DETECT_NARROW, SCH_DETECT_BUFFER = 0, 1, 2   # sch_detect_t
 
 
 def few_nb_hint(host_params):
-    """TRXHIP_FLAG_FEW_NB_SLOTS when fewer than half of the slots of `host_params` (PARAMS_DTYPE[n], or None: no hint) are
+    """TRXHIP_FLAG_FEW_NB_SLOTS when more than 1/32 of the slots of `host_params` (PARAMS_DTYPE[n], or None: no hint) are NOT
     normal-burst slots the normal-burst kernel takes (type TSC = 1, tsc < 8, max_toa <= 32)."""
     if host_params is None or len(host_params) == 0:
         return 0
     nb = (host_params["type"] == 1) & (host_params["tsc"] < 8) & (host_params["max_toa"] <= 32)
-    return FLAG_FEW_NB_SLOTS if 2 * int(nb.sum()) < len(host_params) else 0
+    return FLAG_FEW_NB_SLOTS if 32 * (len(host_params) - int(nb.sum())) > len(host_params) else 0
 
 
 class TrxHipError(RuntimeError):

@@ -130,3 +130,28 @@ def test_concurrent_streams_and_threads(trx):
     for k in range(2):
         for res, soft in out[k]:
             assert torch.equal(res, ref_res) and torch.equal(soft, ref_soft)
+
+
+def test_hint_and_feedback_never_change_results(trx):
+    """TRXHIP_FLAG_FEW_NB_SLOTS (host_params given) and the library's own feedback -- a context that was left more than 1/32 of a
+    batch runs the general kernel alone for a while -- choose between kernels that give the same bits: an access-burst batch and
+    the 7:1 mix, hinted and unhinted, repeated so that the unhinted context passes through probe -> back-off -> probe."""
+    n = 65536
+    mixed = synth.make_mixed_bursts(n, "cpu")
+    rach = synth.make_access_bursts(n, "cpu", seed=91)[:2]
+    nb = synth.make_normal_bursts(n, "cpu", 4, seed=92)[:2]
+    t2 = TrxHip(0)                                                  # a fresh context: its feedback state starts empty
+    try:
+        for iq, params in (mixed, rach, nb, mixed):
+            d_iq, d_p = iq.to("cuda:0"), t2.params_tensor(params)
+            t2.set_nb_kernel(False)
+            ref_res, ref_soft = t2.detect_demod(d_iq, d_p, sps=4)
+            torch.cuda.synchronize()
+            t2.set_nb_kernel(True)
+            for k in range(70):                                     # > 4 slots + 63 back-off launches + a probe
+                res, soft = t2.detect_demod(d_iq, d_p, sps=4, host_params=params if k % 7 == 3 else None)
+                if k % 10 == 0 or k > 66:
+                    torch.cuda.synchronize()
+                    assert torch.equal(res, ref_res) and torch.equal(soft, ref_soft), k
+    finally:
+        t2.close()

@@ -18,9 +18,11 @@ for name, (iq, params) in sets.items():
     out = []
     for split in (True, False):
         trx.set_nb_kernel(split)
-        for _ in range(3):
-            trx.detect_demod(iq, d_p, sps=4, results=res, soft=soft, host_params=params)
-        torch.cuda.synchronize()
+        tw = time.perf_counter()
+        while time.perf_counter() - tw < 1.0:                       # settle the clocks (the first launches of a process run slow)
+            for _ in range(20):
+                trx.detect_demod(iq, d_p, sps=4, results=res, soft=soft, host_params=params)
+            torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
             trx.detect_demod(iq, d_p, sps=4, results=res, soft=soft, host_params=params)
