@@ -196,10 +196,11 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 		pre_prm = reinterpret_cast<const uint32_t *>(params)[2 * (size_t)bb];
 		const uint32_t *src = iq + (size_t)bb * 625;
 #pragma unroll
-		for (int r = 0; r < NLD; r++) {
-			const int i = r * WAVE + lane;
-			pre_i[r] = (r < NLD - 1 || i < 625) ? __builtin_nontemporal_load(src + i) : 0u;   // read once: streaming
-		}
+		for (int r = 0; r < NLD - 1; r++)
+			pre_i[r] = __builtin_nontemporal_load(src + r * WAVE + lane);                  // read once: streaming
+		// the tenth row has 49 words: lanes 49..63 re-read word 624 (never stored to the LDS).  An exec-masked load behind a
+		// "v_mov 0" made the compiler wait for vmcnt(0) -- the nine loads just issued -- in front of the v_mov (measured: -4 %)
+		pre_i[NLD - 1] = __builtin_nontemporal_load(src + (NLD - 1) * WAVE + min(lane, 48));
 	};
 	// items j < 16 * my_groups of the static range exist for every workgroup of a launch the launcher sizes (>= 1 group each)
 	const unsigned b_first = burst_of((unsigned)wave);
@@ -356,6 +357,12 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 						epart = fmaf(v.x, v.x, fmaf(v.y, v.y, epart));
 				}
 			}
+		} else {
+			// the prefetched samples are dropped, but they must be "used": a path that reaches the next prefetch with loads
+			// the compiler still counts as outstanding makes it wait for vmcnt(0) right behind the new loads (measured: -4 %)
+#pragma unroll
+			for (int r = 0; r < NLD; r++)
+				asm volatile("" :: "v"(pre_i[r]));
 		}
 		// ---- the previous burst's output: 148 soft bits (lanes 0..47: symbols 4 + 3 lane + j as one 12-byte store, lanes
 		// 52..55: symbols 0..3) and the result record (lanes 0..7)

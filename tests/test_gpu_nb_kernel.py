@@ -37,6 +37,8 @@ def assert_identical(trx, res_a, soft_a, res_b, soft_b):
         same = (a[k] == b[k]) | ((a[k] != a[k]) & (b[k] != b[k])) if a[k].dtype.kind == "f" else (a[k] == b[k])
         assert same.all(), (k, np.flatnonzero(~same)[:8], a[k][~same][:8], b[k][~same][:8])
     assert torch.equal(soft_a, soft_b), np.flatnonzero((soft_a != soft_b).any(dim=1).cpu().numpy())[:8]
+    # and as bytes: the sign of a zero TOA, the payload of a NaN
+    assert torch.equal(res_a, res_b), np.flatnonzero((res_a != res_b).any(dim=1).cpu().numpy())[:8]
 
 
 @pytest.mark.parametrize("n", [1, 15, 16, 17, 1000, 4096, 70001])
@@ -142,7 +144,7 @@ def test_hint_and_feedback_never_change_results(trx):
     nb = synth.make_normal_bursts(n, "cpu", 4, seed=92)[:2]
     t2 = TrxHip(0)                                                  # a fresh context: its feedback state starts empty
     try:
-        for iq, params in (mixed, rach, nb, mixed):
+        for w, (iq, params) in enumerate((mixed, rach, nb, mixed)):
             d_iq, d_p = iq.to("cuda:0"), t2.params_tensor(params)
             t2.set_nb_kernel(False)
             ref_res, ref_soft = t2.detect_demod(d_iq, d_p, sps=4)
@@ -152,6 +154,10 @@ def test_hint_and_feedback_never_change_results(trx):
                 res, soft = t2.detect_demod(d_iq, d_p, sps=4, host_params=params if k % 7 == 3 else None)
                 if k % 10 == 0 or k > 66:
                     torch.cuda.synchronize()
-                    assert torch.equal(res, ref_res) and torch.equal(soft, ref_soft), k
+                    if not (torch.equal(res, ref_res) and torch.equal(soft, ref_soft)):
+                        rows = np.flatnonzero((res != ref_res).any(dim=1).cpu().numpy())
+                        srows = np.flatnonzero((soft != ref_soft).any(dim=1).cpu().numpy())
+                        raise AssertionError((w, k, len(rows), rows[:8], params["type"][rows[:8]], len(srows), srows[:8],
+                                              t2.results_to_numpy(res)[rows[:4]], t2.results_to_numpy(ref_res)[rows[:4]]))
     finally:
         t2.close()

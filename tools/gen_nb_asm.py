@@ -716,6 +716,7 @@ def block_tail():
     b("s_cselect_b32 s96, s97, s96")
     b("s_lshl_b32 s96, s96, 3")
     b("v_add_u32_e32 v64, s96, %[vd]")                             # &D[rt + lane]: sample ps + lane, ps = start + 1 - N + rt
+    b("s_sub_u32 s96, 0, s87")                                     # -nk (negated as an integer: a TOA of zero is +0.0 like a - a)
     b("s_waitcnt lgkmcnt(0)")
     # ---- every lane: amp = peak / gain (:1701), 1 / amp, the output stage's multiplier VP
     b("v_mul_f32_e32 v82, %[xr], v70")                             # peak * (1 / gain): Complex.h:74
@@ -746,10 +747,10 @@ def block_tail():
     b("v_mul_f32_e64 v76, %[xi], %[xi]")
     b("v_mul_f32_e64 v77, %[xr], %[xr]")
     b("v_mov_b32_e32 v79, %[es]")
-    b("v_cvt_f32_i32_e32 v78, %[toa]")
+    b("v_cvt_f32_i32_e32 v78, s96")
     b("v_add_f32_e32 v76, v76, v77")                               # |peak|^2
     b(f"v_mul_f32_e32 v79, {fhex(0.0125)}, v79")                   # energyDetect(burst, 20 * sps): / 80
-    b("v_mul_f32_e32 v78, 0x3b000000, v78")                        # position (exact)
+    b("v_mul_f32_e32 v78, 0x3b000000, v78")                        # toa = -nk / 512: position - sync->toa (:1704) - head (:1768), exact
     b("v_log_f32_e32 v80, v79")
     b("s_waitcnt lgkmcnt(0)")
     b("v_pk_mul_f32 v[66:67], v[66:67], v[66:67]")
@@ -758,21 +759,19 @@ def block_tail():
     b("v_sub_f32_e32 v80, %[fsdb], v80")                           # rssi
     b("v_mul_f32_e32 v88, v76, v75")                               # C
     b(f"v_add_f32_dpp v81, v81, v81 quad_perm:[1,0,3,2] {D_ALL}")
-    b("v_sub_f32_e32 v78, v78, v73")                               # - sync->toa (:1704)
     b("v_mov_b32_e32 %[rec], 1")
-    b(f"v_add_f32_dpp v81, v81, v81 quad_perm:[2,3,0,1] {D_ALL}")
-    b("v_add_f32_e32 v78, 0xc1200000, v78")                        # - head (:1768)
     b("s_mov_b64 s[98:99], 4")
-    b(f"v_add_f32_dpp v81, v81, v81 row_half_mirror {D_ALL}")
+    b(f"v_add_f32_dpp v81, v81, v81 quad_perm:[2,3,0,1] {D_ALL}")
     b("v_cndmask_b32_e64 %[rec], %[rec], v86, s[98:99]")
     b("s_mov_b64 s[98:99], 8")
-    b(f"v_add_f32_dpp v81, v81, v81 row_mirror {D_ALL}")
+    b(f"v_add_f32_dpp v81, v81, v81 row_half_mirror {D_ALL}")
     b("v_cndmask_b32_e64 %[rec], %[rec], v87, s[98:99]")
     b("s_mov_b64 s[98:99], 2")
-    b("v_mul_f32_e32 v81, 0x3d800000, v81")                        # S = sum / 16 (row 0)
+    b(f"v_add_f32_dpp v81, v81, v81 row_mirror {D_ALL}")
     b("v_cndmask_b32_e64 %[rec], %[rec], v78, s[98:99]")
-    b("v_readlane_b32 s97, v81, 0")
+    b("v_mul_f32_e32 v81, 0x3d800000, v81")                        # S = sum / 16 (row 0)
     b("s_mov_b64 s[98:99], 32")
+    b("v_readlane_b32 s97, v81, 0")
     b("v_cndmask_b32_e64 %[rec], %[rec], v79, s[98:99]")
     b("s_mov_b64 s[98:99], 64")
     b("v_sub_f32_e32 v94, s97, v88")                               # S - C
