@@ -154,6 +154,7 @@ int trxhip_create_from_tables(trxhip_ctx **out, int device, const void *h_blob, 
 		ctx->redo[i].n_last = 0;
 	}
 	ctx->split_backoff = 0;
+	ctx->no_backoff = getenv("TRXHIP_NO_BACKOFF") ? 1 : 0;         /* measurement switch: the split path whatever it leaves */
 	ctx->no_sym = 0;                                           /* the straight-line decimator reads taps 0..7 and mirrors them */
 	for (int k = 0; k < 8; k++)
 		if (memcmp(&t->dec_taps[k], &t->dec_taps[15 - k], sizeof(float)) != 0)
@@ -316,7 +317,7 @@ static int pull_common(trxhip_ctx *ctx, const void *d_iq, int cf32, const trxhip
 			ok = hipEventSynchronize(sl.ev) == hipSuccess;
 			sl.busy = 0;
 			if (ok && sl.h_left && sl.n_last && (size_t)*reinterpret_cast<volatile unsigned *>(sl.h_left) * 32 > sl.n_last)
-				ctx->split_backoff = 63;
+				ctx->split_backoff = ctx->no_backoff ? 0 : 63;
 		}
 		if (ok && !sl.h_left)
 			ok = hipHostMalloc(reinterpret_cast<void **>(&sl.h_left), 64, hipHostMallocDefault) == hipSuccess;

@@ -38,6 +38,7 @@ struct trxhip_ctx {
 	 * slots of other types the caller gave no hint about -- makes the next 63 eligible launches run the general kernel alone
 	 * (every left burst is read twice and stalls the first kernel's prefetch), then one launch probes again. */
 	unsigned split_backoff;
+	int no_backoff;                    /* TRXHIP_NO_BACKOFF at creation: measurement switch */
 };
 #define TRX_POOL_SLOTS 1024
 #define TRX_REDO_SLOTS 4

@@ -178,6 +178,16 @@ __device__ __forceinline__ int claim_take(int ticket)
 	return __builtin_amdgcn_readfirstlane(ticket);
 }
 
+// the same when exactly >= N LDS instructions (and no scalar load) were issued behind claim_issue() on EVERY path that reaches
+// the call: the LDS answers in order, so the ticket has arrived once at most N operations are outstanding -- the writes behind
+// it need not have drained.  (N above the real count would return before the ticket has arrived: callers state a lower bound.)
+template <int N>
+__device__ __forceinline__ int claim_take_behind(int ticket)
+{
+	asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(ticket) : "n"(N) : "memory");
+	return __builtin_amdgcn_readfirstlane(ticket);
+}
+
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp(float v)
 {

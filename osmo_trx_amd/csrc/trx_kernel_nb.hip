@@ -40,6 +40,7 @@
 
 
 typedef float v3f __attribute__((ext_vector_type(3)));
+typedef int v4i __attribute__((ext_vector_type(4)));
 
 // byte address of an LDS object (what the ds_* instructions of the asm blocks take)
 template <typename T>
@@ -195,12 +196,15 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 	auto prefetch = [&](unsigned bb, int lane) {
 		pre_prm = reinterpret_cast<const uint32_t *>(params)[2 * (size_t)bb];
 		const uint32_t *src = iq + (size_t)bb * 625;
+		// (unsigned lane: the offset zero-extends, the loads take the scalar-base form -- no 64-bit vector address whose
+		// high half the compiler would build in one of the destination registers, with a wait for vmcnt(0) in front)
+		const unsigned ul = (unsigned)lane & 63u;
 #pragma unroll
 		for (int r = 0; r < NLD - 1; r++)
-			pre_i[r] = __builtin_nontemporal_load(src + r * WAVE + lane);                  // read once: streaming
+			pre_i[r] = __builtin_nontemporal_load(src + (unsigned)(r * WAVE) + ul);        // read once: streaming
 		// the tenth row has 49 words: lanes 49..63 re-read word 624 (never stored to the LDS).  An exec-masked load behind a
 		// "v_mov 0" made the compiler wait for vmcnt(0) -- the nine loads just issued -- in front of the v_mov (measured: -4 %)
-		pre_i[NLD - 1] = __builtin_nontemporal_load(src + (NLD - 1) * WAVE + min(lane, 48));
+		pre_i[NLD - 1] = __builtin_nontemporal_load(src + (unsigned)((NLD - 1) * WAVE) + min(ul, 48u));
 	};
 	// items j < 16 * my_groups of the static range exist for every workgroup of a launch the launcher sizes (>= 1 group each)
 	const unsigned b_first = burst_of((unsigned)wave);
@@ -211,8 +215,39 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 	v3f o = { 0.0f, 0.0f, 0.0f };
 	int recw = 0;
 	bool pend_any = false;
+	bool pend_rec = false;                                         // recw holds the pending burst's record (a slot without a burst)
 	unsigned pend_b = 0;
 	bool left_any = false;
+	// ---- the records of detected bursts are made 64 at a time: what computeCI / amp / toa / RSSI need of burst k of the batch
+	// goes into lane k of these registers (seven moves under a one-lane mask), flush_records() does the arithmetic once per lane -- the same
+	// operations in the same order as block TAIL did per burst on a wave-uniform value (two logarithms and two reciprocals
+	// at a quarter of the rate among them), and one 32-byte store per record
+	int q_xr = 0, q_xi = 0, q_es = 0, q_toa = 0, q_s = 0, q_fl = 0, q_b = 0;
+	int q_n = 0;
+	auto flush_records = [&](const int lane) {
+		if (lane < q_n) {
+			const float *const h = lhdr + 8 * (q_fl & 0xff);        // {gain, 1 / gain, ci_den, toa, n, 1 / ci_den} of the slot's sequence
+			const float xr = __int_as_float(q_xr), xi = __int_as_float(q_xi);
+			const float a0 = xr * h[2], a1 = xr * h[3], a2 = xi * h[3], a3 = xi * h[2];
+			const float amp_re = a0 - a2, amp_im = a1 + a3;         // amp = peak / gain (:1701): peak * (1 / gain), Complex.h:74
+			const float toa = (float)q_toa * 0.001953125f;          // position - sync->toa (:1704) - head (:1768): exact in 1/512
+			const float energy = __int_as_float(q_es) * 0.0125f;    // energyDetect(burst, 20 * sps): / 80
+			const float rssi = fs_db - 3.01029996f * __log2f(energy);
+			const float p2 = xi * xi + xr * xr;
+			const float C = p2 * h[7];                              // |peak|^2 / ci_den (:1633), table: RN(1 / ci_den)
+			const float S = __int_as_float(q_s);
+			const float ci = 3.0103f * __log2f(C * __builtin_amdgcn_rcpf(S - C));   // (:1637)
+			// (stores the compiler does not see, like every other store of the loop: with its own stores outstanding across the
+			// loop's back edge it waits for vmcnt(0) -- the soft bits just stored -- in front of the next prefetch; measured: -3 %)
+			const v4i r0 = { 1, __float_as_int(toa), __float_as_int(amp_re), __float_as_int(amp_im) };
+			const v4i r1 = { __float_as_int(ci), __float_as_int(energy), __float_as_int(rssi), q_fl };
+			asm volatile("global_store_dwordx4 %0, %1, off\n\t"
+				     "global_store_dwordx4 %0, %2, off offset:16\n\t"
+				     "s_nop 1"
+				     :: "v"(results + (unsigned)q_b), "v"(r0), "v"(r1) : "memory");
+		}
+		q_n = 0;
+	};
 
 	// ---- cold: demodGmskBurst for a TOA outside the straight-line geometry (shift w = nk >> 7 above 0: an early burst; below -36:
 	// later than 9 symbols).  The general kernel's fused demodulator (trx_kernel4.hip, "FUSED": same sums, same order -- the
@@ -345,6 +380,11 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 		// ---- phase 0: registers -> fp32 polyphase LDS; clip scan and energyDetect partial sums on the fly
 		c32 *const pload = P + (lane & 3) * PH_A + PH_M0 + (lane >> 2);
 		float amax = 0.0f, epart = 0.0f;
+#ifdef TRX_DIAG
+		DIAG_MARK(12);                                              // (loop top: mbcnt, ticket issue, slot type)
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		DIAG_MARK(13);                                              // the prefetched samples' arrival, apart from their conversion
+#endif
 		if (!leave) {
 #pragma unroll
 			for (int r = 0; r < NLD; r++) {
@@ -364,6 +404,7 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 			for (int r = 0; r < NLD; r++)
 				asm volatile("" :: "v"(pre_i[r]));
 		}
+		DIAG_MARK(14);
 		// ---- the previous burst's output: 148 soft bits (lanes 0..47: symbols 4 + 3 lane + j as one 12-byte store, lanes
 		// 52..55: symbols 0..3) and the result record (lanes 0..7)
 		if (pend_any) {
@@ -374,20 +415,26 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 				     "global_store_dwordx3 %0, %1, %2 offset:16\n\t"
 				     "s_bfm_b64 exec, 4, 52\n\t"
 				     "global_store_dword %3, %4, %2\n\t"
-				     "s_bfm_b64 exec, 8, 0\n\t"
+				     "s_mov_b64 exec, %8\n\t"
 				     "global_store_dword %5, %6, %7\n\t"
 				     "s_mov_b64 exec, -1\n\t"
 				     "s_nop 0"
-				     :: "v"(lane * 12), "v"(o), "s"(so), "v"(((-lane) & 3) * 4), "v"(oe), "v"(lane * 4), "v"(recw), "s"(rp)
+				     :: "v"(lane * 12), "v"(o), "s"(so), "v"(((-lane) & 3) * 4), "v"(oe), "v"(lane * 4), "v"(recw), "s"(rp),
+				        "s"(pend_rec ? 0xffull : 0ull)
 				     : "memory");
 		}
 		pend_any = false;
-		j_next = (unsigned)claim_take(ticket);
+		DIAG_MARK(16);
+		// (a converted burst has at least five LDS writes behind the ticket's request -- ten rows, at most two per instruction --
+		// and nothing else on lgkmcnt: the ticket is there when five are outstanding, the writes drain under the next block)
+		j_next = (unsigned)(leave ? claim_take(ticket) : claim_take_behind<5>(ticket));
 		b_next = burst_of(j_next);
 		if (pooled && (j_next & 15u) == 0u && j_next + 16u >= items)
 			pool_draw(j_next, b_next == NB_NO_BURST && j_next >= items, lane);
+		DIAG_MARK(17);
 		if (b_next != NB_NO_BURST)
 			prefetch(b_next, lane);
+		DIAG_MARK(15);
 
 		int clip = 0;
 		if (!leave) {
@@ -405,6 +452,7 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 				     : [bad] "=s"(bad)
 				     : [pd] "v"(lds_addr(P + PH_M0 + 52) + 8u * (unsigned)lane), [vd] "v"(vd_addr), [zero] "v"(0), [nact] "s"(15 + len)
 				     : NB_ASM_CLOBBERS);
+			DIAG_MARK(2);
 			{
 				// ---- correlation (lane = lag; the twelve lanes behind the window store the right zero pad), arg-max and the
 				// energyDetect sum (:1573-1585); the lane constants of the TOA search are fetched in the reductions' wait states
@@ -413,6 +461,7 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 					     : [nrm] "=&v"(v)
 					     : [vd] "v"(vd_addr), [vcz] "v"(vcz_addr), [len] "s"(len), [tsc] "s"(tsc), [bad] "s"(bad)
 					     : NB_ASM_CLOBBERS);
+				DIAG_MARK(3);
 				int m_bits, es_bits, bidx;
 				int kr, ka, kb, kic, ktp;                                   // lane constants (lcn[])
 				asm volatile(NB_ASM_AMAX("ds_read_b32 %[kr], %[l4] offset:%c[lc]", "ds_read_b32 %[ka], %[l4] offset:%c[lc]+256",
@@ -424,6 +473,7 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 					     : [nrm] "v"(v), [ep] "v"(epart), [l4] "v"(4 * lane),
 					       [lc] "n"((TRX_SINCV_LDS + 16 * WAVE + NB_COMP_ROWS * 36 + 16 + 64 + 5 * WAVE) * 4)
 					     : NB_ASM_CLOBBERS);
+				DIAG_MARK(4);
 				int hit = 0;
 				int toa512 = 0;
 				if (m_bits != 0) {                                          // fastPeakDetect: a maximum above zero exists (:1120-1139)
@@ -435,12 +485,14 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 						     : [bidx] "s"(bidx), [len] "s"(len), [czb] "s"(lds_addr(cz)), [kr] "v"(kr), [ka] "v"(ka), [l16] "v"(16 * lane),
 						       [k5] "s"(gk5), [k6] "s"(gk6), [k7] "s"(gk7), [k8] "s"(gk8), [c0] "v"(gc0)
 						     : NB_ASM_CLOBBERS);
+					DIAG_MARK(5);
 					int xr_bits = 0, xi_bits = 0;
 					if (st == 1) {
 						asm volatile(NB_ASM_DETB
 							     : [st] "=&s"(st), [toa] "=&s"(toa512), [xr] "=&s"(xr_bits), [xi] "=&s"(xi_bits)
 							     : [e] "s"(e512), [kb] "v"(kb), [czb] "s"(lds_addr(cz)), [km] "v"(km)
 							     : NB_ASM_CLOBBERS);
+						DIAG_MARK(6);
 					}
 					if (st == 3) {
 						// an uncertified early / late decision on the path: the search again in the reference's operand order
@@ -463,26 +515,45 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 					if (st == 1) {
 						// computeCI, amp, toa, the result record, 1 / amp; then demodGmskBurst of the usual geometry (TAIL)
 						hit = 1;
-						int ok;
+						int ok, s_bits;
 						float d0, d1, d2;
 						const int t5 = (t5pk << (28 - 4 * tsc)) >> 28;
-						const uint32_t flags = (uint32_t)tsc | ((uint32_t)clip << 8) | (37u << 24);
 						asm volatile(NB_ASM_TAIL
-							     : [ok] "=&s"(ok), [rec] "=&v"(recw), [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2)
+							     : [ok] "=&s"(ok), [ssum] "=&s"(s_bits), [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2)
 							     : [toa] "s"(toa512), [xr] "s"(xr_bits), [xi] "s"(xi_bits), [t5] "s"(t5), [hdrb] "s"(lds_addr(lhdr) + 32u * (unsigned)tsc),
-							       [e8lo] "s"((unsigned)e8_addr), [e8hi] "s"((unsigned)(e8_addr >> 32)), [es] "s"(es_bits), [fsdb] "s"(unif(fs_db)),
-							       [flags] "s"(flags), [l16] "v"(16 * lane),
+							       [e8lo] "s"((unsigned)e8_addr), [e8hi] "s"((unsigned)(e8_addr >> 32)), [l16] "v"(16 * lane),
 							       [vd] "v"(vd_addr), [pb] "s"(lds_addr(P)), [cb] "s"(lds_addr(comp) + 4u * (K4_U0 + TRX_FUSED_SH)), [db] "s"(lds_addr(D)),
 							       [kic] "v"(kic), [ktp] "v"(ktp)
 							     : NB_ASM_CLOBBERS);
+						DIAG_MARK(10);
 						if (!ok) {
 							// TOA outside the straight-line geometry (an early burst, or one later than 9 symbols): the general form
 							if (lane == 0) atomicAdd(&g_trx_fast_stats[3], 1ull);
-							const c32 ampv = make_float2(__int_as_float(__builtin_amdgcn_readlane(recw, 2)),
-										     __int_as_float(__builtin_amdgcn_readlane(recw, 3)));
+							const float *const h = lhdr + 8 * tsc;
+							const float xr = __int_as_float(xr_bits), xi = __int_as_float(xi_bits);
+							const float a0 = xr * h[2], a1 = xr * h[3], a2 = xi * h[3], a3 = xi * h[2];
+							const c32 ampv = make_float2(unif(a0 - a2), unif(a1 + a3));     // amp = peak / gain, as block TAIL has it
 							if (!demod_general(t5 + 10 * 512 - toa512, ampv, lane))
 								leave = true;
-						} else {
+						}
+						if (!leave) {
+							// the record's inputs: lane q_n of the seven registers (toa in 1/512 symbol: position - sync->toa - head)
+							asm("s_lshl_b64 exec, 1, %[n]\n\t"
+						    "v_mov_b32_e32 %[qxr], %[xr]\n\t"
+						    "v_mov_b32_e32 %[qxi], %[xi]\n\t"
+						    "v_mov_b32_e32 %[qes], %[es]\n\t"
+						    "v_mov_b32_e32 %[qtoa], %[toa]\n\t"
+						    "v_mov_b32_e32 %[qs], %[ss]\n\t"
+						    "v_mov_b32_e32 %[qfl], %[fl]\n\t"
+						    "v_mov_b32_e32 %[qb], %[b]\n\t"
+						    "s_mov_b64 exec, -1"
+						    : [qxr] "+v"(q_xr), [qxi] "+v"(q_xi), [qes] "+v"(q_es), [qtoa] "+v"(q_toa), [qs] "+v"(q_s), [qfl] "+v"(q_fl),
+						      [qb] "+v"(q_b)
+						    : [n] "s"(uni(q_n)), [xr] "s"(xr_bits), [xi] "s"(xi_bits), [es] "s"(es_bits), [toa] "s"(toa512 - t5 - 10 * 512),
+						      [ss] "s"(s_bits), [fl] "s"((int)((uint32_t)tsc | ((uint32_t)clip << 8) | (37u << 24))), [b] "s"((int)b));
+						q_n++;
+						}
+						if (ok) {
 							o.x = __builtin_amdgcn_fmed3f(fmaf(0.5f, d0, 0.5f), 0.0f, 1.0f);     // vectorSlicer: 0.5 * (x + 1), clamped (:546-556)
 							o.y = __builtin_amdgcn_fmed3f(fmaf(0.5f, d1, 0.5f), 0.0f, 1.0f);
 							o.z = __builtin_amdgcn_fmed3f(fmaf(0.5f, d2, 0.5f), 0.0f, 1.0f);
@@ -505,6 +576,7 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 					recw = word;
 					o = (v3f){ 0.0f, 0.0f, 0.0f };
 				}
+				pend_rec = !hit;
 			}
 		}
 		if (leave) {
@@ -521,6 +593,9 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 		}
 		pend_b = b;
 		pend_any = true;
+		if (q_n == WAVE)
+			flush_records(lane);
+		DIAG_MARK(11);
 	}
 	// ---- the last burst's output
 	if (pend_any) {
@@ -533,13 +608,20 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 			     "global_store_dwordx3 %0, %1, %2 offset:16\n\t"
 			     "s_bfm_b64 exec, 4, 52\n\t"
 			     "global_store_dword %3, %4, %2\n\t"
-			     "s_bfm_b64 exec, 8, 0\n\t"
+			     "s_mov_b64 exec, %8\n\t"
 			     "global_store_dword %5, %6, %7\n\t"
 			     "s_mov_b64 exec, -1\n\t"
 			     "s_nop 0"
-			     :: "v"(lane * 12), "v"(o), "s"(so), "v"(((-lane) & 3) * 4), "v"(oe), "v"(lane * 4), "v"(recw), "s"(rp)
+			     :: "v"(lane * 12), "v"(o), "s"(so), "v"(((-lane) & 3) * 4), "v"(oe), "v"(lane * 4), "v"(recw), "s"(rp),
+			        "s"(pend_rec ? 0xffull : 0ull)
 			     : "memory");
 	}
+	{
+		int lane;
+		asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+		flush_records(lane);                                       // the records still in the registers
+	}
+	DIAG_FLUSH();
 	if (pooled) {
 		__syncthreads();
 		int tid0;                                                   // (re-derived: not a mask kept in scalar registers since the prologue)

@@ -694,7 +694,7 @@ def block_detb():
 #   out: SGPR ok (0: TOA outside the straight-line geometry), nk; VGPR rows (4 registers), vp, rec
 # ------------------------------------------------------------------------------------------------------------------
 def block_tail():
-    b = Block("TAIL", ("toa", "xr", "xi", "t5", "hdrb", "e8lo", "e8hi", "es", "fsdb", "flags", "ok", "nk", "pb", "cb", "db"))
+    b = Block("TAIL", ("toa", "xr", "xi", "t5", "hdrb", "e8lo", "e8hi", "ok", "ssum", "pb", "cb", "db"))
     b("v_mov_b32_e32 v65, %[hdrb]")
     b("ds_read_b128 v[68:71], v65")                                # gain, 1 / gain
     b("s_sub_u32 s88, %[t5], %[toa]")
@@ -716,8 +716,10 @@ def block_tail():
     b("s_cselect_b32 s96, s97, s96")
     b("s_lshl_b32 s96, s96, 3")
     b("v_add_u32_e32 v64, s96, %[vd]")                             # &D[rt + lane]: sample ps + lane, ps = start + 1 - N + rt
-    b("s_sub_u32 s96, 0, s87")                                     # -nk (negated as an integer: a TOA of zero is +0.0 like a - a)
-    b("s_waitcnt lgkmcnt(0)")
+    b("s_bfm_b64 exec, 16, 0")
+    b("ds_read_b64 v[66:67], v64")                                 # computeCI's sixteen samples (:1608-1639)
+    b("s_mov_b64 exec, -1")
+    b("s_waitcnt lgkmcnt(1)")
     # ---- every lane: amp = peak / gain (:1701), 1 / amp, the output stage's multiplier VP
     b("v_mul_f32_e32 v82, %[xr], v70")                             # peak * (1 / gain): Complex.h:74
     b("v_mul_f32_e32 v83, %[xr], v71")
@@ -729,12 +731,6 @@ def block_tail():
     b("v_mul_f32_e32 v89, v87, v87")
     b("v_add_f32_e32 v89, v89, v90")                               # |amp|^2
     b("v_rcp_f32_e32 v89, v89")
-    # ---- sixteen lanes (the chip runs at its power limit: wave-uniform arithmetic does not need 64 of them): computeCI, toa,
-    # RSSI, the result record
-    b("s_bfm_b64 exec, 16, 0")
-    b("ds_read_b64 v[66:67], v64")
-    b("ds_read_b128 v[72:75], v65 offset:16")                      # ci_den, toa, n, 1 / ci_den
-    b("s_mov_b64 exec, -1")
     b("s_mov_b32 s88, 0xaaaaaaaa")
     b("s_mov_b32 s89, 0xaaaaaaaa")
     b("v_mul_f32_e32 v91, v86, v89")                               # 1 / amp = conj(amp) / |amp|^2 (Complex.h:75,144-150)
@@ -743,48 +739,8 @@ def block_tail():
     b("s_mov_b32 s88, 0xcccccccc")
     b("s_mov_b32 s89, 0xcccccccc")
     b("v_cndmask_b32_e64 v119, v119, -v119, s[88:89]")            # (lanes 2, 3 mod 4: negated)
-    b("s_bfm_b64 exec, 16, 0")
-    b("v_mul_f32_e64 v76, %[xi], %[xi]")
-    b("v_mul_f32_e64 v77, %[xr], %[xr]")
-    b("v_mov_b32_e32 v79, %[es]")
-    b("v_cvt_f32_i32_e32 v78, s96")
-    b("v_add_f32_e32 v76, v76, v77")                               # |peak|^2
-    b(f"v_mul_f32_e32 v79, {fhex(0.0125)}, v79")                   # energyDetect(burst, 20 * sps): / 80
-    b("v_mul_f32_e32 v78, 0x3b000000, v78")                        # toa = -nk / 512: position - sync->toa (:1704) - head (:1768), exact
-    b("v_log_f32_e32 v80, v79")
-    b("s_waitcnt lgkmcnt(0)")
-    b("v_pk_mul_f32 v[66:67], v[66:67], v[66:67]")
-    b(f"v_mul_f32_e32 v80, {fhex(3.01029996)}, v80")
-    b("v_add_f32_e32 v81, v67, v66")                               # |sample|^2
-    b("v_sub_f32_e32 v80, %[fsdb], v80")                           # rssi
-    b("v_mul_f32_e32 v88, v76, v75")                               # C
-    b(f"v_add_f32_dpp v81, v81, v81 quad_perm:[1,0,3,2] {D_ALL}")
-    b("v_mov_b32_e32 %[rec], 1")
-    b("s_mov_b64 s[98:99], 4")
-    b(f"v_add_f32_dpp v81, v81, v81 quad_perm:[2,3,0,1] {D_ALL}")
-    b("v_cndmask_b32_e64 %[rec], %[rec], v86, s[98:99]")
-    b("s_mov_b64 s[98:99], 8")
-    b(f"v_add_f32_dpp v81, v81, v81 row_half_mirror {D_ALL}")
-    b("v_cndmask_b32_e64 %[rec], %[rec], v87, s[98:99]")
-    b("s_mov_b64 s[98:99], 2")
-    b(f"v_add_f32_dpp v81, v81, v81 row_mirror {D_ALL}")
-    b("v_cndmask_b32_e64 %[rec], %[rec], v78, s[98:99]")
-    b("v_mul_f32_e32 v81, 0x3d800000, v81")                        # S = sum / 16 (row 0)
-    b("s_mov_b64 s[98:99], 32")
-    b("v_readlane_b32 s97, v81, 0")
-    b("v_cndmask_b32_e64 %[rec], %[rec], v79, s[98:99]")
-    b("s_mov_b64 s[98:99], 64")
-    b("v_sub_f32_e32 v94, s97, v88")                               # S - C
-    b("v_cndmask_b32_e64 %[rec], %[rec], v80, s[98:99]")
-    b("v_rcp_f32_e32 v94, v94")
-    b("v_writelane_b32 %[rec], %[flags], 7")
-    b("v_mul_f32_e32 v94, v88, v94")
-    b("s_mov_b64 s[98:99], 16")
-    b("v_log_f32_e32 v94, v94")
-    b("s_nop 0")
-    b(f"v_mul_f32_e32 v94, {fhex(3.0103)}, v94")                   # C/I, dB (:1637)
-    b("v_cndmask_b32_e64 %[rec], %[rec], v94, s[98:99]")
-    b("s_mov_b64 exec, -1")
+    # (the burst's record -- C/I, RSSI, amp, toa -- is not made here: its inputs go into lane `slot` of seven registers and 64
+    # records are made at once, trx_kernel_nb.hip flush_records; what is per burst is S, computeCI's mean sample power)
     block_demod(b)
     b("s_branch .Lnb_tl_end")
     b(".Lnb_tl_wait_end:")
@@ -805,30 +761,41 @@ def block_tail():
 #   out: VGPR d0 d1 d2: real((-j)^i z / amp) of the lane's three symbols (the slicer's input)
 # ------------------------------------------------------------------------------------------------------------------
 def block_demod(b):
-    # the straight-line geometry: shift w = nk >> 7 in -36 .. 0 (0 <= TOA <= 9 symbols); other bursts leave with ok = 0 -- record
-    # and 1 / amp are done -- and take the general form of the demodulator (trx_kernel_nb.hip, cold)
-    b("s_ashr_i32 s88, s87, 7")
-    b("s_sub_u32 s90, 0, s88")
-    b("s_cmp_gt_u32 s90, 36")
-    b("s_cbranch_scc1 .Lnb_tl_wait_end")
-    b("s_mov_b32 %[ok], 1")
+    # the straight-line geometry: shift w = nk >> 7 in -36 .. 0 (0 <= TOA <= 9 symbols); other bursts leave with ok = 0 -- 1 / amp
+    # and S are done -- and take the general form of the demodulator (trx_kernel_nb.hip, cold)
     ACC = [vreg(64 + 2 * j, 2) for j in range(3)]
     RING = lambda v: vreg(72 + 2 * (v & 15), 2)
     CQ = [104, 108]
     P = [112, 113, 114, 115]
-    b("s_ashr_i32 s88, s87, 7")                                  # w
+    # S = mean |sample|^2 of computeCI's sixteen samples (lanes 0..15: a tree sum), in the wait states of the address arithmetic
+    b("s_bfm_b64 exec, 16, 0")
+    b("s_waitcnt lgkmcnt(0)")
+    b("v_pk_mul_f32 v[66:67], v[66:67], v[66:67]")
+    b("s_ashr_i32 s88, s87, 7")                                    # w
+    b("v_add_f32_e32 v81, v67, v66")                               # |sample|^2
     b("s_and_b32 s89, s87, 127")
     b("s_lshr_b32 s90, s89, 1")
+    b(f"v_add_f32_dpp v81, v81, v81 quad_perm:[1,0,3,2] {D_ALL}")
     b("s_cmp_ge_u32 s89, 2")
     b("s_cselect_b32 s90, s90, 64")                                # fidx
+    b(f"v_add_f32_dpp v81, v81, v81 quad_perm:[2,3,0,1] {D_ALL}")
     b("s_sub_u32 s91, -18, s88")                                   # c = -24 - w + U0: tap U0 of symbol i reads sample 4 i + c
     b("s_and_b32 s92, s91, 3")                                     # ph0
+    b(f"v_add_f32_dpp v81, v81, v81 row_half_mirror {D_ALL}")
     b("s_ashr_i32 s93, s91, 2")
     b("s_mul_i32 s94, s92, 180")
+    b(f"v_add_f32_dpp v81, v81, v81 row_mirror {D_ALL}")
     b("s_add_u32 s94, s94, s93")
     b("s_lshl3_add_u32 s94, s94, %[pb]")                           # &P[ph0][m = c >> 2] - 12 entries
+    b("v_mul_f32_e32 v81, 0x3d800000, v81")                        # S = sum / 16 (row 0)
     b("s_mul_i32 s95, s90, 144")
     b("s_add_u32 s95, s95, %[cb]")                                 # composite row of the burst's delay filter, from tap U0
+    b("v_readlane_b32 %[ssum], v81, 0")
+    b("s_mov_b64 exec, -1")
+    b("s_sub_u32 s96, 0, s88")
+    b("s_cmp_gt_u32 s96, 36")
+    b("s_cbranch_scc1 .Lnb_tl_wait_end")
+    b("s_mov_b32 %[ok], 1")
     b(f"v_add_u32_e32 {vreg(P[0])}, s94, %[kic]")
     for k in range(1, 4):
         # p[k] = p[0] + (k * PH_A + ((ph0 + k) >> 2) * (1 - 4 * PH_A)) entries

@@ -12,5 +12,5 @@ d_p = trx.params_tensor(params)
 res = torch.empty((n, 32), dtype=torch.uint8, device="cuda:0")
 soft = torch.empty((n, 148), dtype=torch.float32, device="cuda:0")
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 20):
-    trx.detect_demod(iq, d_p, sps=4, results=res, soft=soft, host_params=params)
+    trx.detect_demod(iq, d_p, sps=4, results=res, soft=soft, host_params=None if os.environ.get('NOHINT') else params)
 torch.cuda.synchronize()
