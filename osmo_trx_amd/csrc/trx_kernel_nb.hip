@@ -121,8 +121,10 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 	}
 	for (int i = lane0; i < NB_SLICE; i += WAVE)
 		wbase[i] = make_float2(0.0f, 0.0f);
-	if (threadIdx.x == 0)
-		*wg_next = NB_WPB;
+	if (threadIdx.x == 0) {
+		wg_next[0] = NB_WPB;
+		wg_next[1] = 0;                                             // the epilogue's election
+	}
 	if (threadIdx.x < NB_POOL_RING)
 		pool_g[threadIdx.x] = NB_POOL_UNSET;
 	__syncthreads();
@@ -626,7 +628,9 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 		__syncthreads();
 		int tid0;                                                   // (re-derived: not a mask kept in scalar registers since the prologue)
 		asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(tid0));
-		if (tid0 == 0 && wave == 0) {
+		// one wave of the workgroup -- whichever reaches the LDS counter first; the wave's index is not kept in a scalar
+		// register through the burst loop for this
+		if (tid0 == 0 && atomicAdd(wg_next + 1, 1) == 0) {
 			const unsigned d = __hip_atomic_fetch_add(pool_ctr + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
 			if (d == gridDim.x - 1u) {
 				__hip_atomic_store(pool_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -242,10 +242,12 @@ class TrxHip:
     # ---- hot path ------------------------------------------------------------------------------
     def detect_demod(self, iq, params, sps=4, threshold=4.0, full_scale=32767.0, soft_stride=148, slice_bits=True,
                      results=None, soft=None, stream=None, want_soft=True, exact=False, idle_dummy=False, _diag_mask=0,
-                     host_params=None):
+                     host_params=None, hint=None):
         """iq: int16[n, burst_len, 2] or complex64[n, burst_len] (device).  params: uint8[n, 8] (device).
         host_params: the caller's host copy of the parameters (PARAMS_DTYPE[n]), if it has one: the slot types decide the
         TRXHIP_FLAG_FEW_NB_SLOTS hint (a batch with few normal-burst slots runs the general kernel alone; results do not change).
+        hint: that flag already worked out (few_nb_hint(host_params): a pass over the host array, a few milliseconds for a million
+        slots -- a caller that launches the same slot table again and again computes it once).
         Returns (results uint8[n, 32], soft float32[n, soft_stride]) device tensors."""
         torch = self.torch
         n = iq.shape[0]
@@ -269,7 +271,7 @@ class TrxHip:
         rc = fn(self.h, ip, self._dev(params), self._dev(results), sp, n, burst_len, sps,
                 threshold, full_scale, soft_stride,
                 (FLAG_SLICE if slice_bits else 0) | (FLAG_EXACT_DEMOD if exact else 0) |
-                (FLAG_IDLE_DUMMY if idle_dummy else 0) | (int(_diag_mask) << 8) | few_nb_hint(host_params),
+                (FLAG_IDLE_DUMMY if idle_dummy else 0) | (int(_diag_mask) << 8) | (few_nb_hint(host_params) if hint is None else int(hint)),
                 self._stream(stream))
         _check(rc, "trxhip_detect_demod_batch")
         return results, soft
