@@ -1415,6 +1415,8 @@ gather_bursts_kernel(const unsigned long long *__restrict__ src, uint32_t *__res
 	if (b >= n)
 		return;
 	const unsigned long long a = src[b];                                   // wave-uniform: a scalar base, 32-bit lane offsets
+	if (a == 0ull)                                                         // this burst came with a run the copy engine moved
+		return;
 	const unsigned a_lo = __builtin_amdgcn_readfirstlane((unsigned)a), a_hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
 	const uint32_t *__restrict__ s = reinterpret_cast<const uint32_t *>(((unsigned long long)a_hi << 32) | a_lo);
 	uint32_t *__restrict__ d = dst + b * dwords;

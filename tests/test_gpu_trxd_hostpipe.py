@@ -656,3 +656,55 @@ def test_fused_tolerance_budget_is_frozen(trx):
           f"{worst_all:.3e} incl. noise slots detected below their samples' level; {n_diff} of {n_tot} TRXD soft bytes differ ({n_diff / n_tot:.2e})")
     assert worst_rel <= 7e-5, (worst_rel, worst_all)
     assert n_diff / n_tot <= 3e-5, (n_diff, n_tot)
+
+
+@pytest.mark.parametrize("layout", ["contiguous", "strided", "runs_and_scatter", "short_runs"])
+def test_hostpipe_by_reference_runs(trx, layout):
+    """Run coalescing of trxhip_hostpipe_submit_by_ref (csrc/trx_hostpipe.cpp): addresses a constant step apart -- the consecutive
+    bursts a radio cuts from one buffer (radioInterface.cpp:272-291) -- go to the copy engine as one (2-D) copy per run, the
+    fetch kernel keeps the rest.  Whatever the split, the slot's results, soft rows and datagrams equal the staged submit's:
+    one long run; a run whose step is wider than a burst; long runs between scattered bursts and a backward step; runs shorter
+    than the threshold (all kernel)."""
+    from osmo_trx_amd.trxhip import HostPipe
+    n, max_bursts = 1200, 2048
+    iq, params, meta = mixed_workload(n)
+    iq = iq.numpy().reshape(n, 625, 2)
+    params, meta = params[:n], meta[:n]
+    pipe = HostPipe(trx, max_bursts, depth=2, soft_stride=148, pkt_stride=160, rssi_offset=0.5)
+    v = pipe.slot(0)
+    v["iq"][:n] = iq
+    v["params"][:n] = params
+    v["meta"][:n] = meta
+    pipe.submit(0, n)
+    pipe.wait(0)
+    want = {k: v[k][:n].copy() for k in ("results", "soft", "pkt", "pkt_len")}
+    burst = 625 * 2                                                      # int16 per burst
+    rng = np.random.default_rng(11)
+    if layout == "contiguous":
+        pos = np.arange(n) * burst
+    elif layout == "strided":
+        pos = np.arange(n) * (burst + 38)                                # 76 bytes of slack between bursts: one 2-D copy
+    elif layout == "runs_and_scatter":
+        # runs of 100 / 37 / 16 bursts in forward order, the other bursts at permuted positions, and one run laid out backwards
+        pos = rng.permutation(n) * (burst + 2)
+        pos[50:150] = (2 * n + np.arange(100)) * (burst + 2)
+        pos[300:337] = (3 * n + np.arange(37)) * burst
+        pos[400:416] = (4 * n + np.arange(16)) * (burst + 2)
+        pos[600:700] = (6 * n - np.arange(100)) * (burst + 2)            # descending addresses: never a run
+    elif layout == "short_runs":
+        pos = (np.arange(n) + (np.arange(n) // 15) * 3) * burst          # runs of 15 < TRX_RUN_MIN
+    ring = np.zeros(int(pos.max()) + burst + 64, dtype=np.int16)
+    for i in range(n):
+        ring[pos[i]:pos[i] + burst] = iq[i].reshape(-1)
+    pipe.register_host(ring)
+    w = pipe.slot(1)
+    w["params"][:n] = params
+    w["meta"][:n] = meta
+    w["iq"][:] = 0
+    pipe.sources(1)[:n] = ring.ctypes.data + 2 * pos.astype(np.uint64)
+    for _ in range(2):                                                   # twice: the slot's address list is rebuilt per submit
+        pipe.submit_by_ref(1, n)
+        pipe.wait(1)
+        for k in want:
+            assert np.array_equal(w[k][:n], want[k]), (layout, k)
+    pipe.close()
