@@ -269,10 +269,12 @@ static int submit_slot(trxhip_hostpipe *p, int slot, size_t n, bool by_ref)
 	 * is device-visible; the detector fetches every sample once, one burst ahead, so the link's latency is covered the way
 	 * HBM's is and the copy engine's start-up cost -- more than such a transfer itself -- is not paid) */
 	static const size_t zc_max = getenv("TRXHIP_HOSTPIPE_ZC") ? (size_t)atol(getenv("TRXHIP_HOSTPIPE_ZC")) : 1024;   /* bursts x paths */
-	const bool in_place = !by_ref && n * np <= zc_max;
+	/* (by reference: the parameters and the TRXD meta -- 16 bytes per burst -- are read where they lie as well: a second
+	 * copy-engine transfer per batch in front of the run(s) cost 3 % of the link, profiles/r06_gather.txt) */
+	const bool in_place = by_ref || n * np <= zc_max;
 	const char *const in = in_place ? sl.dv_in : sl.d_in;
 	bool ok = in_place ||
-		  hipMemcpyAsync(sl.d_in, sl.h_in, p->in_iq_off + (by_ref ? 0 : n * np * c.burst_len * 4), hipMemcpyHostToDevice, st) == hipSuccess;
+		  hipMemcpyAsync(sl.d_in, sl.h_in, p->in_iq_off + n * np * c.burst_len * 4, hipMemcpyHostToDevice, st) == hipSuccess;
 	int rc = ok ? TRXHIP_OK : TRXHIP_EIO;
 	if (rc == TRXHIP_OK && by_ref) {
 		const size_t burst_bytes = np * (size_t)c.burst_len * 4;
@@ -288,7 +290,7 @@ static int submit_slot(trxhip_hostpipe *p, int slot, size_t n, bool by_ref)
 		if (rc == TRXHIP_OK && n_left)                             /* the rest, fetched through their pointers by the device */
 			rc = trx_launch_gather_bursts(sl.dv_src_dev, sl.d_iq, n, (unsigned)(np * (size_t)c.burst_len), st);
 	}
-	const int16_t *d_bursts = reinterpret_cast<const int16_t *>(in + p->in_iq_off);
+	const int16_t *d_bursts = by_ref ? sl.d_iq : reinterpret_cast<const int16_t *>(in + p->in_iq_off);
 	const trxhip_burst_params *const d_params = reinterpret_cast<const trxhip_burst_params *>(in);
 	const trxhip_trxd_meta *const d_meta = reinterpret_cast<const trxhip_trxd_meta *>(in + p->in_meta_off);
 	if (rc == TRXHIP_OK && np > 1) {                              /* Transceiver.cpp:723-741: the path with the highest energy */
