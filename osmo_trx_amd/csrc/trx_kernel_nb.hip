@@ -39,6 +39,16 @@
 
 
 
+// Wave priority by phase: a nibble per point of the burst loop (0: loop top, 1: in front of DEC, 2: of DETA, 3: of TAIL, 4: behind
+// TAIL), 15 = no instruction.  The demodulator's filter (TAIL) is the one phase that is dense in vector work -- 72 packed FMAs back
+// to back; everything else is chains of LDS round trips and scalar glue.  With the filter at priority 0 and the rest at 2, a wave
+// that comes out of a wait gets the next issue slot and the filter waves fill what is left: +0.5 % same box (5 rounds, three
+// alternatives within +-0.3 % of it: profiles/r06_ab_runs.txt).  Measurement builds: tools/build_variants.py name:-DTRX_NB_PRIO=k.
+#ifndef TRX_NB_PRIO
+#define TRX_NB_PRIO 0x20fff
+#endif
+#define NB_PRIO(point) do { if (((TRX_NB_PRIO >> (4 * (point))) & 15) != 15) \
+	asm volatile("s_setprio %0" :: "n"((TRX_NB_PRIO >> (4 * (point))) & 3)); } while (0)
 typedef float v3f __attribute__((ext_vector_type(3)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 
@@ -371,6 +381,7 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 	unsigned j_next = 0, b_next = NB_NO_BURST;
 	for (unsigned b = b_first; b != NB_NO_BURST; b = b_next) {
 		int lane;                                                  // re-materialised per burst (see burst_pull4_kernel)
+		NB_PRIO(0);
 		asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
 		const int ticket = claim_issue(wg_next);
 		const unsigned prm0 = (unsigned)uni((int)pre_prm);
@@ -450,6 +461,7 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 			// (hand-placed blocks: tools/gen_nb_asm.py)  decimator of the window + the addition-only correlation's guard
 			const unsigned vd_addr = lds_addr(D) + 8u * (unsigned)lane, vcz_addr = lds_addr(cz) + 8u * (unsigned)lane;
 			unsigned long long bad;
+			NB_PRIO(1);
 			asm volatile(NB_ASM_DEC
 				     : [bad] "=s"(bad)
 				     : [pd] "v"(lds_addr(P + PH_M0 + 52) + 8u * (unsigned)lane), [vd] "v"(vd_addr), [zero] "v"(0), [nact] "s"(15 + len)
@@ -482,6 +494,7 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 					// edge gate, peak-ratio gate, round A of the TOA bisection and its walk (DETA); round B, walk, peak value (DETB)
 					int st, e512;
 					float km;
+					NB_PRIO(2);
 					asm volatile(NB_ASM_DETA
 						     : [st] "=&s"(st), [e] "=&s"(e512), [km] "=&v"(km)
 						     : [bidx] "s"(bidx), [len] "s"(len), [czb] "s"(lds_addr(cz)), [kr] "v"(kr), [ka] "v"(ka), [l16] "v"(16 * lane),
@@ -520,6 +533,7 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 						int ok, s_bits;
 						float d0, d1, d2;
 						const int t5 = (t5pk << (28 - 4 * tsc)) >> 28;
+						NB_PRIO(3);
 						asm volatile(NB_ASM_TAIL
 							     : [ok] "=&s"(ok), [ssum] "=&s"(s_bits), [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2)
 							     : [toa] "s"(toa512), [xr] "s"(xr_bits), [xi] "s"(xi_bits), [t5] "s"(t5), [hdrb] "s"(lds_addr(lhdr) + 32u * (unsigned)tsc),
@@ -528,6 +542,7 @@ nb_pull4_kernel(const uint32_t *__restrict__ iq, const trxhip_burst_params *__re
 							       [kic] "v"(kic), [ktp] "v"(ktp)
 							     : NB_ASM_CLOBBERS);
 						DIAG_MARK(10);
+						NB_PRIO(4);
 						if (!ok) {
 							// TOA outside the straight-line geometry (an early burst, or one later than 9 symbols): the general form
 							if (lane == 0) atomicAdd(&g_trx_fast_stats[3], 1ull);
