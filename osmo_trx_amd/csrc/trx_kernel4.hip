@@ -93,6 +93,13 @@ __device__ __forceinline__ int cdiv4(int a) { return (a + 3) >> 2; }
 // once.  A wave scans the flags 256 at a time (one dword per lane; chunks gw, gw + waves, ...), clears what it read and works
 // through the set ones; the next burst is known when the current one is prefetched, as in the claiming form.
 #define TRX_REDO_HDR 16                   /* words: [0] anything left, [1] workgroups done (this kernel); flag bytes behind them */
+// wave priority: the demodulator's filters at 0, everything else at 2 (measured on the normal-burst kernel: trx_kernel_nb.hip;
+// here: profiles/r06_ab_runs.txt section 8).  -DTRX_K4_NO_PRIO: measurement build without it.
+#ifdef TRX_K4_NO_PRIO
+#define K4_PRIO(p)
+#else
+#define K4_PRIO(p) asm volatile("s_setprio %0" :: "n"(p))
+#endif
 template <bool CF32, bool EXACT, bool COMMON, bool LIST = false>
 __global__ void __launch_bounds__(K4_WPB(CF32, EXACT) * WAVE)
 burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__restrict__ params,
@@ -792,6 +799,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 		};
 		bool record_done = false;
 		// ---- demodAnyBurst -> demodGmskBurst (:2055-2072) ----
+		K4_PRIO(0);                                                 // the filters: dense vector work, lowest priority (see trx_kernel_nb.hip)
 		if (COMMON && !EXACT && rc == TRXHIP_TSC && fast_nk != (1 << 30) && !fast_done && !ABL(0)) {
 #ifndef TRX_LATE_RECORD
 			nbits = 148;                                                // (what fast_demod() sets)
@@ -1160,6 +1168,7 @@ burst_pull4_kernel(const void *__restrict__ iq_, const trxhip_burst_params *__re
 		}
 
 		DIAG_MARK(11);
+		K4_PRIO(2);
 		if (!record_done)
 			assemble_record();
 		DIAG_MARK(12);
