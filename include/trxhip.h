@@ -368,7 +368,11 @@ int  trxhip_hostpipe_query(trxhip_hostpipe *p, int slot);
  * Contract: every src[i] is 4-byte aligned and lies, with its whole burst, inside one registered range (TRXHIP_EINVAL
  * otherwise, nothing enqueued); the samples stay unchanged until wait() on the slot has returned.
  * register_host: pins [base, base + bytes) and maps it into the device's address space (hipHostRegister; a range some
- * other pipe of the process has registered already is shared); at most 8 ranges per pipe; unregister_host (or destroy)
+ * other pipe of the process has registered already is shared -- accepted only if that registration is mapped and covers
+ * the whole range, TRXHIP_EINVAL otherwise; the sharing pipe does not own the pin: whoever registered first must outlive
+ * every pipe that shares the range, which is how a multi-device gatherer destroys its pipes -- in reverse order of creation);
+ * round 6: runs of 16 or more addresses a constant step apart are moved by the copy engine (one copy per run), the rest by
+ * the fetch kernel; at most 8 ranges per pipe; unregister_host (or destroy)
  * releases what this pipe pinned -- before the memory is freed, and with no slot that refers to the range in flight.
  * register / unregister are not synchronised against submits of the same pipe on other threads. */
 int  trxhip_hostpipe_register_host(trxhip_hostpipe *p, const void *base, size_t bytes);

@@ -384,6 +384,20 @@ int trxhip_hostpipe_register_host(trxhip_hostpipe *p, const void *base, size_t b
 			(void)hipHostUnregister(const_cast<void *>(base));
 		return TRXHIP_EIO;
 	}
+	if (e == hipErrorHostMemoryAlreadyRegistered) {
+		/* someone else's registration: it must be mapped into the device and cover the WHOLE range -- the fetch kernel and the
+		 * copy engine would fault on the first burst behind its end otherwise.  Checked on the flags and on the
+		 * device address of the range's last byte, which must continue the first one's. */
+		unsigned fl = 0;
+		void *dv_last = nullptr;
+		const char *const last = static_cast<const char *>(base) + (bytes - 1);
+		if (hipHostGetFlags(&fl, const_cast<void *>(base)) != hipSuccess || !(fl & hipHostRegisterMapped) ||
+		    hipHostGetDevicePointer(&dv_last, const_cast<char *>(last), 0) != hipSuccess ||
+		    static_cast<char *>(dv_last) != static_cast<char *>(dv) + (bytes - 1)) {
+			(void)hipGetLastError();
+			return TRXHIP_EINVAL;
+		}
+	}
 	trxhip_hostpipe::Region &g = p->region[p->n_region++];
 	g.base = static_cast<const char *>(base);
 	g.bytes = bytes;

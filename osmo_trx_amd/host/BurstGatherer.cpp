@@ -172,7 +172,9 @@ struct BurstGatherer::Impl {
 	int slot_of(int b) const { return b / (int)dev.size(); }
 	void release_devices()
 	{
-		for (Dev &d : dev) {
+		/* in reverse order of creation: the first pipe pinned the registered ranges, the others share its pin (include/trxhip.h) */
+		for (size_t k = dev.size(); k-- > 0;) {
+			Dev &d = dev[k];
 			if (d.pipe) trxhip_hostpipe_destroy(d.pipe);
 			if (d.own_ctx && d.ctx) trxsigproc_destroy_context(d.ctx);
 		}
@@ -452,8 +454,11 @@ bool BurstGatherer::start()
 	m.free_q.clear(); m.closed_q.clear(); m.flight_q.clear();
 	for (int s = 0; s < n_batch; s++) {
 		trxhip_hostpipe_slot_buffers(m.pipe_of(s), m.slot_of(s), &m.batch[s].h);
-		if (m.cfg.by_reference && trxhip_hostpipe_slot_sources(m.pipe_of(s), m.slot_of(s), &m.batch[s].src) != TRXHIP_OK)
+		if (m.cfg.by_reference && trxhip_hostpipe_slot_sources(m.pipe_of(s), m.slot_of(s), &m.batch[s].src) != TRXHIP_OK) {
+			m.batch.clear();
+			m.release_devices();                                   /* (release_devices() takes no lock: contexts and pipes only) */
 			return false;
+		}
 		m.batch[s].slot = std::vector<Slot>(m.cfg.max_batch);
 		for (size_t k = 0; k < m.cfg.max_batch; k++)
 			m.batch[s].slot[k].ready.store(0, std::memory_order_relaxed);
