@@ -192,6 +192,19 @@ struct BurstGatherer::Impl {
 	bool submitter_done = false;                /* under mu: nothing more will enter flight_q */
 	std::thread submitter;
 	std::vector<std::thread> completers;        /* one per device entry (or cfg.n_completers): see complete_loop() */
+	size_t n_compl_active = 0;                  /* set by start() before the completion threads exist */
+	std::mutex deliver_mu;                      /* sleepers of the delivery order (several completers only) */
+	std::condition_variable cv_deliver;
+	/* hand channel `ch`'s ring to the batch with sequence number `next`; wakes a completer that sleeps for its turn (the empty
+	 * critical section orders the store against a sleeper's predicate check: no lost wake-up) */
+	void pass_turn(Chan &ch, uint64_t next)
+	{
+		ch.deliver_seq.store(next, std::memory_order_release);
+		if (n_compl_active > 1) {
+			{ std::lock_guard<std::mutex> lk(deliver_mu); }
+			cv_deliver.notify_all();
+		}
+	}
 	uint64_t next_seq = 0;                      /* under mu */
 	std::atomic<uint64_t> n_batches{0}, n_dropped{0}, n_rejected{0};
 
@@ -300,10 +313,19 @@ struct BurstGatherer::Impl {
 				/* Several completion threads: each has waited for its own batch and sorted it on its own; the rings are
 				 * written in ticket order, channel by channel -- the thread of batch k + 1 follows one channel behind the
 				 * thread of batch k.  (One thread: the ticket is always the ring's turn.) */
-				for (unsigned spin = 0; ch.deliver_seq.load(std::memory_order_acquire) != seq; spin++)
-					if (spin > 64) std::this_thread::yield();
+				if (ch.deliver_seq.load(std::memory_order_acquire) != seq) {
+					/* a short spin (the thread ahead is usually one channel away), then SLEEP: it can be a whole GPU batch
+					 * ahead when devices finish out of order, and the producers need the CPU */
+					unsigned spin = 0;
+					while (ch.deliver_seq.load(std::memory_order_acquire) != seq && ++spin < 256)
+						;
+					if (ch.deliver_seq.load(std::memory_order_acquire) != seq) {
+						std::unique_lock<std::mutex> lk(deliver_mu);
+						cv_deliver.wait(lk, [&] { return ch.deliver_seq.load(std::memory_order_acquire) == seq; });
+					}
+				}
 				if (first[c] == first[c + 1]) {
-					ch.deliver_seq.store(seq + 1, std::memory_order_release);
+					pass_turn(ch, seq + 1);
 					continue;
 				}
 				size_t tail = ch.tail.load(std::memory_order_relaxed);
@@ -330,7 +352,7 @@ struct BurstGatherer::Impl {
 					}
 				}
 				ch.tail.store(tail, std::memory_order_seq_cst);          /* publish; then look for a sleeping consumer */
-				ch.deliver_seq.store(seq + 1, std::memory_order_release);
+				pass_turn(ch, seq + 1);
 				if (ch.waiting.load(std::memory_order_seq_cst)) {
 					std::lock_guard<std::mutex> g(ch.mu);
 					ch.cv.notify_one();
@@ -487,6 +509,7 @@ bool BurstGatherer::start()
 	size_t n_compl = m.cfg.n_completers > 0 ? (size_t)m.cfg.n_completers : m.dev.size();
 	if (const char *e = getenv("TRXHIP_COMPLETERS")) if (atoi(e) > 0) n_compl = (size_t)atoi(e);
 	if (n_compl > 16) n_compl = 16;
+	m.n_compl_active = n_compl;
 	m.completers.clear();
 	for (size_t k = 0; k < n_compl; k++)
 		m.completers.emplace_back([&m] { m.complete_loop(); });
